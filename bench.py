@@ -1,0 +1,223 @@
+#!/usr/bin/env python
+"""Headline benchmark: vision tokens reduced per second by one FrameFusion.forward merge call on
+synthetic [1, 64 frames x 576 tokens, 4096] bf16 activations (BASELINE.json configs[1], "C2").
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = prepare() + one FrameFusion.forward call (K0 order, K1 similarity, K2/K3 plan, K4
+merge+compaction, one 128-byte readback) on one video sample resident in HBM.  With N ranks each
+rank reduces its own independent sample (seed + rank): weak scaling, no data-path collective.
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (live hipEvent timing on the
+launch stream, algorithmic bytes from DESIGN.md); `cpu_baseline` times the CPU oracle
+(oracle/ff_oracle.py, a torch-CPU port of the reference path) on the same input.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FRAMES, PATCHES, DIM, HEAD_DIM = 64, 576, 4096, 128
+COST, THRESHOLD, RATIO_LB = 0.3, 0.6, 0.1          # reference operating point (README.md:123)
+P_CHANGE, SIGMA = 0.2, 0.3                         # top-k regime 36864 -> 11060
+HBM_PEAK_GBS = 8000.0                              # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--frames", type=int, default=FRAMES)
+    ap.add_argument("--patches", type=int, default=PATCHES)
+    ap.add_argument("--dim", type=int, default=DIM)
+    ap.add_argument("--p-change", type=float, default=P_CHANGE)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-calls", type=int, default=5)
+    return ap.parse_args()
+
+
+def algorithmic_bytes(L_in, L_out, nv, d, elt, head_dim, pe_outer=1):
+    """DESIGN.md §Roofline / SURVEY.md §8d: compulsory HBM traffic of one merge call."""
+    hidden_in = L_in * d * elt
+    hidden_out = L_out * d * elt
+    pos = 2 * (L_in + L_out) * head_dim * elt * pe_outer
+    ints = 8 * (L_in + L_out)
+    return dict(step=hidden_in + hidden_out + pos + ints,
+                similarity=nv * d * elt + nv * elt,
+                merge_compact=hidden_in + hidden_out + pos + ints)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    elif args.gpus > 1:
+        print("bench.py: --gpus > 1 must be launched with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import framefusion_amd as ffa
+    from framefusion_amd import _lib
+    from framefusion_amd.synth import video_tokens, rotary_tables
+
+    F, P, d = args.frames, args.patches, args.dim
+    hidden, ptype = video_tokens(F, P, d, p_change=args.p_change, sigma=SIGMA, seed=1234 + rank,
+                                 dtype=torch.bfloat16, device=str(dev))
+    L = hidden.shape[1]
+    cos, sin = rotary_tables(L, HEAD_DIM, torch.bfloat16, device=str(dev))
+    ff = ffa.FrameFusion(COST, THRESHOLD, RATIO_LB)
+
+    def step():
+        ff.prepare(ptype, P, 0, L, L, L)
+        out, pos, _ = ff(hidden, [cos, sin], None)
+        return out
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    L_out = out.shape[1]
+    info = ff.last_call
+    reduced = L - L_out
+
+    # whole-job numbers: max time over ranks, tokens summed over ranks
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tok = torch.tensor([float(reduced * args.steps)], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tok, op=dist.ReduceOp.SUM)
+    t_max, tok_all = float(t), float(tok)
+
+    result = None
+    if rank == 0:
+        # ---- per-kernel timing with events on the launch stream (stage entry points) -------------
+        lib = _lib.load()
+        sc = ff._scratch[(dev.type, dev.index)]
+        stream = _lib.stream_ptr()
+        elt = hidden.element_size()
+        nv = info["nv"]
+        sim = sc.sim(hidden.dtype, L)
+        out_buf = torch.empty(1, L, d, dtype=hidden.dtype, device=dev)
+        ptype_out = torch.empty(1, L, dtype=torch.int64, device=dev)
+        cos_o, sin_o = torch.empty_like(cos), torch.empty_like(sin)
+        aux = (_lib.FFAux * _lib.MAX_AUX)()
+        aux[0] = _lib.FFAux(ptype.data_ptr(), ptype_out.data_ptr(), 8, 1)
+        aux[1] = _lib.FFAux(cos.data_ptr(), cos_o.data_ptr(), HEAD_DIM * elt, 1)
+        aux[2] = _lib.FFAux(sin.data_ptr(), sin_o.data_ptr(), HEAD_DIM * elt, 1)
+        thr = float(torch.tensor(THRESHOLD, dtype=hidden.dtype))
+        sub = float(ff._compute_pruning_ratio([], COST))
+        stages = {
+            "order": lambda: lib.ff_build_order(ptype.data_ptr(), L, P, sc.order.data_ptr(), sc.stats.data_ptr(),
+                                                None, 0, stream),
+            "similarity": lambda: lib.ff_pair_similarity(hidden.data_ptr(), _lib.FF_BF16, L, d, ptype.data_ptr(),
+                                                         sc.order.data_ptr(), sc.stats.data_ptr(), sim.data_ptr(), stream),
+            "plan": lambda: lib.ff_plan_merge(sim.data_ptr(), _lib.FF_BF16, sc.order.data_ptr(), L, thr, sub, RATIO_LB,
+                                              sc.run_len.data_ptr(), sc.dst.data_ptr(), sc.keep.data_ptr(),
+                                              sc.stats.data_ptr(), sc.ws.data_ptr(), sc.ws_bytes, stream),
+            "merge_compact": lambda: lib.ff_merge_compact(hidden.data_ptr(), out_buf.data_ptr(), _lib.FF_BF16, L, d, L,
+                                                          sc.order.data_ptr(), sc.run_len.data_ptr(), sc.dst.data_ptr(),
+                                                          aux, 3, stream),
+        }
+        reps = max(10, min(args.steps, 50))
+        kernel_us = {}
+        for name, fn in stages.items():
+            for _ in range(3):
+                _lib.check(fn(), name)
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+            for a, b in ev:
+                a.record()
+                _lib.check(fn(), name)
+                b.record()
+            torch.cuda.synchronize()
+            kernel_us[name] = sum(a.elapsed_time(b) for a, b in ev) / reps * 1e3
+        alg = algorithmic_bytes(L, L_out, nv, d, elt, HEAD_DIM)
+        dominant = max(("similarity", "merge_compact"), key=lambda k: kernel_us[k])
+        achieved = alg[dominant] / (kernel_us[dominant] * 1e-6) / 1e9
+        ms_per_step = t_max / args.steps * 1e3
+        result = {
+            "metric": "vision tokens reduced/sec (64 frames x 576 tok, d=4096 bf16)",
+            "value": tok_all / t_max,
+            "unit": "tokens/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": f"C2: one FrameFusion.forward merge call on [1, {F}x{P}, {d}] bf16, "
+                                   f"cost={COST} thr={THRESHOLD} lb={RATIO_LB}, p_change={args.p_change} "
+                                   f"({'top-k' if info['branch'] else 'threshold'} branch), one sample per GPU",
+                       "tokens_in": L, "tokens_out": L_out, "tokens_processed_per_s": world * L * args.steps / t_max,
+                       "parallelism": f"dp{world} (independent samples)"},
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes": alg[dominant], "kernel_us": kernel_us[dominant]},
+            "kernels_us": kernel_us,
+            "step_roofline": {"algorithmic_bytes": alg["step"], "achieved": alg["step"] / (ms_per_step * 1e-3) / 1e9,
+                              "frac": alg["step"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        }
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(hidden, ptype, cos, sin, P, L, args.cpu_calls)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+def cpu_baseline(hidden, ptype, cos, sin, P, L, calls):
+    """The reference's torch-CPU path, as restated in oracle/ff_oracle.py ("port"), on this box's
+    host cores: `calls` merge calls on the same sample (bounded: ~0.5-1 s each)."""
+    from oracle import ff_oracle as orc
+    h, pt, c, s = hidden.cpu(), ptype.cpu(), cos.cpu(), sin.cpu()
+    threads = torch.get_num_threads()
+
+    def one():
+        f = orc.OracleFrameFusion(COST, THRESHOLD, RATIO_LB)
+        f.prepare(pt, P, 0, L, L, L)
+        o, _, _ = f.forward(h, [c, s], None)
+        return o.shape[1]
+
+    one()
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        lo = one()
+    dt = time.perf_counter() - t0
+    return {"value": (L - lo) * calls / dt, "unit": "tokens/s", "cores": threads, "kind": "port",
+            "sample": f"{calls} merge calls of the CPU oracle on the same [1, {L}, {hidden.shape[2]}] bf16 sample "
+                      f"({dt / calls * 1e3:.0f} ms per call, torch {torch.__version__} CPU, {os.cpu_count()} logical cores)"}
+
+
+if __name__ == "__main__":
+    main()

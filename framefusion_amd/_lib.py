@@ -1,0 +1,110 @@
+"""ctypes binding of libframefusion_hip.so (the C ABI declared in include/framefusion_hip.h).
+
+There is no fallback: if the library is missing or fails to load, every product entry point
+raises.  ``import torch`` happens first on purpose - the HIP runtime PyTorch-ROCm has already
+loaded (SONAME libamdhip64.so.7) is then the one the kernels run on, so ``tensor.data_ptr()`` and
+``torch.cuda.current_stream().cuda_stream`` are directly usable across the boundary.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import torch  # noqa: F401  (must precede the CDLL below)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libframefusion_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+FF_F32, FF_BF16, FF_F16 = 0, 1, 2
+DTYPE_CODE = {torch.float32: FF_F32, torch.bfloat16: FF_BF16, torch.float16: FF_F16}
+
+(STAT_NV, STAT_FTN, STAT_COUNT, STAT_BRANCH, STAT_K, STAT_MERGED, STAT_LOUT, STAT_BELOW_LB,
+ STAT_KTH_KEY, STAT_TIES_TAKEN, STAT_SEQ) = range(11)
+STAT_WORDS = 16
+MAX_AUX = 4
+ABI_VERSION = 1
+
+
+class FFAux(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("row_bytes", C.c_int64), ("outer", C.c_int64)]
+
+
+class FrameFusionHipError(RuntimeError):
+    pass
+
+
+_vp, _i64, _i32, _f64, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/framefusion_hip.h one to one
+PROTOTYPES = {
+    "ff_abi_version": (C.c_int, []),
+    "ff_error_string": (C.c_char_p, [_i32]),
+    "ff_workspace_bytes": (_sz, [_i64, _i64]),
+    "ff_build_order": (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "ff_pair_similarity": (_i32, [_vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "ff_plan_merge": (_i32, [_vp, _i32, _vp, _i64, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ff_plan_from_index": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ff_plan_prune": (_i32, [_vp, _i32, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ff_merge_compact": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp, C.POINTER(FFAux), _i32, _vp]),
+    "ff_gather_mask": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "ff_head_mean": (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _vp]),
+    "ff_last_query_attention": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _i64, _i64, _f64, _i32, _vp, _vp, _vp,
+                                       _sz, _vp]),
+    "ff_merge_step": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _i64, _i32, _f64, _f64, _f64, _vp, _vp, _vp,
+                             _vp, _vp, _vp, _vp, _i64, C.POINTER(FFAux), _i32, _vp, _sz, _vp]),
+}
+
+_lib = None
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the HIP sources in csrc/ for gfx950 (hipcc cross-compiles without a GPU)."""
+    res = subprocess.run(["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 1))],
+                         capture_output=True, text=True)
+    if verbose or res.returncode:
+        print(res.stdout[-4000:])
+        print(res.stderr[-4000:])
+    if res.returncode:
+        raise FrameFusionHipError("building libframefusion_hip.so failed (see output above)")
+    return LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FrameFusionHipError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"(or `make -C {CSRC}`). framefusion_amd has no CPU/eager fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise FrameFusionHipError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
+        fn.restype, fn.argtypes = res, args
+    got = lib.ff_abi_version()
+    if got != ABI_VERSION:
+        raise FrameFusionHipError(f"ABI mismatch: library {got}, binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().ff_error_string(rc)
+        raise FrameFusionHipError(f"{what} failed: [{rc}] {msg.decode() if msg else '?'}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise FrameFusionHipError(
+            f"{what}: framefusion_amd runs on MI355X only (got a {t.device.type} tensor); "
+            "there is no CPU path in the product - the CPU oracle lives in oracle/ for tests.")

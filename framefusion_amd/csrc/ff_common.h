@@ -1,0 +1,161 @@
+// Shared device helpers for the gfx950 kernels of libframefusion_hip.so.
+// Compiled with -ffp-contract=off: every rounding below is placed by hand because the reference's
+// results are defined by where it rounds to the activation dtype.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "framefusion_hip.h"
+
+namespace ff {
+
+constexpr int kWave = 64;  // gfx950 wavefront
+
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
+// ---- activation dtype traits ---------------------------------------------------------------
+// PER16: elements per 16-byte lane load.  rnd(x): x rounded to T (RNE), returned as float.
+template <int DT> struct Act;
+
+template <> struct Act<FF_F32> {
+    static constexpr int kPer16 = 4;
+    static constexpr int kBytes = 4;
+    static constexpr int kKeyBits = 32;
+    __device__ static inline float rnd(float x) { return x; }
+    __device__ static inline void unpack(const uint4& v, float* f) {
+        f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y);
+        f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+    }
+    __device__ static inline uint4 pack(const float* f) {
+        return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+    }
+    __device__ static inline float load1(const void* p, int64_t idx) { return ((const float*)p)[idx]; }
+    __device__ static inline void store1(void* p, int64_t idx, float x) { ((float*)p)[idx] = x; }
+    __device__ static inline uint32_t bits1(const void* p, int64_t idx) { return ((const uint32_t*)p)[idx]; }
+};
+
+template <> struct Act<FF_BF16> {
+    static constexpr int kPer16 = 8;
+    static constexpr int kBytes = 2;
+    static constexpr int kKeyBits = 16;
+    __device__ static inline float rnd(float x) { return (float)(__bf16)x; }  // v_cvt_pk_bf16_f32 (RNE)
+    __device__ static inline void unpack(const uint4& v, float* f) {
+        f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+        f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+        f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+        f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+    }
+    // inputs are already T-valued floats (low 16 bits zero)
+    __device__ static inline uint4 pack(const float* f) {
+        return make_uint4((__float_as_uint(f[0]) >> 16) | (__float_as_uint(f[1]) & 0xffff0000u),
+                          (__float_as_uint(f[2]) >> 16) | (__float_as_uint(f[3]) & 0xffff0000u),
+                          (__float_as_uint(f[4]) >> 16) | (__float_as_uint(f[5]) & 0xffff0000u),
+                          (__float_as_uint(f[6]) >> 16) | (__float_as_uint(f[7]) & 0xffff0000u));
+    }
+    __device__ static inline float load1(const void* p, int64_t idx) {
+        return __uint_as_float((uint32_t)((const uint16_t*)p)[idx] << 16);
+    }
+    __device__ static inline void store1(void* p, int64_t idx, float x) {
+        ((uint16_t*)p)[idx] = (uint16_t)(__float_as_uint(rnd(x)) >> 16);
+    }
+    __device__ static inline uint32_t bits1(const void* p, int64_t idx) { return ((const uint16_t*)p)[idx]; }
+};
+
+template <> struct Act<FF_F16> {
+    static constexpr int kPer16 = 8;
+    static constexpr int kBytes = 2;
+    static constexpr int kKeyBits = 16;
+    __device__ static inline float rnd(float x) { return (float)(_Float16)x; }  // v_cvt_f16_f32 (RNE)
+    __device__ static inline void unpack2(uint32_t w, float* f) {
+        half2_t h = __builtin_bit_cast(half2_t, w);
+        f[0] = (float)h.x; f[1] = (float)h.y;
+    }
+    __device__ static inline void unpack(const uint4& v, float* f) {
+        unpack2(v.x, f); unpack2(v.y, f + 2); unpack2(v.z, f + 4); unpack2(v.w, f + 6);
+    }
+    __device__ static inline uint32_t pack2(float a, float b) {
+        half2_t h; h.x = (_Float16)a; h.y = (_Float16)b;
+        return __builtin_bit_cast(uint32_t, h);
+    }
+    __device__ static inline uint4 pack(const float* f) {
+        return make_uint4(pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7]));
+    }
+    __device__ static inline float load1(const void* p, int64_t idx) { return (float)((const _Float16*)p)[idx]; }
+    __device__ static inline void store1(void* p, int64_t idx, float x) { ((_Float16*)p)[idx] = (_Float16)x; }
+    __device__ static inline uint32_t bits1(const void* p, int64_t idx) { return ((const uint16_t*)p)[idx]; }
+};
+
+// Order-preserving unsigned key of a T value given its raw bits: larger value <=> larger key;
+// every NaN maps to the maximum (torch.topk ranks NaN highest).
+template <int DT> __device__ inline uint32_t order_key(uint32_t bits);
+template <> __device__ inline uint32_t order_key<FF_F32>(uint32_t b) {
+    if ((b & 0x7fffffffu) > 0x7f800000u) return 0xffffffffu;
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+template <> __device__ inline uint32_t order_key<FF_BF16>(uint32_t b) {
+    if ((b & 0x7fffu) > 0x7f80u) return 0xffffu;
+    return (b & 0x8000u) ? (~b & 0xffffu) : (b | 0x8000u);
+}
+template <> __device__ inline uint32_t order_key<FF_F16>(uint32_t b) {
+    if ((b & 0x7fffu) > 0x7c00u) return 0xffffu;
+    return (b & 0x8000u) ? (~b & 0xffffu) : (b | 0x8000u);
+}
+
+// ---- wave / block primitives (wave = 64 lanes) -------------------------------------------------
+__device__ inline int lane_id() { return threadIdx.x & (kWave - 1); }
+__device__ inline int wave_id() { return threadIdx.x >> 6; }
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+__device__ inline int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+__device__ inline int wave_incl_scan(int v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        int t = __shfl_up(v, o, kWave);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// Exclusive scan of one int per thread across a block of NW waves; `total` = block sum.
+// `scratch` = NW + 1 ints of LDS; safe to call back to back (two barriers inside).
+template <int NW>
+__device__ inline int block_excl_scan(int v, int* scratch, int& total) {
+    const int incl = wave_incl_scan(v);
+    const int w = wave_id();
+    if (lane_id() == kWave - 1) scratch[w] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        const int s = scratch[k];
+        base += (k < w) ? s : 0;
+        tot += s;
+    }
+    __syncthreads();
+    total = tot;
+    return base + incl - v;
+}
+
+template <int NW>
+__device__ inline int block_sum_i(int v, int* scratch) {
+    v = wave_sum_i(v);
+    if (lane_id() == 0) scratch[wave_id()] = v;
+    __syncthreads();
+    int tot = 0;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) tot += scratch[k];
+    __syncthreads();
+    return tot;
+}
+
+}  // namespace ff

@@ -1,0 +1,129 @@
+// K5 - attention probabilities of the last `num` queries and their head mean: the only extra work
+// FrameFusion adds inside the attention module (framefusion/utils.py:27-57, called from
+// models/qwen2/modeling_qwen2.py:166-178 with num=1 and modeling_qwen2_vl.py:292-300 with num=4),
+// feeding the prune of main.py:69-92.
+//
+// The reference repeats K to all H heads first (repeat_kv, modeling_qwen2.py:147) and materialises
+// a [1, H, num, S] tensor; here one workgroup reads a 64-key tile of ONE kv head once and scores it
+// against every query head of the GQA group, so K traffic is H_kv*S*dh*sizeof(T) (11 MB at
+// S = 11k, H_kv = 4, dh = 128), negligible next to the activation passes.
+//
+// Staged rounding, T = activation dtype:
+//   s = T(sum_fp32 q_i*k_i);  s = T(fp32(s) * fp32(scale));  s = T(s + bias);  p = T(exp(s - max) / sum)
+#include "ff_common.h"
+
+namespace ff {
+
+// scores[h, n, s] as float holding T values.  grid: (ceil(S/64), H_kv); block 256 = 4 waves, each
+// wave takes 16 keys of the tile, a key row is spread over the 64 lanes.
+template <int DT>
+__global__ __launch_bounds__(256) void k_lq_scores(const void* __restrict__ q, const void* __restrict__ k,
+                                                   int H, int H_kv, int num, int S, int dh, float scale,
+                                                   int causal, float* __restrict__ scores) {
+    using A = Act<DT>;
+    extern __shared__ __attribute__((aligned(16))) float q_lds[];   // [group*num][dh]
+    const int hk = blockIdx.y;
+    const int group = H / H_kv;
+    const int rows = group * num;
+    for (int x = threadIdx.x; x < rows * dh; x += blockDim.x) {
+        const int r = x / dh, e = x - r * dh;
+        const int h = hk * group + r / num, n = r % num;
+        q_lds[x] = A::load1(q, ((int64_t)h * num + n) * dh + e);
+    }
+    __syncthreads();
+    const int lane = lane_id(), w = wave_id();
+    const int s_base = blockIdx.x * 64 + w * 16;
+    for (int ks = 0; ks < 16; ++ks) {
+        const int s = s_base + ks;
+        if (s >= S) break;
+        const int64_t krow = ((int64_t)hk * S + s) * dh;
+        for (int r = 0; r < rows; ++r) {
+            float acc = 0.f;
+            for (int e = lane; e < dh; e += kWave)
+                acc = __builtin_fmaf(q_lds[r * dh + e], A::load1(k, krow + e), acc);
+            acc = wave_sum(acc);
+            if (lane == 0) {
+                const int h = hk * group + r / num, n = r % num;
+                float v = A::rnd(acc);
+                v = A::rnd(v * scale);
+                if (causal && s > S - num + n) v = A::rnd(v + (-INFINITY));
+                scores[((int64_t)h * num + n) * S + s] = v;
+            }
+        }
+    }
+}
+
+// One workgroup per (h, n) row: softmax over S in fp32, rounded to T.
+template <int DT>
+__global__ __launch_bounds__(256) void k_lq_softmax(const float* __restrict__ scores, int S,
+                                                    float* __restrict__ probs_f, void* __restrict__ weights) {
+    using A = Act<DT>;
+    __shared__ float red[4];
+    const int64_t base = (int64_t)blockIdx.x * S;
+    float m = -INFINITY;
+    for (int s = threadIdx.x; s < S; s += blockDim.x) m = fmaxf(m, scores[base + s]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, kWave));
+    if (lane_id() == 0) red[wave_id()] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int s = threadIdx.x; s < S; s += blockDim.x) sum += expf(scores[base + s] - m);
+    sum = wave_sum(sum);
+    if (lane_id() == 0) red[wave_id()] = sum;
+    __syncthreads();
+    sum = (red[0] + red[1]) + (red[2] + red[3]);
+    for (int s = threadIdx.x; s < S; s += blockDim.x) {
+        const float p = A::rnd(__fdiv_rn(expf(scores[base + s] - m), sum));
+        probs_f[base + s] = p;
+        if (weights) A::store1(weights, base + s, p);
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void k_lq_mean(const float* __restrict__ probs_f, int rows, int S,
+                                                 void* __restrict__ imp) {
+    using A = Act<DT>;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    float acc = 0.f;
+    for (int r = 0; r < rows; ++r) acc += probs_f[(int64_t)r * S + s];
+    A::store1(imp, s, __fdiv_rn(acc, (float)rows));
+}
+
+template <int DT>
+static int launch_lq(const void* q, const void* k, int64_t H, int64_t H_kv, int64_t num, int64_t S, int64_t dh,
+                     double scale, int causal, void* weights, void* importance, void* ws, hipStream_t st) {
+    float* scores = (float*)ws;
+    float* probs = scores + H * num * S;
+    const size_t lds = (size_t)(H / H_kv) * num * dh * sizeof(float);
+    hipLaunchKernelGGL(k_lq_scores<DT>, dim3((unsigned)((S + 63) / 64), (unsigned)H_kv), dim3(256), lds, st, q, k,
+                       (int)H, (int)H_kv, (int)num, (int)S, (int)dh, (float)scale, causal, scores);
+    hipLaunchKernelGGL(k_lq_softmax<DT>, dim3((unsigned)(H * num)), dim3(256), 0, st, scores, (int)S, probs, weights);
+    if (importance)
+        hipLaunchKernelGGL(k_lq_mean<DT>, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, probs, (int)(H * num),
+                           (int)S, importance);
+    return (int)hipGetLastError();
+}
+
+}  // namespace ff
+
+extern "C" int ff_last_query_attention(const void* q_last, const void* k, int dtype, int64_t H, int64_t H_kv,
+                                       int64_t num, int64_t S, int64_t dh, double scale, int causal,
+                                       void* weights, void* importance, void* ws, size_t ws_bytes,
+                                       ff_stream_t stream) {
+    if (!q_last || !k || !ws || H < 1 || H_kv < 1 || num < 1 || S < 1 || dh < 1) return FF_ERR_ARG;
+    if (H % H_kv) return FF_ERR_ARG;
+    if (!weights && !importance) return FF_ERR_ARG;
+    if (S >= (1ll << 31) || H * num * S >= (1ll << 40)) return FF_ERR_UNSUPPORTED;
+    if ((size_t)(H / H_kv) * num * dh * sizeof(float) > 64 * 1024) return FF_ERR_UNSUPPORTED;
+    if (ws_bytes < (size_t)(2 * H * num * S) * sizeof(float)) return FF_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+        case FF_F32: return ff::launch_lq<FF_F32>(q_last, k, H, H_kv, num, S, dh, scale, causal, weights, importance, ws, st);
+        case FF_BF16: return ff::launch_lq<FF_BF16>(q_last, k, H, H_kv, num, S, dh, scale, causal, weights, importance, ws, st);
+        case FF_F16: return ff::launch_lq<FF_F16>(q_last, k, H, H_kv, num, S, dh, scale, causal, weights, importance, ws, st);
+        default: return FF_ERR_ARG;
+    }
+}

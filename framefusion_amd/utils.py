@@ -1,0 +1,78 @@
+"""Boundary helpers with the reference's names (``framefusion/utils.py``).
+
+``scaled_dot_product_attention`` is the importance input of the prune step: the attention
+probabilities of the last ``num`` queries (utils.py:27-57).  Here it runs on the gfx950 kernel
+behind ``ff_last_query_attention`` and reads the un-repeated GQA keys directly.
+"""
+from __future__ import annotations
+
+import math
+from typing import Any
+
+import torch
+
+from . import _lib
+from ._lib import FrameFusionHipError
+
+TEXT_TOKEN = -1
+IGNORE_TOKEN = -2
+
+
+def get_attr_by_name(obj: Any, name: str) -> Any:
+    """Dotted attribute lookup with integer components indexing sequences, e.g.
+    ``get_attr_by_name(model, "llm.model.layers.0")`` (reference utils.py:13-25)."""
+    node = obj
+    for part in name.split("."):
+        node = node[int(part)] if part.isdigit() else getattr(node, part)
+    return node
+
+
+def _launch_last_query(query, key, num, is_causal, scale, want_weights, want_importance):
+    _lib.require_gpu(query, "scaled_dot_product_attention")
+    if query.ndim != 4 or key.ndim != 4 or query.shape[0] != 1 or key.shape[0] != 1:
+        raise FrameFusionHipError("expected query [1, H, L, dh] and key [1, H_kv, S, dh]")
+    lib = _lib.load()
+    H, dh = query.shape[1], query.shape[3]
+    H_kv, S = key.shape[1], key.shape[2]
+    num = min(num, query.shape[2])
+    if H % H_kv:
+        raise FrameFusionHipError(f"{H} query heads are not a multiple of {H_kv} kv heads")
+    code = _lib.DTYPE_CODE.get(query.dtype)
+    if code is None or key.dtype != query.dtype:
+        raise FrameFusionHipError(f"unsupported dtypes {query.dtype} / {key.dtype}")
+    q_last = query[0, :, -num:, :].contiguous()
+    k = key[0].contiguous()
+    factor = 1 / math.sqrt(dh) if scale is None else scale
+    dev = query.device
+    weights = torch.empty(1, H, num, S, dtype=query.dtype, device=dev) if want_weights else None
+    importance = torch.empty(S, dtype=query.dtype, device=dev) if want_importance else None
+    ws_bytes = 2 * H * num * S * 4
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    rc = lib.ff_last_query_attention(q_last.data_ptr(), k.data_ptr(), code, H, H_kv, num, S, dh, float(factor),
+                                     1 if is_causal else 0,
+                                     weights.data_ptr() if want_weights else None,
+                                     importance.data_ptr() if want_importance else None,
+                                     ws.data_ptr(), ws_bytes, _lib.stream_ptr())
+    _lib.check(rc, "ff_last_query_attention")
+    return weights, importance
+
+
+def scaled_dot_product_attention(query, key, value, num=1, attn_mask=None, dropout_p=0.0,
+                                 is_causal=False, scale=None, enable_gqa=False) -> torch.Tensor:
+    """Reference utils.py:27-57: softmax attention weights [1, H, num, S] of the last ``num``
+    queries.  ``key`` may carry H_kv < H heads whether or not ``enable_gqa`` is set (head h reads
+    kv head h // (H // H_kv), exactly what repeat_kv / repeat_interleave produce)."""
+    if attn_mask is not None:
+        raise FrameFusionHipError("attn_mask is not supported by the HIP importance kernel "
+                                  "(every reference call site passes attn_mask=None)")
+    if dropout_p != 0.0:
+        raise FrameFusionHipError("dropout_p must be 0 (prefill-time importance scoring)")
+    weights, _ = _launch_last_query(query, key, num, is_causal, scale, True, False)
+    return weights
+
+
+def last_query_importance(query, key, num=1, is_causal=True, scale=None) -> torch.Tensor:
+    """Fused form for the attention hook: the head/query mean of the weights
+    above, shaped [1, 1, 1, S] so that FrameFusion.forward's own mean (main.py:70) is the identity."""
+    _, imp = _launch_last_query(query, key, num, is_causal, scale, False, True)
+    return imp[None, None, None, :]

@@ -1,0 +1,177 @@
+/*
+ * framefusion_hip.h - C ABI of libframefusion_hip.so, the MI355X (gfx950) implementation of the
+ * FrameFusion token-reduction hot path.
+ *
+ * The reference (thu-nics/FrameFusion) is pure Python/torch and has no FFI; each entry point below
+ * replaces the torch-op sequence of one reference function (file:line relative to the reference
+ * tree) and is what a binding for that function would call.  The Python host in framefusion_amd/
+ * binds them with ctypes (see INTEGRATION.md for the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; raw sizes, no torch types;
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t; 0 = the null stream): no
+ *     allocation, no synchronisation, no host read of device data; outputs are caller-allocated;
+ *   - return value: 0 = OK, <0 = FF_ERR_* (bad argument, nothing enqueued), >0 = hipError_t;
+ *   - dtype codes: FF_F32 / FF_BF16 / FF_F16 = the activation dtype T the reference computes in;
+ *   - all index outputs are int32 (sequence lengths < 2^31); patch types are int64 as in the
+ *     reference's `patch_type` tensor.
+ *   - sequence positions are "i" (0..L-1); by-patch positions are "j" (0..Nv-1): the visual tokens
+ *     sorted by (patch type, position), the order compute_similarity_and_token_index_by_patch
+ *     (framefusion/main.py:208-214) defines.
+ */
+#ifndef FRAMEFUSION_HIP_H
+#define FRAMEFUSION_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FF_ABI_VERSION 1
+
+enum { FF_F32 = 0, FF_BF16 = 1, FF_F16 = 2 };
+
+enum {
+    FF_OK = 0,
+    FF_ERR_ARG = -1,          /* null pointer / negative size / unknown dtype            */
+    FF_ERR_ALIGN = -2,        /* pointer or row size not 16-byte aligned                 */
+    FF_ERR_UNSUPPORTED = -3,  /* size outside what the kernels are built for             */
+    FF_ERR_WORKSPACE = -4     /* workspace smaller than ff_workspace_bytes()             */
+};
+
+/* Device-side result block written by the plan kernels and read back once per call by the host
+ * (the only host<-device traffic of a FrameFusion.forward call). int64 each. */
+enum {
+    FF_STAT_NV = 0,        /* visual tokens with 0 <= type < patch_num  (len of by-patch order)   */
+    FF_STAT_FTN = 1,       /* tokens with type != TEXT_TOKEN            (main.py:112)             */
+    FF_STAT_COUNT = 2,     /* #{j : sim[j] >= T(threshold)}             (main.py:113)             */
+    FF_STAT_BRANCH = 3,    /* 0: threshold set kept (main.py:116-120); 1: top-k (main.py:121-127) */
+    FF_STAT_K = 4,         /* top-k size int(sub * ftn) when BRANCH == 1                          */
+    FF_STAT_MERGED = 5,    /* tokens folded away (= L_in - L_out)                                 */
+    FF_STAT_LOUT = 6,      /* output sequence length                                              */
+    FF_STAT_BELOW_LB = 7,  /* 1 if BRANCH == 0 and count/ftn < ratio_lower_bound                  */
+    FF_STAT_KTH_KEY = 8,   /* debug: order-preserving key of the k-th largest similarity          */
+    FF_STAT_TIES_TAKEN = 9,/* debug: entries equal to the k-th value that were selected           */
+    FF_STAT_SEQ = 10,      /* sequence number, copied from the call (host polling)                */
+    FF_STAT_WORDS = 16
+};
+
+typedef void* ff_stream_t; /* hipStream_t */
+
+int ff_abi_version(void);
+const char* ff_error_string(int code);
+
+/* Scratch bytes any entry point may need for a sequence of L tokens and `patch_num` patch types. */
+size_t ff_workspace_bytes(int64_t L, int64_t patch_num);
+
+/* ---- K0: by-patch order --------------------------------------------------------------------
+ * Replaces torch.where(patch_type == arange(P)[:, None]) (main.py:208-210).
+ * order[0 .. Nv)  = sequence index of the visual tokens, stable-sorted by patch type;
+ * order[Nv .. L)  = the remaining (text / out-of-range) positions in sequence order, so that
+ *                   `order` is a permutation of 0..L-1 that later stages can walk uniformly.
+ * stats[FF_STAT_NV], stats[FF_STAT_FTN] are written.  patch_num <= 32768. */
+int ff_build_order(const int64_t* patch_type, int64_t L, int64_t patch_num,
+                   int32_t* order, int64_t* stats, void* ws, size_t ws_bytes, ff_stream_t stream);
+
+/* ---- K1: adjacent-pair cosine similarity ----------------------------------------------------
+ * Replaces the two [Nv-1, d] gathers + cosine_similarity + boundary fill (main.py:216-238,
+ * 345-349).  sim[j] (dtype T, j in [0, Nv)) = T(T(sum T(a*b)) / T(T(|a|) * T(|b|))) for
+ * a = hidden[order[j-1]], b = hidden[order[j]]; -2 when j == 0 or the two patch types differ.
+ * hidden: [L, d] row-major, 16-byte aligned, d*sizeof(T) a multiple of 16. */
+int ff_pair_similarity(const void* hidden, int dtype, int64_t L, int64_t d,
+                       const int64_t* patch_type, const int32_t* order, const int64_t* stats,
+                       void* sim, ff_stream_t stream);
+
+/* ---- K2+K3: select + run detection + compaction scan ----------------------------------------
+ * Replaces main.py:112-127 (threshold count, budget test, top-k) and the index algebra of
+ * merge_tokens_and_get_mask / find_contigious_latter_index (main.py:269-301, 351-380).
+ *   threshold : similarity_lower_bound already rounded to T by the caller (double holding T(thr))
+ *   sub       : sparsity upper bound from the budget (main.py:109); ratio_lb: ratio_lower_bound
+ * Decision on device, in double like python: ratio = count/ftn; ratio < sub ? threshold set
+ * : top-k with k = (int64)(sub*ftn), ties at the k-th value taken in ascending j.
+ * Outputs (caller-allocated):
+ *   run_len [L] int32 : for t in by-patch order (then the non-visual tail): -1 if token t is
+ *                       folded into a predecessor, else the number n >= 0 of following tokens
+ *                       folded into it (its run, main.py:282-301);
+ *   dst     [L] int32 : for each SEQUENCE position i: its row in the compacted output, or -1;
+ *   keep    [L] uint8 : the keep mask of main.py:278-279 by sequence position;
+ *   stats             : FF_STAT_COUNT .. FF_STAT_TIES_TAKEN. */
+int ff_plan_merge(const void* sim, int dtype, const int32_t* order, int64_t L,
+                  double threshold, double sub, double ratio_lb,
+                  int32_t* run_len, int32_t* dst, uint8_t* keep, int64_t* stats,
+                  void* ws, size_t ws_bytes, ff_stream_t stream);
+
+/* Same outputs for an EXPLICIT merge set (the static merge_tokens_and_get_mask entry point,
+ * main.py:243-319): merge_index[0..n_merge) ascending by-patch positions. */
+int ff_plan_from_index(const int64_t* merge_index, int64_t n_merge, const int32_t* order, int64_t L,
+                       int32_t* run_len, int32_t* dst, uint8_t* keep, int64_t* stats,
+                       void* ws, size_t ws_bytes, ff_stream_t stream);
+
+/* ---- prune plan (main.py:69-92) ---------------------------------------------------------------
+ * importance [S] dtype T; keeps every position outside [start, start+n_img) and the k largest
+ * inside it (ties -> lowest index).  Outputs as ff_plan_merge with order = identity. */
+int ff_plan_prune(const void* importance, int dtype, int64_t S, int64_t start, int64_t n_img,
+                  int64_t k, int32_t* run_len, int32_t* dst, uint8_t* keep, int64_t* stats,
+                  void* ws, size_t ws_bytes, ff_stream_t stream);
+
+/* ---- K4: run merge + compaction ---------------------------------------------------------------
+ * Replaces index_add_ + divide (main.py:304-317) and the keep-mask gathers of hidden /
+ * position embeddings / patch_type (main.py:132-138, 161-178) in one pass.
+ * For every t with run_len[t] = n >= 0, i = order[t] (order == NULL: i = t):
+ *   out[dst[i]] = T( (..(T(h[i] + h[order[t+1]]) + ..) + h[order[t+n]]) / T(n+1) )   (n > 0)
+ *   out[dst[i]] = h[i]                                                               (n == 0)
+ * and each aux tensor (viewed as [outer, L, row_bytes] bytes) is gathered the same way into
+ * [outer, L_cap, row_bytes]. `hidden_out` holds L_cap rows (L_cap >= L_out; L is always enough). */
+typedef struct {
+    const void* src;     /* [outer, L, row_bytes]                         */
+    void* dst;           /* [outer, L_cap, row_bytes]                     */
+    int64_t row_bytes;   /* bytes per token (multiple of 2)               */
+    int64_t outer;       /* leading dims folded together (>= 1)           */
+} ff_aux_t;
+
+#define FF_MAX_AUX 4
+
+int ff_merge_compact(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d,
+                     int64_t L_cap, const int32_t* order, const int32_t* run_len,
+                     const int32_t* dst, const ff_aux_t* aux_host, int n_aux,
+                     ff_stream_t stream);
+
+/* Square attention-mask gather: out[r, c] = mask[src_r, src_c] for kept rows/cols
+ * (main.py:137-138, 99-100). mask: [L, L] elements of elem_bytes; out: [L_cap, L_cap]. */
+int ff_gather_mask(const void* mask, void* out, int64_t elem_bytes, int64_t L, int64_t L_cap,
+                   const int32_t* dst, ff_stream_t stream);
+
+/* ---- importance (framefusion/utils.py:27-57 + main.py:69-70) -----------------------------------
+ * Head/query mean of attention probabilities: attn_w [H, num, S] (T) -> importance [S] (T),
+ * T(mean over H*num accumulated in fp32). */
+int ff_head_mean(const void* attn_w, int dtype, int64_t H, int64_t num, int64_t S,
+                 void* importance, ff_stream_t stream);
+
+/* Last-`num`-query attention probabilities with the reference's staged rounding:
+ * p = T(softmax_fp32(T(T(q K^T) * scale) + causal_bias)).  q_last [H, num, dh], k [H_kv, S, dh]
+ * (GQA: head h reads kv head h / (H/H_kv), the repeat_kv of modeling_qwen2.py:147 folded in),
+ * weights [H, num, S] (may be NULL), importance [S] (may be NULL) = head_mean(weights). */
+int ff_last_query_attention(const void* q_last, const void* k, int dtype, int64_t H, int64_t H_kv,
+                            int64_t num, int64_t S, int64_t dh, double scale, int causal,
+                            void* weights, void* importance, void* ws, size_t ws_bytes,
+                            ff_stream_t stream);
+
+/* ---- fused step -----------------------------------------------------------------------------
+ * One FrameFusion.forward merge call (main.py:104-138): K0 (skipped when order_valid != 0) ->
+ * K1 -> K2+K3 -> K4, all enqueued by one host call.  `stats_host_mapped` (may be NULL) is a
+ * device-visible pinned host pointer that receives a copy of the stats block, its FF_STAT_SEQ
+ * word written last with `seq`, so the host can poll instead of synchronising the stream. */
+int ff_merge_step(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
+                  const int64_t* patch_type, int64_t patch_num, int order_valid,
+                  double threshold, double sub, double ratio_lb,
+                  int32_t* order, void* sim, int32_t* run_len, int32_t* dst, uint8_t* keep,
+                  int64_t* stats, int64_t* stats_host_mapped, int64_t seq,
+                  const ff_aux_t* aux_host, int n_aux,
+                  void* ws, size_t ws_bytes, ff_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRAMEFUSION_HIP_H */

@@ -1,0 +1,357 @@
+"""GPU: the HIP path (through the C ABI, via framefusion_amd) against the golden vectors of the real
+reference and against the CPU oracle on the same seeded inputs.
+
+Bars: integer/index outputs bit-exact; activations bit-exact on dyadic-grid inputs (where the fp32
+sums are order-independent) and within 1e-3 relative (the north-star tolerance) elsewhere;
+similarities on gaussian inputs within 1 ulp on <= 0.1 % of the pairs (fp32 reduction-order noise,
+SURVEY.md Appendix B).
+"""
+import numpy as np
+import pytest
+import torch
+
+import framefusion_amd as ffa
+from framefusion_amd import _lib
+from framefusion_amd.synth import video_tokens, rotary_tables
+from oracle import ff_oracle as orc
+from tests import harness
+from tests.conftest import DT, from_bits, same_bits, Golden
+from tests.test_oracle_golden import make_pos, SIM_CASES, FWD_CASES, CAS_CASES, IMP_CASES
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dev(t):
+    return t.to(DEV)
+
+
+# ---------------------------------------------------------------------------------------------
+# K0
+# ---------------------------------------------------------------------------------------------
+def hip_order(pt, P):
+    lib = _lib.load()
+    L = pt.numel()
+    ptd = dev(pt.reshape(-1).contiguous())
+    order = torch.full((L,), -7, dtype=torch.int32, device=DEV)
+    stats = torch.zeros(_lib.STAT_WORDS, dtype=torch.int64, device=DEV)
+    _lib.check(lib.ff_build_order(ptd.data_ptr(), L, P, order.data_ptr(), stats.data_ptr(), None, 0,
+                                  _lib.stream_ptr()), "ff_build_order")
+    torch.cuda.synchronize()
+    return order.cpu().long(), stats.cpu()
+
+
+def check_order(pt, P):
+    order, stats = hip_order(pt, P)
+    want, _ = orc.by_patch_order(pt, P)
+    nv = want.numel()
+    assert int(stats[_lib.STAT_NV]) == nv
+    assert int(stats[_lib.STAT_FTN]) == int((pt != -1).sum())
+    assert torch.equal(order[:nv], want)
+    flat = pt.reshape(-1)
+    rest = torch.nonzero(~((flat >= 0) & (flat < P))).reshape(-1)
+    assert torch.equal(order[nv:], rest)
+
+
+@pytest.mark.parametrize("F,P,pre,post", [(8, 16, 3, 2), (64, 576, 14, 20), (5, 7, 0, 0), (3, 1, 1, 1),
+                                           (40, 100, 0, 9), (7, 3000, 2, 2), (2, 20000, 0, 0)])
+def test_order_regular(F, P, pre, post):
+    pt = torch.cat((torch.full((pre,), -1), torch.arange(P).repeat(F), torch.full((post,), -1)))[None]
+    check_order(pt, P)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_order_ragged_random(seed):
+    g = torch.Generator().manual_seed(seed)
+    L = [1000, 4097, 70001][seed]
+    P = [5, 70, 1300][seed]
+    pt = torch.randint(-2, P + 3, (1, L), generator=g)     # text, IGNORE, out-of-range types included
+    check_order(pt, P)
+    check_order(torch.full((1, 333), -1), 4)               # no visual token at all
+    check_order(torch.zeros(1, 129, dtype=torch.long), 1)  # one type only: every wave step collides
+
+
+# ---------------------------------------------------------------------------------------------
+# K1
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", [c for c in SIM_CASES if c != "hand"])
+def test_similarity_golden(golden, name):
+    g = golden("similarity_merge")
+    dtype = DT[str(g[f"{name}/dtype"])]
+    h = from_bits(g[f"{name}/hidden"], dtype)[None]
+    pt = torch.from_numpy(g[f"{name}/patch_type"])[None]
+    P = int(g[f"{name}/patch_num"])
+    sim, order = ffa.FrameFusion.compute_similarity_and_token_index_by_patch(dev(h), dev(pt), P)
+    assert np.array_equal(order[0].cpu().numpy(), g[f"{name}/order"])
+    want = from_bits(g[f"{name}/sim"], dtype)
+    got = sim[0].cpu()
+    if bool(g[f"{name}/exact"]):
+        assert same_bits(got, want)
+    else:
+        assert torch.allclose(got.float(), want.float(), rtol=2 ** -7 if dtype != torch.float32 else 1e-5, atol=0)
+
+
+def test_hand_example(golden):
+    g = golden("similarity_merge")
+    h = torch.from_numpy(g["hand/hidden"])
+    h = torch.cat((h, torch.zeros(h.shape[0], 4)), dim=1)[None]      # pad d to a 16-byte row (zeros are neutral)
+    pt = torch.from_numpy(g["hand/patch_type"])[None]
+    sim, order = ffa.FrameFusion.compute_similarity_and_token_index_by_patch(dev(h), dev(pt), 2)
+    assert order.tolist() == [[1, 3, 5, 2, 4, 6]]
+    assert np.allclose(sim[0].cpu().numpy(), g["hand/sim"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("dt,F,P,d,grid", [("bf16", 16, 33, 1024, 0.125), ("bf16", 9, 20, 3584, 0.125),
+                                            ("fp16", 8, 17, 512, 0.125), ("fp32", 8, 17, 640, 0.125),
+                                            ("bf16", 6, 11, 8192, 0.125), ("bf16", 12, 40, 4096, None)])
+def test_similarity_vs_oracle(dt, F, P, d, grid):
+    dtype = DT[dt]
+    h, pt = video_tokens(F, P, d, p_change=0.3, sigma=0.2, sigma_hi=1.5, seed=5, pre=3, post=4, dtype=dtype, grid=grid)
+    sim_o, ord_o = orc.pair_similarity(h, pt, P)
+    sim, order = ffa.FrameFusion.compute_similarity_and_token_index_by_patch(dev(h), dev(pt), P)
+    assert torch.equal(order.cpu(), ord_o)
+    if grid is not None:
+        assert same_bits(sim.cpu(), sim_o)
+    else:
+        a, b = sim.cpu().float(), sim_o.float()
+        assert float((a != b).float().mean()) <= 2e-3
+        assert torch.allclose(a, b, rtol=2 ** -7, atol=0)
+
+
+def test_cosine_similarity_api():
+    a = harness.snap(torch.randn(37, 256, generator=torch.Generator().manual_seed(1)), torch.bfloat16)
+    b = harness.snap(torch.randn(37, 256, generator=torch.Generator().manual_seed(2)) * 0.5 + a.float(), torch.bfloat16)
+    want = orc.staged_cosine(a, b)
+    got = ffa.cosine_similarity(dev(a), dev(b))
+    assert same_bits(got.cpu(), want)
+
+
+# ---------------------------------------------------------------------------------------------
+# plan + merge (static entry point, reference main.py:243-319)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", [c for c in SIM_CASES if c != "hand"])
+def test_merge_golden(golden, name):
+    g = golden("similarity_merge")
+    dtype = DT[str(g[f"{name}/dtype"])]
+    h = from_bits(g[f"{name}/hidden"], dtype)[None]
+    sim = from_bits(g[f"{name}/sim"], dtype)[None]
+    order = torch.from_numpy(g[f"{name}/order"])[None]
+    for sname in ("thr", "all", "alt", "none"):
+        midx = torch.from_numpy(g[f"{name}/merge_{sname}/idx"])
+        hd = dev(h.clone())
+        merged, keep = ffa.FrameFusion.merge_tokens_and_get_mask(hd, dev(sim), dev(order), dev(midx))
+        assert merged.data_ptr() == hd.data_ptr()                      # in place, like the reference
+        assert np.array_equal(keep[0].cpu().numpy(), g[f"{name}/merge_{sname}/keep"]), sname
+        assert same_bits(merged[0].cpu(), from_bits(g[f"{name}/merge_{sname}/hidden"], dtype)), sname
+
+
+# ---------------------------------------------------------------------------------------------
+# FrameFusion.forward
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", FWD_CASES)
+def test_forward_golden(golden, name):
+    g = golden("forward")
+    dtype = DT[str(g[f"{name}/dtype"])]
+    F, P, d, pre, post = (int(x) for x in g[f"{name}/meta"])
+    cost, thr, lb = (float(x) for x in g[f"{name}/params"])
+    h = from_bits(g[f"{name}/hidden"], dtype)[None]
+    pt = torch.from_numpy(g[f"{name}/patch_type"])[None]
+    L = h.shape[1]
+    ff = ffa.FrameFusion(cost, thr, lb)
+    ff.prepare(dev(pt), P, pre, pre + F * P, F * P, L)
+    pos = make_pos(str(g[f"{name}/pos_kind"]), L, dtype)
+    pos_in = [p.clone() for p in pos] if isinstance(pos, list) else pos.clone()
+    pos = [dev(p) for p in pos] if isinstance(pos, list) else dev(pos)
+    mask = None
+    if bool(g[f"{name}/mask"]):
+        mask = torch.zeros(1, 1, L, L, dtype=dtype).masked_fill_(torch.ones(L, L, dtype=torch.bool).triu(1), float("-inf"))
+    hd = dev(h)
+    out, pos_out, mask_out = ff(hd, pos, None if mask is None else dev(mask))
+    keep = torch.from_numpy(g[f"{name}/keep"])
+    got_keep = torch.nonzero(ff.last_call["keep"].bool()).reshape(-1).cpu() if ff.last_call else torch.arange(L)
+    assert np.array_equal(got_keep.numpy(), keep.numpy())
+    assert same_bits(out[0].cpu(), from_bits(g[f"{name}/hidden_out"], dtype))
+    assert np.array_equal(ff.patch_type[0].cpu().numpy(), g[f"{name}/patch_type_out"])
+    assert [ff.finish_merging, ff.finish_pruning] == [bool(x) for x in g[f"{name}/flags"]]
+    assert ff.sparsity_list == list(g[f"{name}/sparsity"])
+    if isinstance(pos_in, list):
+        assert pos_out is pos                                           # list mutated in place (main.py:146-170)
+        for a, b in zip(pos_out, pos_in):
+            assert same_bits(a.cpu().contiguous(), b.index_select(b.ndim - 2, keep))
+    else:
+        assert torch.equal(pos_out.cpu(), pos_in[:, keep])
+    if mask is not None:
+        assert same_bits(mask_out.cpu().contiguous(), mask[:, :, keep][:, :, :, keep])
+    assert same_bits(hd.cpu(), h)                                        # the fast path leaves its input alone
+
+
+@pytest.mark.parametrize("name", CAS_CASES)
+def test_cascade_golden(golden, name):
+    g = golden("cascade")
+    dtype = DT[str(g[f"{name}/dtype"])]
+    F, P, d, pre, post, layers, heads, num = (int(x) for x in g[f"{name}/meta"])
+    h = from_bits(g[f"{name}/hidden"], dtype)[None]
+    pt = torch.from_numpy(g[f"{name}/patch_type"])[None]
+    L = h.shape[1]
+    log, _ = harness.run_cascade(ffa.FrameFusion(0.3, 0.6, 0.1), dev(h), dev(pt), P,
+                                 dev(torch.arange(L)[None]), None, layers, heads, num)
+    assert [r["length"] for r in log] == [int(x) for x in g[f"{name}/lengths"]]
+    for r, fl, ns in zip(log, g[f"{name}/flags"], g[f"{name}/n_sparsity"]):
+        assert [r["finish_merging"], r["finish_pruning"]] == [bool(fl[0]), bool(fl[1])], r["tag"]
+        assert len(r["sparsity"]) == int(ns)
+        assert np.array_equal(r["pos"][0].cpu().numpy(), g[f"{name}/{r['tag']}/index"]), r["tag"]
+        assert same_bits(r["hidden"][0].cpu(), from_bits(g[f"{name}/{r['tag']}/hidden"], dtype)), r["tag"]
+    assert log[-1]["sparsity"] == list(g[f"{name}/sparsity"])
+
+
+def test_cascade_with_rotary_containers(golden):
+    """Same cascades with [cos, sin] containers (3-D and M-RoPE 4-D) against the oracle."""
+    g = golden("cascade")
+    for name, kind in (("c_thr_prune", "qwen2"), ("c_low_prune", "mrope")):
+        dtype = DT[str(g[f"{name}/dtype"])]
+        F, P, d, pre, post, layers, heads, num = (int(x) for x in g[f"{name}/meta"])
+        h = from_bits(g[f"{name}/hidden"], dtype)[None]
+        pt = torch.from_numpy(g[f"{name}/patch_type"])[None]
+        L = h.shape[1]
+        want, _ = harness.run_cascade(orc.OracleFrameFusion(0.3, 0.6, 0.1), h.clone(), pt.clone(), P,
+                                      make_pos(kind, L, dtype), None, layers, heads, num)
+        got, _ = harness.run_cascade(ffa.FrameFusion(0.3, 0.6, 0.1), dev(h), dev(pt), P,
+                                     [dev(p) for p in make_pos(kind, L, dtype)], None, layers, heads, num)
+        for a, b in zip(got, want):
+            assert a["length"] == b["length"]
+            assert same_bits(a["hidden"].cpu(), b["hidden"])
+            for x, y in zip(a["pos"], b["pos"]):
+                assert same_bits(x.cpu().contiguous(), y.contiguous())
+
+
+# ---------------------------------------------------------------------------------------------
+# selection rules
+# ---------------------------------------------------------------------------------------------
+def run_plan(sim, thr, sub, lb, ftn=None):
+    lib = _lib.load()
+    nv = sim.numel()
+    dtype = sim.dtype
+    simd = dev(sim.contiguous())
+    order = torch.arange(nv, dtype=torch.int32, device=DEV)
+    out = [torch.empty(nv, dtype=torch.int32, device=DEV), torch.empty(nv, dtype=torch.int32, device=DEV),
+           torch.empty(nv, dtype=torch.uint8, device=DEV)]
+    stats = torch.zeros(_lib.STAT_WORDS, dtype=torch.int64, device=DEV)
+    stats[_lib.STAT_NV] = nv
+    stats[_lib.STAT_FTN] = nv if ftn is None else ftn
+    wsb = int(lib.ff_workspace_bytes(nv, 1))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    thr_t = float(torch.tensor(thr, dtype=dtype))
+    _lib.check(lib.ff_plan_merge(simd.data_ptr(), _lib.DTYPE_CODE[dtype], order.data_ptr(), nv, thr_t, sub, lb,
+                                 out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), stats.data_ptr(),
+                                 ws.data_ptr(), wsb, _lib.stream_ptr()), "ff_plan_merge")
+    torch.cuda.synchronize()
+    return [o.cpu() for o in out], stats.cpu()
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16", "fp32"])
+@pytest.mark.parametrize("n,seed", [(50, 0), (4099, 1), (70000, 2)])
+def test_select_threshold_and_topk(dt, n, seed):
+    dtype = DT[dt]
+    g = torch.Generator().manual_seed(seed)
+    sim = (torch.rand(n, generator=g) * 1.2 - 0.1).to(dtype)       # few distinct bf16 values: many ties
+    sim[0] = -2
+    sim[torch.rand(n, generator=g) < 0.05] = -2
+    if n > 100:
+        sim[7] = float("nan")
+    for sub in (0.9, 0.3, 0.05, 0.0):
+        (run_len, dst, keep), st = run_plan(sim, 0.6, sub, 0.1)
+        count = int((sim >= 0.6).sum())
+        assert int(st[_lib.STAT_COUNT]) == count
+        ratio = count / n
+        if ratio < sub:
+            assert int(st[_lib.STAT_BRANCH]) == 0
+            members = torch.nonzero(sim >= 0.6).reshape(-1)
+            assert int(st[_lib.STAT_BELOW_LB]) == int(ratio < 0.1)
+        else:
+            assert int(st[_lib.STAT_BRANCH]) == 1
+            k = int(sub * n)
+            assert int(st[_lib.STAT_K]) == k
+            members = orc.topk_lowest_index(sim, k)
+        members = members[members != 0]                               # position 0 never folds
+        want_keep = torch.ones(n, dtype=torch.uint8)
+        want_keep[members] = 0
+        assert torch.equal(keep, want_keep), sub
+        assert int(st[_lib.STAT_LOUT]) == int(want_keep.sum())
+        assert torch.equal(dst[want_keep.bool()], torch.arange(int(want_keep.sum()), dtype=torch.int32))
+        flags = torch.zeros(n, dtype=torch.long)
+        flags[members] = 1
+        lens = orc.run_lengths(flags[None])[0]
+        ends = torch.nonzero(lens).reshape(-1)
+        want_rl = torch.zeros(n, dtype=torch.int32)
+        want_rl[members] = -1
+        want_rl[ends - lens[ends]] = lens[ends].int()
+        assert torch.equal(run_len, want_rl), sub
+
+
+# ---------------------------------------------------------------------------------------------
+# importance
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", IMP_CASES)
+def test_importance_golden(golden, name):
+    g = golden("importance")
+    dtype = DT[str(g[f"{name}/dtype"])]
+    H, Hk, S, dh, num, causal = (int(x) for x in g[f"{name}/meta"])
+    q = from_bits(g[f"{name}/q"], dtype)[None]
+    k = from_bits(g[f"{name}/k"], dtype)[None]
+    w = ffa.scaled_dot_product_attention(dev(q), dev(k), None, num=num, is_causal=bool(causal), enable_gqa=H != Hk)
+    want = from_bits(g[f"{name}/weights"], dtype)
+    tol = 2 ** -7 if dtype != torch.float32 else 2e-6
+    assert torch.allclose(w[0].cpu().float(), want.float(), rtol=tol, atol=1e-30)
+    imp = ffa.last_query_importance(dev(q), dev(k), num=num, is_causal=bool(causal))
+    assert imp.shape == (1, 1, 1, S)
+    assert torch.allclose(imp.reshape(-1).cpu().float(), from_bits(g[f"{name}/importance"], dtype).float(),
+                          rtol=tol, atol=1e-30)
+
+
+def test_head_mean_exact():
+    w = harness.attention_stub(28, 4, 5000, torch.bfloat16)
+    want = torch.mean(w, dim=(1, 2))[0]
+    lib = _lib.load()
+    wd = dev(w)
+    imp = torch.empty(5000, dtype=torch.bfloat16, device=DEV)
+    _lib.check(lib.ff_head_mean(wd.data_ptr(), _lib.FF_BF16, 28, 4, 5000, imp.data_ptr(), _lib.stream_ptr()), "hm")
+    assert same_bits(imp.cpu(), want)
+
+
+# ---------------------------------------------------------------------------------------------
+# errors and edge cases (reference behaviour)
+# ---------------------------------------------------------------------------------------------
+def test_edges_and_errors():
+    f = ffa.FrameFusion()
+    f.prepare(dev(torch.tensor([[-1]])), 4, 0, 0, 0, 1)
+    tok = torch.zeros(1, 1, 8, device=DEV)
+    r = f(tok, "pos", "mask")
+    assert r[0] is tok and r[1] == "pos" and r[2] == "mask"
+    f.prepare(dev(torch.tensor([[-1, -1, -1]])), 4, 0, 0, 0, 3)
+    with pytest.raises(AssertionError):
+        f(torch.zeros(1, 3, 8, device=DEV), [torch.zeros(1, 3, 2, device=DEV)] * 2, None)
+    for bad in ((torch.zeros(1, 4, 2, device=DEV),) * 2, torch.zeros(1, 4, 2, device=DEV)):
+        f.prepare(dev(torch.tensor([[0, 1, 0, 1]])), 2, 0, 4, 4, 4)
+        with pytest.raises(NotImplementedError):
+            f(torch.ones(1, 4, 8, device=DEV), bad, None)
+    f.prepare(dev(torch.tensor([[0, 1, 0, 1]])), 2, 0, 4, 4, 4, sparsity_list=[0] * 10)
+    with pytest.raises(ValueError, match="The cost is too small"):
+        f(torch.ones(1, 4, 8, device=DEV), torch.arange(4, device=DEV)[None], None)
+    g = ffa.FrameFusion()
+    with pytest.raises(AttributeError):
+        g(torch.zeros(1, 3, 8, device=DEV), None, None)
+    with pytest.raises(ffa.FrameFusionHipError):                  # no CPU path in the product
+        f.prepare(torch.tensor([[0, 1, 0, 1]]), 2, 0, 4, 4, 4)
+        f(torch.ones(1, 4, 8), torch.arange(4)[None], None)
+
+
+def test_determinism():
+    h, pt = video_tokens(16, 48, 1024, p_change=0.3, sigma_hi=1.5, seed=9, pre=5, post=5)
+    outs = []
+    for _ in range(3):
+        f = ffa.FrameFusion(0.3, 0.6, 0.1)
+        f.prepare(dev(pt), 48, 5, 5 + 16 * 48, 16 * 48, h.shape[1])
+        o, p, _ = f(dev(h), dev(torch.arange(h.shape[1])[None]), None)
+        outs.append((o.cpu(), p.cpu()))
+    for o, p in outs[1:]:
+        assert same_bits(o, outs[0][0]) and torch.equal(p, outs[0][1])
