@@ -22,7 +22,8 @@ DTYPE_CODE = {torch.float32: FF_F32, torch.bfloat16: FF_BF16, torch.float16: FF_
 
 (STAT_NV, STAT_FTN, STAT_COUNT, STAT_BRANCH, STAT_K, STAT_MERGED, STAT_LOUT, STAT_BELOW_LB,
  STAT_KTH_KEY, STAT_TIES_TAKEN, STAT_SEQ) = range(11)
-STAT_WORDS = 16
+STAT_T_ORDER, STAT_T_PLAN = 16, 24
+STAT_WORDS = 32
 MAX_AUX = 4
 ABI_VERSION = 1
 

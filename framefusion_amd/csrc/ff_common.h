@@ -13,6 +13,22 @@ namespace ff {
 constexpr int kWave = 64;  // gfx950 wavefront
 
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- raw buffer access (SRSRC): a wave-uniform base + byte count; lanes past the end read 0 and
+// their stores are dropped by the hardware, so ragged row tails need no predication.
+__device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ inline uint4 buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t voffset) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voffset, 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ inline void buf_store16(__amdgpu_buffer_rsrc_t r, uint32_t voffset, const uint4& x) {
+    u32x4 v; v.x = x.x; v.y = x.y; v.z = x.z; v.w = x.w;
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voffset, 0, 0);
+}
+__device__ inline int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
 // ---- activation dtype traits ---------------------------------------------------------------
 // PER16: elements per 16-byte lane load.  rnd(x): x rounded to T (RNE), returned as float.

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void k_lq_softmax(const float* __restrict__ sc
     __syncthreads();
     sum = (red[0] + red[1]) + (red[2] + red[3]);
     for (int s = threadIdx.x; s < S; s += blockDim.x) {
-        const float p = A::rnd(__fdiv_rn(expf(scores[base + s] - m), sum));
+        const float p = A::rnd(expf(scores[base + s] - m) / sum);
         probs_f[base + s] = p;
         if (weights) A::store1(weights, base + s, p);
     }
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void k_lq_mean(const float* __restrict__ probs
     if (s >= S) return;
     float acc = 0.f;
     for (int r = 0; r < rows; ++r) acc += probs_f[(int64_t)r * S + s];
-    A::store1(imp, s, __fdiv_rn(acc, (float)rows));
+    A::store1(imp, s, acc / (float)rows);
 }
 
 template <int DT>

@@ -13,6 +13,8 @@
 // Rounding recipe, T = activation dtype:
 //     dot = T(sum_fp32 T(a_i*b_i));  na = T(sqrt_fp32(sum_fp32 a_i^2));  sim = T(dot / T(na*nb))
 // sqrt and divide are the correctly rounded fp32 forms (hipcc default).
+#include <stdlib.h>
+
 #include "ff_common.h"
 
 namespace ff {
@@ -22,49 +24,47 @@ constexpr int kSimWaves = kSimThreads / kWave;
 
 template <int DT, int kPairs>
 __global__ __launch_bounds__(kSimThreads) void k_pair_similarity(
-    const char* __restrict__ hidden, int64_t row_bytes, const int64_t* __restrict__ ptype,
+    const char* __restrict__ hidden, uint32_t row_bytes, const int64_t* __restrict__ ptype,
     const int32_t* __restrict__ order, const int64_t* __restrict__ stats, void* __restrict__ sim) {
     using A = Act<DT>;
     constexpr int E = A::kPer16;
+    constexpr int R = kPairs + 1;
     const int nv = (int)stats[FF_STAT_NV];
     const int lane = lane_id();
-    const int j0 = (blockIdx.x * kSimWaves + wave_id()) * kPairs;
+    const int j0 = uniform((blockIdx.x * kSimWaves + wave_id()) * kPairs);
     if (j0 >= nv) return;
 
-    const char* row[kPairs + 1];
+    __amdgpu_buffer_rsrc_t row[R];
 #pragma unroll
-    for (int r = 0; r <= kPairs; ++r) {
+    for (int r = 0; r < R; ++r) {
         int j = j0 - 1 + r;
         j = j < 0 ? 0 : (j >= nv ? nv - 1 : j);
-        row[r] = hidden + (int64_t)order[j] * row_bytes + lane * 16;
+        row[r] = make_rsrc(hidden + (int64_t)uniform(order[j]) * row_bytes, row_bytes);
     }
 
-    float nrm[kPairs + 1], dot[kPairs];
+    float nrm[R], dot[kPairs];
 #pragma unroll
-    for (int r = 0; r <= kPairs; ++r) nrm[r] = 0.f;
+    for (int r = 0; r < R; ++r) nrm[r] = 0.f;
 #pragma unroll
     for (int r = 0; r < kPairs; ++r) dot[r] = 0.f;
 
-    const int64_t lane_off = (int64_t)lane * 16;
-    const uint4 zero = make_uint4(0, 0, 0, 0);
-    uint4 cur[kPairs + 1], nxt[kPairs + 1];
+    // 1 KiB tiles; tile t+1 is in flight while tile t is reduced
+    const uint32_t lane_off = (uint32_t)lane * 16;
+    const uint32_t tiles = (row_bytes + 1023u) >> 10;
+    uint4 cur[R], nxt[R];
 #pragma unroll
-    for (int r = 0; r <= kPairs; ++r)
-        cur[r] = (lane_off < row_bytes) ? *(const uint4*)(row[r]) : zero;
-
-    for (int64_t off = 0; off < row_bytes; off += 1024) {
-        const int64_t noff = off + 1024;
-        const bool more = (noff + lane_off) < row_bytes;
+    for (int r = 0; r < R; ++r) cur[r] = buf_load16(row[r], lane_off);
+    for (uint32_t t = 0; t < tiles; ++t) {
+        const uint32_t noff = lane_off + (t + 1) * 1024u;      // past-the-end lanes read zeros
 #pragma unroll
-        for (int r = 0; r <= kPairs; ++r)
-            nxt[r] = more ? *(const uint4*)(row[r] + noff) : zero;
+        for (int r = 0; r < R; ++r) nxt[r] = buf_load16(row[r], noff);
 
         float prev[E], x[E];
         A::unpack(cur[0], prev);
 #pragma unroll
         for (int e = 0; e < E; ++e) nrm[0] = __builtin_fmaf(prev[e], prev[e], nrm[0]);
 #pragma unroll
-        for (int r = 1; r <= kPairs; ++r) {
+        for (int r = 1; r < R; ++r) {
             A::unpack(cur[r], x);
 #pragma unroll
             for (int e = 0; e < E; ++e) {
@@ -74,11 +74,11 @@ __global__ __launch_bounds__(kSimThreads) void k_pair_similarity(
             }
         }
 #pragma unroll
-        for (int r = 0; r <= kPairs; ++r) cur[r] = nxt[r];
+        for (int r = 0; r < R; ++r) cur[r] = nxt[r];
     }
 
 #pragma unroll
-    for (int r = 0; r <= kPairs; ++r) nrm[r] = wave_sum(nrm[r]);
+    for (int r = 0; r < R; ++r) nrm[r] = wave_sum(nrm[r]);
 #pragma unroll
     for (int r = 0; r < kPairs; ++r) dot[r] = wave_sum(dot[r]);
 
@@ -90,10 +90,10 @@ __global__ __launch_bounds__(kSimThreads) void k_pair_similarity(
                 float s = -2.0f;   // IGNORE_TOKEN (main.py:225-238)
                 if (j > 0 && ptype[order[j - 1]] == ptype[order[j]]) {
                     const float d = A::rnd(dot[r]);
-                    const float na = A::rnd(__fsqrt_rn(nrm[r]));
-                    const float nb = A::rnd(__fsqrt_rn(nrm[r + 1]));
+                    const float na = A::rnd(sqrtf(nrm[r]));
+                    const float nb = A::rnd(sqrtf(nrm[r + 1]));
                     const float den = A::rnd(na * nb);
-                    s = A::rnd(__fdiv_rn(d, den));
+                    s = A::rnd(d / den);
                 }
                 A::store1(sim, j, s);
             }
@@ -101,16 +101,34 @@ __global__ __launch_bounds__(kSimThreads) void k_pair_similarity(
     }
 }
 
-template <int DT>
-static int launch_similarity(const void* hidden, int64_t L, int64_t d, const int64_t* ptype,
-                             const int32_t* order, const int64_t* stats, void* sim, hipStream_t st) {
-    constexpr int kPairs = 4;
+template <int DT, int kPairs>
+static int launch_similarity_p(const void* hidden, int64_t L, int64_t d, const int64_t* ptype,
+                               const int32_t* order, const int64_t* stats, void* sim, hipStream_t st) {
     const int64_t row_bytes = d * Act<DT>::kBytes;
     const int64_t per_block = (int64_t)kSimWaves * kPairs;
     const int64_t blocks = (L + per_block - 1) / per_block;
     hipLaunchKernelGGL((k_pair_similarity<DT, kPairs>), dim3((unsigned)blocks), dim3(kSimThreads), 0, st,
-                       (const char*)hidden, row_bytes, ptype, order, stats, sim);
+                       (const char*)hidden, (uint32_t)row_bytes, ptype, order, stats, sim);
     return (int)hipGetLastError();
+}
+
+static int tune_pairs() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("FF_SIM_PAIRS");
+        v = e ? atoi(e) : 4;
+    }
+    return v;
+}
+
+template <int DT>
+static int launch_similarity(const void* hidden, int64_t L, int64_t d, const int64_t* ptype,
+                             const int32_t* order, const int64_t* stats, void* sim, hipStream_t st) {
+    switch (tune_pairs()) {
+        case 2: return launch_similarity_p<DT, 2>(hidden, L, d, ptype, order, stats, sim, st);
+        case 8: return launch_similarity_p<DT, 8>(hidden, L, d, ptype, order, stats, sim, st);
+        default: return launch_similarity_p<DT, 4>(hidden, L, d, ptype, order, stats, sim, st);
+    }
 }
 
 }  // namespace ff
@@ -122,7 +140,7 @@ extern "C" int ff_pair_similarity(const void* hidden, int dtype, int64_t L, int6
     if (dtype != FF_F32 && dtype != FF_BF16 && dtype != FF_F16) return FF_ERR_ARG;
     const int64_t esz = dtype == FF_F32 ? 4 : 2;
     if (((uintptr_t)hidden & 15) || ((d * esz) & 15)) return FF_ERR_ALIGN;
-    if (L >= (1ll << 31)) return FF_ERR_UNSUPPORTED;
+    if (L >= (1ll << 31) || d * esz >= (1ll << 31)) return FF_ERR_UNSUPPORTED;
     if (L == 0) return FF_OK;
     hipStream_t st = (hipStream_t)stream;
     switch (dtype) {

@@ -55,7 +55,9 @@ enum {
     FF_STAT_KTH_KEY = 8,   /* debug: order-preserving key of the k-th largest similarity          */
     FF_STAT_TIES_TAKEN = 9,/* debug: entries equal to the k-th value that were selected           */
     FF_STAT_SEQ = 10,      /* sequence number, copied from the call (host polling)                */
-    FF_STAT_WORDS = 16
+    FF_STAT_T_ORDER = 16,  /* 4 words: shader-clock cycles of K0's phases (diagnostics)           */
+    FF_STAT_T_PLAN = 24,   /* 5 words: shader-clock cycles of the plan kernel's passes            */
+    FF_STAT_WORDS = 32
 };
 
 typedef void* ff_stream_t; /* hipStream_t */

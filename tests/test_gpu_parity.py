@@ -60,6 +60,19 @@ def test_order_regular(F, P, pre, post):
     check_order(pt, P)
 
 
+def test_order_almost_regular():
+    """Layouts that nearly match the frame-major closed form must still take the general sort."""
+    F, P, pre = 6, 40, 5
+    base = torch.cat((torch.full((pre,), -1), torch.arange(P).repeat(F), torch.full((3,), -1)))
+    a = base.clone(); a[pre + 57] = -1                       # a text token inside the visual span
+    b = base.clone(); b[pre + 90] = (b[pre + 90] + 1) % P    # one type off
+    c = torch.cat((base[:pre + 3 * P], torch.full((2,), -1), base[pre + 3 * P:]))   # text between frames
+    d = base[:-3 - 7]                                        # last frame incomplete
+    e = torch.cat((torch.full((pre,), -1), (torch.arange(F * P) + 3) % P))          # first type is not 0
+    for pt in (a, b, c, d, e):
+        check_order(pt[None], P)
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_order_ragged_random(seed):
     g = torch.Generator().manual_seed(seed)
