@@ -140,11 +140,11 @@ def main():
             "similarity": lambda: lib.ff_pair_similarity(hidden.data_ptr(), _lib.FF_BF16, L, d, ptype.data_ptr(),
                                                          sc.order.data_ptr(), sc.stats.data_ptr(), sim.data_ptr(), stream),
             "plan": lambda: lib.ff_plan_merge(sim.data_ptr(), _lib.FF_BF16, sc.order.data_ptr(), L, thr, sub, RATIO_LB,
-                                              sc.run_len.data_ptr(), sc.dst.data_ptr(), sc.keep.data_ptr(),
+                                              sc.member.data_ptr(), sc.dst.data_ptr(), sc.keep.data_ptr(),
                                               sc.stats.data_ptr(), sc.ws.data_ptr(), sc.ws_bytes, stream),
             "merge_compact": lambda: lib.ff_merge_compact(hidden.data_ptr(), out_buf.data_ptr(), _lib.FF_BF16, L, d, L,
-                                                          sc.order.data_ptr(), sc.run_len.data_ptr(), sc.dst.data_ptr(),
-                                                          aux, 3, stream),
+                                                          sc.order.data_ptr(), sc.member.data_ptr(), 1, sc.dst.data_ptr(),
+                                                          sc.keep.data_ptr(), aux, 3, stream),
         }
         reps = max(10, min(args.steps, 50))
         kernel_us = {}

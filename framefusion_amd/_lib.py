@@ -48,11 +48,15 @@ PROTOTYPES = {
     "ff_plan_merge": (_i32, [_vp, _i32, _vp, _i64, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ff_plan_from_index": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ff_plan_prune": (_i32, [_vp, _i32, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "ff_merge_compact": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp, C.POINTER(FFAux), _i32, _vp]),
+    "ff_merge_compact": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _vp, _i32, _vp, _vp, C.POINTER(FFAux), _i32,
+                                _vp]),
     "ff_gather_mask": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "ff_head_mean": (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _vp]),
     "ff_last_query_attention": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _i64, _i64, _f64, _i32, _vp, _vp, _vp,
                                        _sz, _vp]),
+    "ff_merge_begin": (_i32, [_vp, _i32, _i64, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ff_merge_finish": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                               _i64, C.POINTER(FFAux), _i32, _vp, _sz, _vp]),
     "ff_merge_step": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _i64, _i32, _f64, _f64, _f64, _vp, _vp, _vp,
                              _vp, _vp, _vp, _vp, _i64, C.POINTER(FFAux), _i32, _vp, _sz, _vp]),
 }

@@ -5,11 +5,8 @@
 
 namespace ff {
 int launch_plan_merge(const void* sim, int dtype, const int32_t* order, int64_t L, double thr, double sub,
-                      double ratio_lb, int32_t* run_len, int32_t* dst, uint8_t* keep, int64_t* stats,
+                      double ratio_lb, uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
                       void* ws, int64_t* host_mapped, int64_t seq, hipStream_t st);
-int launch_merge_compact(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
-                         const int32_t* order, const int32_t* run_len, const int32_t* dst,
-                         const ff_aux_t* aux_host, int n_aux, hipStream_t st);
 }  // namespace ff
 
 extern "C" int ff_abi_version(void) { return FF_ABI_VERSION; }
@@ -28,29 +25,46 @@ extern "C" const char* ff_error_string(int code) {
 extern "C" size_t ff_workspace_bytes(int64_t L, int64_t patch_num) {
     (void)patch_num;
     if (L < 0) return 0;
-    return (size_t)((L + 255) / 256 * 256 + 256);
+    return (size_t)256;   // the Select record handed from k_select to k_flags
+}
+
+extern "C" int ff_merge_begin(const void* hidden, int dtype, int64_t L, int64_t d, const int64_t* patch_type,
+                              int64_t patch_num, int order_valid, int32_t* order, void* sim, int64_t* stats,
+                              void* ws, size_t ws_bytes, ff_stream_t stream) {
+    if (!hidden || !patch_type || !order || !sim || !stats || !ws) return FF_ERR_ARG;
+    if (ws_bytes < ff_workspace_bytes(L, patch_num)) return FF_ERR_WORKSPACE;
+    if (!order_valid) {
+        int rc = ff_build_order(patch_type, L, patch_num, order, stats, ws, ws_bytes, stream);
+        if (rc) return rc;
+    }
+    return ff_pair_similarity(hidden, dtype, L, d, patch_type, order, stats, sim, stream);
+}
+
+extern "C" int ff_merge_finish(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
+                               double threshold, double sub, double ratio_lb, const int32_t* order, const void* sim,
+                               uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
+                               int64_t* stats_host_mapped, int64_t seq, const ff_aux_t* aux_host, int n_aux,
+                               void* ws, size_t ws_bytes, ff_stream_t stream) {
+    if (!hidden || !hidden_out || !order || !sim || !member || !dst || !keep || !stats || !ws) return FF_ERR_ARG;
+    if (ws_bytes < ff_workspace_bytes(L, 1)) return FF_ERR_WORKSPACE;
+    if (L_cap < L) return FF_ERR_ARG;
+    if (dtype != FF_F32 && dtype != FF_BF16 && dtype != FF_F16) return FF_ERR_ARG;
+    if (L == 0) return FF_OK;
+    int rc = ff::launch_plan_merge(sim, dtype, order, L, threshold, sub, ratio_lb, member, dst, keep, stats, ws,
+                                   stats_host_mapped, seq, (hipStream_t)stream);
+    if (rc) return rc;
+    return ff_merge_compact(hidden, hidden_out, dtype, L, d, L_cap, order, member, 1, dst, keep, aux_host, n_aux, stream);
 }
 
 extern "C" int ff_merge_step(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
                              const int64_t* patch_type, int64_t patch_num, int order_valid, double threshold,
-                             double sub, double ratio_lb, int32_t* order, void* sim, int32_t* run_len,
+                             double sub, double ratio_lb, int32_t* order, void* sim, uint8_t* member,
                              int32_t* dst, uint8_t* keep, int64_t* stats, int64_t* stats_host_mapped,
                              int64_t seq, const ff_aux_t* aux_host, int n_aux, void* ws, size_t ws_bytes,
                              ff_stream_t stream) {
-    if (!hidden || !hidden_out || !patch_type || !order || !sim || !run_len || !dst || !keep || !stats || !ws)
-        return FF_ERR_ARG;
-    if (ws_bytes < ff_workspace_bytes(L, patch_num)) return FF_ERR_WORKSPACE;
-    if (L_cap < L) return FF_ERR_ARG;
-    int rc;
-    if (!order_valid) {
-        rc = ff_build_order(patch_type, L, patch_num, order, stats, ws, ws_bytes, stream);
-        if (rc) return rc;
-    }
-    rc = ff_pair_similarity(hidden, dtype, L, d, patch_type, order, stats, sim, stream);
+    int rc = ff_merge_begin(hidden, dtype, L, d, patch_type, patch_num, order_valid, order, sim, stats, ws, ws_bytes,
+                            stream);
     if (rc) return rc;
-    if (L == 0) return FF_OK;
-    rc = ff::launch_plan_merge(sim, dtype, order, L, threshold, sub, ratio_lb, run_len, dst, keep, stats, ws,
-                               stats_host_mapped, seq, (hipStream_t)stream);
-    if (rc) return rc;
-    return ff_merge_compact(hidden, hidden_out, dtype, L, d, L_cap, order, run_len, dst, aux_host, n_aux, stream);
+    return ff_merge_finish(hidden, hidden_out, dtype, L, d, L_cap, threshold, sub, ratio_lb, order, sim, member, dst,
+                           keep, stats, stats_host_mapped, seq, aux_host, n_aux, ws, ws_bytes, stream);
 }

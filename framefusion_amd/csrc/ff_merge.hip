@@ -5,8 +5,8 @@
 // folded row exactly once and writes every output row exactly once.
 //
 // Work decomposition: by INPUT rows, not output rows - a wave owns kSlots consecutive slots t of
-// the by-patch order (then the non-visual tail) for one 4 KiB column block.  Slots whose run_len
-// is -1 are members: they are read by the wave that owns their anchor.  Because every input row
+// the by-patch order (then the non-visual tail) for one 1 KiB column block.  Member slots are
+// read by the wave that owns their anchor.  Because every input row
 // is read by exactly one wave per column block and slots are spread evenly, the HBM read load is
 // balanced no matter how long individual runs are (an output-row decomposition would leave the
 // longest run as the tail).
@@ -15,14 +15,16 @@
 // order with a rounding to the activation dtype T after EVERY add, then one rounded divide by
 // T(n+1) - the order CPU index_add_ applies; fp32-accumulate-then-round differs on ~23 % of
 // elements by more than 1e-3 relative.
+#include <stdlib.h>
+
 #include "ff_common.h"
 
 namespace ff {
 
 constexpr int kMergeThreads = 256;
 constexpr int kMergeWaves = kMergeThreads / kWave;
-constexpr int kSlots = 8;     // consecutive by-patch slots per workgroup
-constexpr int kChunks = 2;    // 1 KiB chunks per column block: a wave moves 2 KiB of a row at a time
+constexpr int kSlotsDefault = 32;  // consecutive by-patch slots per workgroup (<= 56)
+
 
 struct AuxPack {
     ff_aux_t a[FF_MAX_AUX];
@@ -50,117 +52,148 @@ __device__ inline void copy_row(const char* __restrict__ src, char* __restrict__
 }
 
 // Waves are independent (no LDS, no barrier): the 4 waves of a workgroup own the same kSlots
-// consecutive by-patch slots and one 2 KiB column block each, so together they read whole 8 KiB
-// rows.  One coalesced load of order[t0 .. t0+63] / run_len[...] gives a wave the anchors AND
-// the member rows that follow them (members are simply the next slots), so the only dependent
-// index fetch is dst[] for the anchors.  Row pieces move as raw buffer loads/stores (lanes past
-// the row end read 0 / are dropped); member pieces are prefetched two ahead and the next slot's
-// anchor piece is requested before the current slot's members are folded.
-template <int DT>
+// consecutive by-patch slots and one 1 KiB column tile each (16 bytes per lane), so a workgroup
+// reads 4 KiB of a row at a time.  A wave treats its job as a STREAM of rows in by-patch order:
+// it starts at its first non-member slot and runs until the first non-member slot at or beyond
+// t0 + kSlots; a non-member row opens a new output row, a member row is folded into the open one.
+// One coalesced load of order[] / member[] for 64 slots tells the wave the whole stream, so the
+// row pieces are requested kDepth at a time, the next batch being issued BEFORE the current one
+// is folded (two register batches), with no dependent index fetch in between (dst[] is only
+// needed by the stores).  The additions stay sequential - a rounding after each - but the loads
+// do not wait for them.  Row pieces move as raw buffer loads/stores (lanes past the row end read
+// 0 / are dropped).
+template <int kDepth>
+struct Batch {
+    uint4 buf[kDepth];
+    int idx[kDepth];       // sequence index of each row (wave-uniform)
+    int pos, take;
+    unsigned mem_bits;
+    bool last;
+};
+
+template <int DT, int kDepth>
 __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
     const char* __restrict__ hidden, char* __restrict__ out, uint32_t row_bytes, int L, int64_t L_cap,
-    const int32_t* __restrict__ order, const int32_t* __restrict__ run_len, const int32_t* __restrict__ dst,
-    AuxPack aux) {
+    const int32_t* __restrict__ order, const uint8_t* __restrict__ member, int fold,
+    const int32_t* __restrict__ dst, const uint8_t* __restrict__ keep, AuxPack aux, int kSlots, int n_main,
+    int ablate) {
     using A = Act<DT>;
     constexpr int E = A::kPer16;
-    constexpr uint32_t kBlk = kChunks * 1024u;
     const int lane = lane_id();
+    if ((int)blockIdx.x >= n_main) {
+        // ---- auxiliary rows (position embeddings, patch types, position ids): plain compaction by
+        // SEQUENCE position - reads coalesced, writes in increasing order.  Only blockIdx.y == 0.
+        if (blockIdx.y != 0 || (ablate & 2)) return;
+        const int i = ((int)blockIdx.x - n_main) * kMergeWaves * 4 + wave_id() * 4 + (lane >> 4);
+        const int sub = lane & 15;                       // 16 lanes per row
+        if (i >= L || !keep[i]) return;
+        const int r = dst[i];
+        for (int x = 0; x < aux.n; ++x) {
+            const ff_aux_t& ax = aux.a[x];
+            for (int64_t ou = 0; ou < ax.outer; ++ou)
+                copy_row((const char*)ax.src + (ou * L + i) * ax.row_bytes,
+                         (char*)ax.dst + (ou * L_cap + r) * ax.row_bytes, ax.row_bytes, sub, 16);
+        }
+        return;
+    }
     const int t0 = blockIdx.x * kSlots;
-    const int cb = uniform(blockIdx.y * kMergeWaves + wave_id());
-    const uint32_t col = (uint32_t)cb * kBlk;
+    const int cb = uniform(blockIdx.y * kMergeWaves + wave_id());     // 1 KiB column tile
+    const uint32_t col = (uint32_t)cb * 1024u;
     if (col >= row_bytes) return;
-    const uint32_t blk_bytes = min(kBlk, row_bytes - col);
+    const uint32_t blk_bytes = min(1024u, row_bytes - col);
     const uint32_t voff = (uint32_t)lane * 16;
+    const int t_end = min(t0 + kSlots, L);
 
-    const int tl = t0 + lane;
-    const int rl = tl < L ? run_len[tl] : -1;
-    const int ord = tl < L ? (order ? order[tl] : tl) : 0;
-    const int dv = (lane < kSlots && rl >= 0) ? dst[ord] : 0;
+    // window of 64 slots: row indices and member flags
+    int win = t0;
+    int ordw = (t0 + lane < L) ? (order ? order[t0 + lane] : t0 + lane) : 0;
+    unsigned long long memw = __ballot((t0 + lane < L) ? (member[t0 + lane] != 0) : false);
+    // output rows of my anchors (only slots [t0, t_end) can open a row here)
+    const bool anchor_lane = t0 + lane < t_end && !((memw >> lane) & 1ull);
+    const int dv = anchor_lane ? dst[ordw] : 0;
 
-    auto row_of = [&](int t_abs) -> int {     // sequence index of by-patch slot t_abs (wave-uniform)
-        const int rel = t_abs - t0;
-        return rel < kWave ? __builtin_amdgcn_readlane(ord, rel) : uniform(order[t_abs]);
-    };
+    // first slot of the stream
+    const unsigned long long own = (1ull << (t_end - t0)) - 1ull;         // kSlots <= 56
+    const unsigned long long starts = ~memw & own;
+    if (starts == 0ull) return;                             // every slot here belongs to an earlier anchor
+
     auto piece = [&](int i) { return make_rsrc(hidden + (int64_t)i * row_bytes + col, blk_bytes); };
 
-    uint4 a[kChunks];
-    int q = 0;
-    // first live slot
-    while (q < kSlots && __builtin_amdgcn_readlane(rl, q) < 0) ++q;
-    if (q < kSlots) {
-        const __amdgpu_buffer_rsrc_t src = piece(__builtin_amdgcn_readlane(ord, q));
-#pragma unroll
-        for (int c = 0; c < kChunks; ++c) a[c] = buf_load16(src, voff + c * 1024u);
-    }
-    while (q < kSlots) {
-        const int n = __builtin_amdgcn_readlane(rl, q);
-        const int i = __builtin_amdgcn_readlane(ord, q);
-        const int r = __builtin_amdgcn_readlane(dv, q);
-        int qn = q + 1;
-        while (qn < kSlots && __builtin_amdgcn_readlane(rl, qn) < 0) ++qn;
-        uint4 an[kChunks];
-        if (qn < kSlots) {      // request the next slot's anchor piece now
-            const __amdgpu_buffer_rsrc_t src = piece(__builtin_amdgcn_readlane(ord, qn));
-#pragma unroll
-            for (int c = 0; c < kChunks; ++c) an[c] = buf_load16(src, voff + c * 1024u);
+    // request the next (up to) kDepth rows of the stream
+    auto issue = [&](Batch<kDepth>& b, int pos) {
+        if (pos - win > kWave - kDepth) {                   // keep kDepth slots of lookahead in the window
+            win = pos;
+            ordw = (pos + lane < L) ? (order ? order[pos + lane] : pos + lane) : 0;
+            memw = __ballot((pos + lane < L) ? (member[pos + lane] != 0) : false);
         }
-        if (n > 0) {
-            const int t = t0 + q;
-            float acc[kChunks][E];
-            uint4 n0[kChunks], n1[kChunks];
-            {
-                const __amdgpu_buffer_rsrc_t m0 = piece(row_of(t + 1));
+        const int rel = pos - win;
+        int take = 0;
+        unsigned mem_bits = 0;
 #pragma unroll
-                for (int c = 0; c < kChunks; ++c) n0[c] = buf_load16(m0, voff + c * 1024u);
-            }
-            if (n > 1) {
-                const __amdgpu_buffer_rsrc_t m1 = piece(row_of(t + 2));
+        for (int u = 0; u < kDepth; ++u) {
+            const int s = pos + u;
+            const bool is_mem = (memw >> (rel + u)) & 1ull;
+            const bool in = take == u && s < L && (is_mem || s < t_end);
+            if (in) { ++take; mem_bits |= is_mem ? (1u << u) : 0u; }
+            b.idx[u] = __builtin_amdgcn_readlane(ordw, rel + u);
+        }
+        b.pos = pos; b.take = take; b.mem_bits = mem_bits; b.last = take < kDepth;
 #pragma unroll
-                for (int c = 0; c < kChunks; ++c) n1[c] = buf_load16(m1, voff + c * 1024u);
-            }
+        for (int u = 0; u < kDepth; ++u) {
+            const bool is_mem = (mem_bits >> u) & 1u;
+            if (u < take && (fold || !is_mem)) b.buf[u] = buf_load16(piece(b.idx[u]), voff);
+        }
+    };
+
+    float acc[E];
+    int open_r = -1, open_n = 0;                            // the output row being accumulated
+    auto flush = [&]() {
+        float o[E];
+        if (open_n > 0) {
+            const float div = A::rnd((float)(open_n + 1));
 #pragma unroll
-            for (int c = 0; c < kChunks; ++c) A::unpack(a[c], acc[c]);
-            for (int m = 1; m <= n; ++m) {
-                uint4 cur[kChunks];
+            for (int e = 0; e < E; ++e) o[e] = A::rnd(acc[e] / div);
+        } else {
 #pragma unroll
-                for (int c = 0; c < kChunks; ++c) { cur[c] = n0[c]; n0[c] = n1[c]; }
-                if (m + 2 <= n) {
-                    const __amdgpu_buffer_rsrc_t mr = piece(row_of(t + m + 2));
+            for (int e = 0; e < E; ++e) o[e] = acc[e];
+        }
+        if (!(ablate & 1)) buf_store16(make_rsrc(out + (int64_t)open_r * row_bytes + col, blk_bytes), voff, A::pack(o));
+        else if (o[0] == 1.2345f) buf_store16(make_rsrc(out, 16), 0, A::pack(o));
+    };
+    auto fold_batch = [&](Batch<kDepth>& b) {
 #pragma unroll
-                    for (int c = 0; c < kChunks; ++c) n1[c] = buf_load16(mr, voff + c * 1024u);
-                }
-#pragma unroll
-                for (int c = 0; c < kChunks; ++c) {
+        for (int u = 0; u < kDepth; ++u) {
+            if (u < b.take) {
+                const bool is_mem = (b.mem_bits >> u) & 1u;
+                if (!is_mem) {
+                    if (open_r >= 0) flush();
+                    open_r = __builtin_amdgcn_readlane(dv, b.pos + u - t0);
+                    open_n = 0;
+                    A::unpack(b.buf[u], acc);
+                } else if (fold) {
                     float x[E];
-                    A::unpack(cur[c], x);
+                    A::unpack(b.buf[u], x);
 #pragma unroll
-                    for (int e = 0; e < E; ++e) acc[c][e] = A::rnd(acc[c][e] + x[e]);
+                    for (int e = 0; e < E; ++e) acc[e] = A::rnd(acc[e] + x[e]);
+                    ++open_n;
                 }
             }
-            const float div = A::rnd((float)(n + 1));
-#pragma unroll
-            for (int c = 0; c < kChunks; ++c) {
-#pragma unroll
-                for (int e = 0; e < E; ++e) acc[c][e] = A::rnd(acc[c][e] / div);
-                a[c] = A::pack(acc[c]);
-            }
         }
-        const __amdgpu_buffer_rsrc_t dstr = make_rsrc(out + (int64_t)r * row_bytes + col, blk_bytes);
-#pragma unroll
-        for (int c = 0; c < kChunks; ++c) buf_store16(dstr, voff + c * 1024u, a[c]);
-        // position embeddings / patch types / position ids ride along: tiny rows, same mapping
-        if (cb == 0) {
-            for (int x = 0; x < aux.n; ++x) {
-                const ff_aux_t& ax = aux.a[x];
-                for (int64_t o = 0; o < ax.outer; ++o)
-                    copy_row((const char*)ax.src + (o * L + i) * ax.row_bytes,
-                             (char*)ax.dst + (o * L_cap + r) * ax.row_bytes, ax.row_bytes, lane, kWave);
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < kChunks; ++c) a[c] = an[c];
-        q = qn;
+    };
+
+    Batch<kDepth> b0, b1;
+    int pos = t0 + __ffsll((long long)starts) - 1;
+    issue(b0, pos);
+    pos += b0.take;
+    while (true) {
+        if (!b0.last) { issue(b1, pos); pos += b1.take; }
+        fold_batch(b0);
+        if (b0.last) break;
+        if (!b1.last) { issue(b0, pos); pos += b0.take; }
+        fold_batch(b1);
+        if (b1.last) break;
     }
+    if (open_r >= 0) flush();
 }
 
 // out[r, c] = mask[i_r, i_c]: one workgroup per kept input row, threads over input columns.
@@ -194,30 +227,46 @@ __global__ __launch_bounds__(256) void k_head_mean(const void* __restrict__ w, i
     A::store1(imp, s, acc / (float)rows);
 }
 
+template <int DT>
+static void launch_mc(dim3 grid, hipStream_t st, int depth, const char* h, char* o, uint32_t row_bytes, int L,
+                      int64_t L_cap, const int32_t* order, const uint8_t* member, int fold, const int32_t* dst,
+                      const uint8_t* keep, const AuxPack& pack, int slots, int n_main, int ablate) {
+    if (depth == 4)
+        hipLaunchKernelGGL((k_merge_compact<DT, 4>), grid, dim3(kMergeThreads), 0, st, h, o, row_bytes, L, L_cap, order,
+                           member, fold, dst, keep, pack, slots, n_main, ablate);
+    else
+        hipLaunchKernelGGL((k_merge_compact<DT, 8>), grid, dim3(kMergeThreads), 0, st, h, o, row_bytes, L, L_cap, order,
+                           member, fold, dst, keep, pack, slots, n_main, ablate);
+}
+
 int launch_merge_compact(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
-                         const int32_t* order, const int32_t* run_len, const int32_t* dst,
-                         const ff_aux_t* aux_host, int n_aux, hipStream_t st) {
+                         const int32_t* order, const uint8_t* member, int fold, const int32_t* dst,
+                         const uint8_t* keep, const ff_aux_t* aux_host, int n_aux, hipStream_t st) {
     AuxPack pack;
-    pack.n = n_aux;
-    for (int x = 0; x < n_aux; ++x) pack.a[x] = aux_host[x];
-    for (int x = n_aux; x < FF_MAX_AUX; ++x) pack.a[x] = ff_aux_t{nullptr, nullptr, 0, 0};
+    pack.n = keep ? n_aux : 0;
+    for (int x = 0; x < pack.n; ++x) pack.a[x] = aux_host[x];
+    for (int x = pack.n; x < FF_MAX_AUX; ++x) pack.a[x] = ff_aux_t{nullptr, nullptr, 0, 0};
     const int64_t row_bytes = d * (dtype == FF_F32 ? 4 : 2);
-    const int nblk = (int)((row_bytes + kChunks * 1024 - 1) / (kChunks * 1024));
-    const dim3 blocks((unsigned)((L + kSlots - 1) / kSlots), (unsigned)((nblk + kMergeWaves - 1) / kMergeWaves));
+    const int nblk = (int)((row_bytes + 1023) / 1024);
+    static int slots = 0, depth = 0, ablate = 0;
+    if (!slots) {
+        const char* e1 = getenv("FF_MERGE_SLOTS");
+        const char* e2 = getenv("FF_MERGE_DEPTH");
+        const char* e3 = getenv("FF_MERGE_ABLATE");
+        slots = e1 ? atoi(e1) : kSlotsDefault;
+        depth = e2 ? atoi(e2) : 4;
+        ablate = e3 ? atoi(e3) : 0;
+        if (slots < 1 || slots > 56) slots = kSlotsDefault;
+    }
+    const int n_main = (int)((L + slots - 1) / slots);
+    const int n_aux_blocks = pack.n ? (int)((L + kMergeWaves * 4 - 1) / (kMergeWaves * 4)) : 0;
+    const dim3 grid((unsigned)(n_main + n_aux_blocks), (unsigned)((nblk + kMergeWaves - 1) / kMergeWaves));
     const char* h = (const char*)hidden;
     char* o = (char*)hidden_out;
     switch (dtype) {
-        case FF_F32:
-            hipLaunchKernelGGL(k_merge_compact<FF_F32>, blocks, dim3(kMergeThreads), 0, st, h, o,
-                               (uint32_t)row_bytes, (int)L, L_cap, order, run_len, dst, pack);
-            break;
-        case FF_BF16:
-            hipLaunchKernelGGL(k_merge_compact<FF_BF16>, blocks, dim3(kMergeThreads), 0, st, h, o,
-                               (uint32_t)row_bytes, (int)L, L_cap, order, run_len, dst, pack);
-            break;
-        default:
-            hipLaunchKernelGGL(k_merge_compact<FF_F16>, blocks, dim3(kMergeThreads), 0, st, h, o,
-                               (uint32_t)row_bytes, (int)L, L_cap, order, run_len, dst, pack);
+        case FF_F32: launch_mc<FF_F32>(grid, st, depth, h, o, (uint32_t)row_bytes, (int)L, L_cap, order, member, fold, dst, keep, pack, slots, n_main, ablate); break;
+        case FF_BF16: launch_mc<FF_BF16>(grid, st, depth, h, o, (uint32_t)row_bytes, (int)L, L_cap, order, member, fold, dst, keep, pack, slots, n_main, ablate); break;
+        default: launch_mc<FF_F16>(grid, st, depth, h, o, (uint32_t)row_bytes, (int)L, L_cap, order, member, fold, dst, keep, pack, slots, n_main, ablate);
     }
     return (int)hipGetLastError();
 }
@@ -225,9 +274,11 @@ int launch_merge_compact(const void* hidden, void* hidden_out, int dtype, int64_
 }  // namespace ff
 
 extern "C" int ff_merge_compact(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d,
-                                int64_t L_cap, const int32_t* order, const int32_t* run_len, const int32_t* dst,
-                                const ff_aux_t* aux_host, int n_aux, ff_stream_t stream) {
-    if (!hidden || !hidden_out || !run_len || !dst || L < 0 || d < 1 || L_cap < 0) return FF_ERR_ARG;
+                                int64_t L_cap, const int32_t* order, const uint8_t* member, int fold,
+                                const int32_t* dst, const uint8_t* keep, const ff_aux_t* aux_host, int n_aux,
+                                ff_stream_t stream) {
+    if (n_aux > 0 && !keep) return FF_ERR_ARG;
+    if (!hidden || !hidden_out || !member || !dst || L < 0 || d < 1 || L_cap < 0) return FF_ERR_ARG;
     if (dtype != FF_F32 && dtype != FF_BF16 && dtype != FF_F16) return FF_ERR_ARG;
     if (n_aux < 0 || n_aux > FF_MAX_AUX || (n_aux > 0 && !aux_host)) return FF_ERR_ARG;
     for (int x = 0; x < n_aux; ++x)
@@ -238,7 +289,7 @@ extern "C" int ff_merge_compact(const void* hidden, void* hidden_out, int dtype,
     if (((uintptr_t)hidden & 15) || ((uintptr_t)hidden_out & 15) || ((d * esz) & 15)) return FF_ERR_ALIGN;
     if (L >= (1ll << 29) || d * esz >= (1ll << 31)) return FF_ERR_UNSUPPORTED;
     if (L == 0) return FF_OK;
-    return ff::launch_merge_compact(hidden, hidden_out, dtype, L, d, L_cap, order, run_len, dst, aux_host, n_aux,
+    return ff::launch_merge_compact(hidden, hidden_out, dtype, L, d, L_cap, order, member, fold, dst, keep, aux_host, n_aux,
                                     (hipStream_t)stream);
 }
 

@@ -43,7 +43,7 @@ def _to_int(x) -> int:
 
 
 class _Scratch:
-    """Per-device integer scratch reused across calls (order, run_len, dst, keep, flags, stats)."""
+    """Per-device integer scratch reused across calls (order, member, dst, keep, stats)."""
 
     def __init__(self, device):
         self.device = device
@@ -55,7 +55,7 @@ class _Scratch:
             cap = max(L, 1024)
             dev = self.device
             self.order = torch.empty(cap, dtype=torch.int32, device=dev)
-            self.run_len = torch.empty(cap, dtype=torch.int32, device=dev)
+            self.member = torch.empty(cap, dtype=torch.uint8, device=dev)
             self.dst = torch.empty(cap, dtype=torch.int32, device=dev)
             self.keep = torch.empty(cap, dtype=torch.uint8, device=dev)
             self.sim32 = torch.empty(cap, dtype=torch.float32, device=dev)   # viewed as T
@@ -63,12 +63,29 @@ class _Scratch:
             self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
             self.stats = torch.zeros(_lib.STAT_WORDS, dtype=torch.int64, device=dev)
             self.stats_host = torch.zeros(_lib.STAT_WORDS, dtype=torch.int64).pin_memory()
+            self.stats_host_ptr = self.stats_host.data_ptr()     # device-visible (pinned, UVA)
+            self.stats_np = self.stats_host.numpy()              # shares the pinned memory
+            self.seq = 0
             self.cap = cap
             self.order_valid_for = None
         return self
 
     def sim(self, dtype, n):
         return self.sim32.view(dtype)[:n]
+
+    def wait_stats(self, seq, spins=4_000_000):
+        """Poll the pinned result block until the device has published call `seq`."""
+        view = self.stats_np
+        word = _lib.STAT_SEQ
+        n = 0
+        while view[word] != seq:
+            n += 1
+            if n > spins:
+                torch.cuda.current_stream().synchronize()
+                if view[word] != seq:
+                    raise FrameFusionHipError("the device never published the result block of this call")
+                break
+        return view
 
 
 class FrameFusion(nn.Module):
@@ -180,7 +197,7 @@ class FrameFusion(nn.Module):
         device = hidden_states.device
         dtype = hidden_states.dtype
         code = _dtype_code(hidden_states)
-        hidden = hidden_states.contiguous()
+        hidden = hidden_states if hidden_states.is_contiguous() else hidden_states.contiguous()
 
         ptype = self.patch_type
         if ptype.device != device or ptype.dtype != torch.int64 or not ptype.is_contiguous():
@@ -190,10 +207,20 @@ class FrameFusion(nn.Module):
             raise FrameFusionHipError(f"patch_type has {ptype.numel()} entries for a sequence of {L}")
 
         sub = self._compute_pruning_ratio(self.sparsity_list, self.cost)           # main.py:109
-        thr = _round_to(self.similarity_lower_bound, dtype)
-
         sc = self._scratch_for(device, L, dtype)
         stream = _lib.stream_ptr()
+        sim_ptr = sc.sim32.data_ptr()
+        order_key = (ptype.data_ptr(), L)
+        order_valid = 1 if sc.order_valid_for == order_key else 0
+
+        # first half (K0 + K1) goes out before any output tensor exists: the allocations below
+        # overlap the similarity pass
+        rc = lib.ff_merge_begin(hidden.data_ptr(), code, L, d, ptype.data_ptr(), int(self.patch_num), order_valid,
+                                sc.order.data_ptr(), sim_ptr, sc.stats.data_ptr(), sc.ws.data_ptr(), sc.ws_bytes,
+                                stream)
+        _lib.check(rc, "ff_merge_begin")
+
+        thr = _round_to(self.similarity_lower_bound, dtype)
         L_cap = L
         out = torch.empty(1, L_cap, d, dtype=dtype, device=device)
         ptype_out = torch.empty(1, L_cap, dtype=torch.int64, device=device)
@@ -201,31 +228,29 @@ class FrameFusion(nn.Module):
         aux = (FFAux * _lib.MAX_AUX)()
         n_aux = self._fill_aux(aux, 0, [ptype.view(1, L)], [ptype_out], L)
         n_aux = self._fill_aux(aux, n_aux, srcs, outs, L)
-
-        order_key = (ptype.data_ptr(), L)
-        order_valid = 1 if sc.order_valid_for == order_key else 0
-        sim = sc.sim(dtype, L)
-        rc = lib.ff_merge_step(hidden.data_ptr(), out.data_ptr(), code, L, d, L_cap,
-                               ptype.data_ptr(), int(self.patch_num), order_valid,
-                               float(thr), float(sub), float(self.ratio_lower_bound),
-                               sc.order.data_ptr(), sim.data_ptr(), sc.run_len.data_ptr(), sc.dst.data_ptr(),
-                               sc.keep.data_ptr(), sc.stats.data_ptr(), None, 0,
-                               aux, n_aux, sc.ws.data_ptr(), sc.ws_bytes, stream)
-        _lib.check(rc, "ff_merge_step")
+        sc.seq += 1
+        seq = sc.seq
+        rc = lib.ff_merge_finish(hidden.data_ptr(), out.data_ptr(), code, L, d, L_cap,
+                                 float(thr), float(sub), float(self.ratio_lower_bound),
+                                 sc.order.data_ptr(), sim_ptr, sc.member.data_ptr(), sc.dst.data_ptr(),
+                                 sc.keep.data_ptr(), sc.stats.data_ptr(), sc.stats_host_ptr, seq,
+                                 aux, n_aux, sc.ws.data_ptr(), sc.ws_bytes, stream)
+        _lib.check(rc, "ff_merge_finish")
         mask_out = None
         if attention_mask is not None:
             mask_out = self._gather_mask(attention_mask, L, L_cap, sc.dst, stream)
 
-        # the one device->host readback of the call
-        sc.stats_host.copy_(sc.stats, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
-        st = sc.stats_host.tolist()
-        nv, ftn, count = st[_lib.STAT_NV], st[_lib.STAT_FTN], st[_lib.STAT_COUNT]
-        L_out = st[_lib.STAT_LOUT]
+        # The one device->host hand-off of the call: the scan kernel stores the result block into
+        # pinned host memory (sequence word last) BEFORE the merge kernel runs, so the host learns
+        # L_out while the second streaming pass is still in flight and returns without waiting for it.
+        st = sc.wait_stats(seq)
+        nv, ftn, count = int(st[_lib.STAT_NV]), int(st[_lib.STAT_FTN]), int(st[_lib.STAT_COUNT])
+        L_out = int(st[_lib.STAT_LOUT])
+        branch = int(st[_lib.STAT_BRANCH])
         assert nv > 0, "no visual tokens"                                          # main.py:240
 
         above_k_ratio = count / ftn                                                 # main.py:114
-        if st[_lib.STAT_BRANCH] == 0:                                               # main.py:116-120
+        if branch == 0:                                                             # main.py:116-120
             self.sparsity_list.append(above_k_ratio)
             if above_k_ratio < self.ratio_lower_bound:
                 self.finish_merging = True
@@ -235,14 +260,20 @@ class FrameFusion(nn.Module):
 
         self.patch_type = ptype_out[:, :L_out]                                      # main.py:132
         sc.order_valid_for = None
-        self.last_call = dict(kind="merge", L_in=L, L_out=L_out, nv=nv, ftn=ftn, count=count,
-                              branch=st[_lib.STAT_BRANCH], k=st[_lib.STAT_K], keep=sc.keep[:L],
-                              sim=sim[:nv], order=sc.order[:nv], run_len=sc.run_len[:L], stats=st)
+        self.last_call = dict(kind="merge", L_in=L, L_out=L_out, nv=nv, ftn=ftn, count=count, branch=branch,
+                              k=int(st[_lib.STAT_K]), scratch=sc, dtype=dtype)
         hidden_states = out[:, :L_out]
         position_embeddings = rebuild(L_out)
         if mask_out is not None:
             attention_mask = mask_out[:, :, :L_out, :L_out]
         return hidden_states, position_embeddings, attention_mask
+
+    def last_plan(self):
+        """Diagnostics of the most recent merge call (views into the reusable scratch: valid until
+        the next call): keep mask by sequence position, similarities, by-patch order, member flags."""
+        c = self.last_call
+        sc, L, nv = c["scratch"], c["L_in"], c["nv"]
+        return dict(keep=sc.keep[:L], sim=sc.sim(c["dtype"], nv), order=sc.order[:nv], member=sc.member[:L])
 
     # ---- prune call: main.py:61-101 ----------------------------------------------------------------
     def _prune(self, hidden_states, position_embeddings, attention_mask, self_attn_weights):
@@ -274,7 +305,7 @@ class FrameFusion(nn.Module):
         if k < 0 or k > n_img:
             raise RuntimeError("selected index k out of range")                     # torch.topk's error
         L_out = q_len - n_img + k
-        _lib.check(lib.ff_plan_prune(imp.data_ptr(), code, q_len, start, n_img, k, sc.run_len.data_ptr(),
+        _lib.check(lib.ff_plan_prune(imp.data_ptr(), code, q_len, start, n_img, k, sc.member.data_ptr(),
                                      sc.dst.data_ptr(), sc.keep.data_ptr(), sc.stats.data_ptr(),
                                      sc.ws.data_ptr(), sc.ws_bytes, stream), "ff_plan_prune")
         out = torch.empty(1, L_out, d, dtype=dtype, device=device)
@@ -282,13 +313,13 @@ class FrameFusion(nn.Module):
         aux = (FFAux * _lib.MAX_AUX)()
         n_aux = self._fill_aux(aux, 0, srcs, outs, q_len)
         _lib.check(lib.ff_merge_compact(hidden.data_ptr(), out.data_ptr(), code, q_len, d, L_out, None,
-                                        sc.run_len.data_ptr(), sc.dst.data_ptr(), aux, n_aux, stream),
+                                        sc.member.data_ptr(), 0, sc.dst.data_ptr(), sc.keep.data_ptr(), aux, n_aux,
+                                        stream),
                    "ff_merge_compact")
         if attention_mask is not None:
             attention_mask = self._gather_mask(attention_mask, q_len, L_out, sc.dst, stream)
         self.finish_pruning = True                                                  # main.py:101
-        self.last_call = dict(kind="prune", L_in=q_len, L_out=L_out, k=k, keep=sc.keep[:q_len],
-                              importance=imp)
+        self.last_call = dict(kind="prune", L_in=q_len, L_out=L_out, k=k, nv=q_len, scratch=sc, dtype=dtype)
         return out, rebuild(L_out), attention_mask
 
     # ---- static parity entry points ---------------------------------------------------------------
@@ -334,7 +365,7 @@ class FrameFusion(nn.Module):
         rest[token_index_by_patch[0]] = False
         order = torch.cat((order32, torch.nonzero(rest).reshape(-1).to(torch.int32))).contiguous()
         midx = merge_index_by_patch.to(device=device, dtype=torch.int64).contiguous()
-        run_len = torch.empty(L, dtype=torch.int32, device=device)
+        member = torch.empty(L, dtype=torch.uint8, device=device)
         dst = torch.empty(L, dtype=torch.int32, device=device)
         keep = torch.empty(L, dtype=torch.uint8, device=device)
         stats = torch.zeros(_lib.STAT_WORDS, dtype=torch.int64, device=device)
@@ -342,13 +373,14 @@ class FrameFusion(nn.Module):
         ws_bytes = int(lib.ff_workspace_bytes(L, 1))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
         stream = _lib.stream_ptr()
-        _lib.check(lib.ff_plan_from_index(midx.data_ptr(), midx.numel(), order.data_ptr(), L, run_len.data_ptr(),
+        _lib.check(lib.ff_plan_from_index(midx.data_ptr(), midx.numel(), order.data_ptr(), L, member.data_ptr(),
                                           dst.data_ptr(), keep.data_ptr(), stats.data_ptr(), ws.data_ptr(),
                                           ws_bytes, stream), "ff_plan_from_index")
         hidden = hidden_states.contiguous()
         compact = torch.empty(L, d, dtype=dtype, device=device)
         _lib.check(lib.ff_merge_compact(hidden.data_ptr(), compact.data_ptr(), code, L, d, L, order.data_ptr(),
-                                        run_len.data_ptr(), dst.data_ptr(), None, 0, stream), "ff_merge_compact")
+                                        member.data_ptr(), 1, dst.data_ptr(), None, None, 0, stream),
+                   "ff_merge_compact")
         keep_b = keep.bool()
         kept = torch.nonzero(keep_b).reshape(-1)
         hidden_states[0, kept] = compact[: kept.numel()]      # members keep their old rows, like the reference

@@ -94,38 +94,43 @@ int ff_pair_similarity(const void* hidden, int dtype, int64_t L, int64_t d,
  * Decision on device, in double like python: ratio = count/ftn; ratio < sub ? threshold set
  * : top-k with k = (int64)(sub*ftn), ties at the k-th value taken in ascending j.
  * Outputs (caller-allocated):
- *   run_len [L] int32 : for t in by-patch order (then the non-visual tail): -1 if token t is
- *                       folded into a predecessor, else the number n >= 0 of following tokens
- *                       folded into it (its run, main.py:282-301);
+ *   member  [L] uint8 : for slot t of the by-patch order (then the non-visual tail): 1 if token t
+ *                       is folded into its nearest preceding non-member slot (its run's anchor,
+ *                       main.py:282-301), else 0.  Slot 0 is never a member;
  *   dst     [L] int32 : for each SEQUENCE position i: its row in the compacted output, or -1;
  *   keep    [L] uint8 : the keep mask of main.py:278-279 by sequence position;
- *   stats             : FF_STAT_COUNT .. FF_STAT_TIES_TAKEN. */
+ *   stats             : FF_STAT_COUNT .. FF_STAT_TIES_TAKEN, FF_STAT_LOUT, FF_STAT_MERGED.
+ * dst, keep and ws must be 16-byte aligned; ws >= ff_workspace_bytes(). */
 int ff_plan_merge(const void* sim, int dtype, const int32_t* order, int64_t L,
                   double threshold, double sub, double ratio_lb,
-                  int32_t* run_len, int32_t* dst, uint8_t* keep, int64_t* stats,
+                  uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
                   void* ws, size_t ws_bytes, ff_stream_t stream);
 
 /* Same outputs for an EXPLICIT merge set (the static merge_tokens_and_get_mask entry point,
  * main.py:243-319): merge_index[0..n_merge) ascending by-patch positions. */
 int ff_plan_from_index(const int64_t* merge_index, int64_t n_merge, const int32_t* order, int64_t L,
-                       int32_t* run_len, int32_t* dst, uint8_t* keep, int64_t* stats,
+                       uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
                        void* ws, size_t ws_bytes, ff_stream_t stream);
 
 /* ---- prune plan (main.py:69-92) ---------------------------------------------------------------
  * importance [S] dtype T; keeps every position outside [start, start+n_img) and the k largest
- * inside it (ties -> lowest index).  Outputs as ff_plan_merge with order = identity. */
+ * inside it (ties -> lowest index).  Outputs as ff_plan_merge with order = identity; member[i] = 1
+ * marks a DROPPED position (nothing is folded: ff_merge_compact is then called with order = NULL
+ * and fold = 0). */
 int ff_plan_prune(const void* importance, int dtype, int64_t S, int64_t start, int64_t n_img,
-                  int64_t k, int32_t* run_len, int32_t* dst, uint8_t* keep, int64_t* stats,
+                  int64_t k, uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
                   void* ws, size_t ws_bytes, ff_stream_t stream);
 
 /* ---- K4: run merge + compaction ---------------------------------------------------------------
  * Replaces index_add_ + divide (main.py:304-317) and the keep-mask gathers of hidden /
  * position embeddings / patch_type (main.py:132-138, 161-178) in one pass.
- * For every t with run_len[t] = n >= 0, i = order[t] (order == NULL: i = t):
+ * For every slot t with member[t] == 0, i = order[t] (order == NULL: i = t), n = number of
+ * consecutive member slots after t (fold != 0; with fold == 0 members are simply dropped):
  *   out[dst[i]] = T( (..(T(h[i] + h[order[t+1]]) + ..) + h[order[t+n]]) / T(n+1) )   (n > 0)
  *   out[dst[i]] = h[i]                                                               (n == 0)
  * and each aux tensor (viewed as [outer, L, row_bytes] bytes) is gathered the same way into
- * [outer, L_cap, row_bytes]. `hidden_out` holds L_cap rows (L_cap >= L_out; L is always enough). */
+ * [outer, L_cap, row_bytes] (every kept position i goes to row dst[i]; `keep` is the plan's keep
+ * mask, only read when n_aux > 0). `hidden_out` holds L_cap rows (L_cap >= L_out; L is enough). */
 typedef struct {
     const void* src;     /* [outer, L, row_bytes]                         */
     void* dst;           /* [outer, L_cap, row_bytes]                     */
@@ -136,8 +141,8 @@ typedef struct {
 #define FF_MAX_AUX 4
 
 int ff_merge_compact(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d,
-                     int64_t L_cap, const int32_t* order, const int32_t* run_len,
-                     const int32_t* dst, const ff_aux_t* aux_host, int n_aux,
+                     int64_t L_cap, const int32_t* order, const uint8_t* member, int fold,
+                     const int32_t* dst, const uint8_t* keep, const ff_aux_t* aux_host, int n_aux,
                      ff_stream_t stream);
 
 /* Square attention-mask gather: out[r, c] = mask[src_r, src_c] for kept rows/cols
@@ -168,10 +173,23 @@ int ff_last_query_attention(const void* q_last, const void* k, int dtype, int64_
 int ff_merge_step(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
                   const int64_t* patch_type, int64_t patch_num, int order_valid,
                   double threshold, double sub, double ratio_lb,
-                  int32_t* order, void* sim, int32_t* run_len, int32_t* dst, uint8_t* keep,
+                  int32_t* order, void* sim, uint8_t* member, int32_t* dst, uint8_t* keep,
                   int64_t* stats, int64_t* stats_host_mapped, int64_t seq,
                   const ff_aux_t* aux_host, int n_aux,
                   void* ws, size_t ws_bytes, ff_stream_t stream);
+
+/* The same step in two halves, so the host can allocate the output tensors while the first
+ * streaming pass runs: begin = K0 (unless order_valid) + K1, finish = K2+K3 + K4. */
+int ff_merge_begin(const void* hidden, int dtype, int64_t L, int64_t d,
+                   const int64_t* patch_type, int64_t patch_num, int order_valid,
+                   int32_t* order, void* sim, int64_t* stats, void* ws, size_t ws_bytes,
+                   ff_stream_t stream);
+int ff_merge_finish(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
+                    double threshold, double sub, double ratio_lb,
+                    const int32_t* order, const void* sim, uint8_t* member, int32_t* dst, uint8_t* keep,
+                    int64_t* stats, int64_t* stats_host_mapped, int64_t seq,
+                    const ff_aux_t* aux_host, int n_aux,
+                    void* ws, size_t ws_bytes, ff_stream_t stream);
 
 #ifdef __cplusplus
 }

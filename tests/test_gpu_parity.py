@@ -181,7 +181,7 @@ def test_forward_golden(golden, name):
     hd = dev(h)
     out, pos_out, mask_out = ff(hd, pos, None if mask is None else dev(mask))
     keep = torch.from_numpy(g[f"{name}/keep"])
-    got_keep = torch.nonzero(ff.last_call["keep"].bool()).reshape(-1).cpu() if ff.last_call else torch.arange(L)
+    got_keep = torch.nonzero(ff.last_plan()["keep"].bool()).reshape(-1).cpu() if ff.last_call else torch.arange(L)
     assert np.array_equal(got_keep.numpy(), keep.numpy())
     assert same_bits(out[0].cpu(), from_bits(g[f"{name}/hidden_out"], dtype))
     assert np.array_equal(ff.patch_type[0].cpu().numpy(), g[f"{name}/patch_type_out"])
@@ -246,7 +246,7 @@ def run_plan(sim, thr, sub, lb, ftn=None):
     dtype = sim.dtype
     simd = dev(sim.contiguous())
     order = torch.arange(nv, dtype=torch.int32, device=DEV)
-    out = [torch.empty(nv, dtype=torch.int32, device=DEV), torch.empty(nv, dtype=torch.int32, device=DEV),
+    out = [torch.empty(nv, dtype=torch.uint8, device=DEV), torch.empty(nv, dtype=torch.int32, device=DEV),
            torch.empty(nv, dtype=torch.uint8, device=DEV)]
     stats = torch.zeros(_lib.STAT_WORDS, dtype=torch.int64, device=DEV)
     stats[_lib.STAT_NV] = nv
@@ -272,7 +272,7 @@ def test_select_threshold_and_topk(dt, n, seed):
     if n > 100:
         sim[7] = float("nan")
     for sub in (0.9, 0.3, 0.05, 0.0):
-        (run_len, dst, keep), st = run_plan(sim, 0.6, sub, 0.1)
+        (member, dst, keep), st = run_plan(sim, 0.6, sub, 0.1)
         count = int((sim >= 0.6).sum())
         assert int(st[_lib.STAT_COUNT]) == count
         ratio = count / n
@@ -291,14 +291,7 @@ def test_select_threshold_and_topk(dt, n, seed):
         assert torch.equal(keep, want_keep), sub
         assert int(st[_lib.STAT_LOUT]) == int(want_keep.sum())
         assert torch.equal(dst[want_keep.bool()], torch.arange(int(want_keep.sum()), dtype=torch.int32))
-        flags = torch.zeros(n, dtype=torch.long)
-        flags[members] = 1
-        lens = orc.run_lengths(flags[None])[0]
-        ends = torch.nonzero(lens).reshape(-1)
-        want_rl = torch.zeros(n, dtype=torch.int32)
-        want_rl[members] = -1
-        want_rl[ends - lens[ends]] = lens[ends].int()
-        assert torch.equal(run_len, want_rl), sub
+        assert torch.equal(member, 1 - want_keep), sub        # order = identity here
 
 
 # ---------------------------------------------------------------------------------------------

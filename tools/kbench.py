@@ -65,11 +65,11 @@ def main():
                   8 * L + 4 * L),
         "similarity": (lambda: lib.ff_pair_similarity(hidden.data_ptr(), code, L, d, ptype.data_ptr(), sc.order.data_ptr(),
                                                       sc.stats.data_ptr(), sim.data_ptr(), stream), nv * d * elt),
-        "plan": (lambda: lib.ff_plan_merge(sim.data_ptr(), code, sc.order.data_ptr(), L, thr, sub, 0.1, sc.run_len.data_ptr(),
+        "plan": (lambda: lib.ff_plan_merge(sim.data_ptr(), code, sc.order.data_ptr(), L, thr, sub, 0.1, sc.member.data_ptr(),
                                            sc.dst.data_ptr(), sc.keep.data_ptr(), sc.stats.data_ptr(), sc.ws.data_ptr(),
                                            sc.ws_bytes, stream), nv * elt + 4 * L * 3),
         "merge_compact": (lambda: lib.ff_merge_compact(hidden.data_ptr(), out_buf.data_ptr(), code, L, d, L, sc.order.data_ptr(),
-                                                       sc.run_len.data_ptr(), sc.dst.data_ptr(), aux, 3, stream),
+                                                       sc.member.data_ptr(), 1, sc.dst.data_ptr(), sc.keep.data_ptr(), aux, 3, stream),
                           (L + L_out) * d * elt + 2 * (L + L_out) * 128 * elt),
     }
     total = 0.0
