@@ -59,28 +59,21 @@ def algorithmic_bytes(L_in, L_out, nv, d, elt, head_dim, pe_outer=1):
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    elif args.gpus > 1:
+    from framefusion_amd import dp
+    world, rank, local = dp.env_world()
+    if world == 1 and args.gpus > 1:
         print("bench.py: --gpus > 1 must be launched with torch.distributed.run", file=sys.stderr)
         sys.exit(2)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    dist = dp.init("nccl", dev)
 
     import framefusion_amd as ffa
     from framefusion_amd import _lib
     from framefusion_amd.synth import video_tokens, rotary_tables
 
     F, P, d = args.frames, args.patches, args.dim
-    hidden, ptype = video_tokens(F, P, d, p_change=args.p_change, sigma=SIGMA, seed=1234 + rank,
+    hidden, ptype = video_tokens(F, P, d, p_change=args.p_change, sigma=SIGMA, seed=dp.sample_seed(1234, rank),
                                  dtype=torch.bfloat16, device=str(dev))
     L = hidden.shape[1]
     cos, sin = rotary_tables(L, HEAD_DIM, torch.bfloat16, device=str(dev))
@@ -92,9 +85,7 @@ def main():
         return out
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        dp.barrier(dist)
 
     for _ in range(args.warmup):
         step()
@@ -109,12 +100,7 @@ def main():
     reduced = L - L_out
 
     # whole-job numbers: max time over ranks, tokens summed over ranks
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    tok = torch.tensor([float(reduced * args.steps)], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tok, op=dist.ReduceOp.SUM)
-    t_max, tok_all = float(t), float(tok)
+    t_max, tok_all = dp.aggregate(dist, elapsed, float(reduced * args.steps), dev)
 
     result = None
     if rank == 0:

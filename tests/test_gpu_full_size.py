@@ -1,0 +1,133 @@
+"""GPU: parity at BASELINE.json's full sizes (configs C2/C3/C5) against the CPU oracle,
+plus size-independent properties of the reduction."""
+import numpy as np
+import pytest
+import torch
+
+import framefusion_amd as ffa
+from framefusion_amd.synth import video_tokens, rotary_tables
+from oracle import ff_oracle as orc
+from tests import harness
+from tests.conftest import same_bits
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def run_both(F, P, d, p_change, dtype=torch.bfloat16, pre=14, post=20, grid=0.125, sigma_hi=None,
+             params=(0.3, 0.6, 0.1), pos="qwen2", seed=1234):
+    h, pt = video_tokens(F, P, d, p_change=p_change, sigma=0.3, seed=seed, pre=pre, post=post, dtype=dtype,
+                         grid=grid, sigma_hi=sigma_hi)
+    L = h.shape[1]
+    mk = (lambda: rotary_tables(L, 128, dtype, mrope=(pos == "mrope")))
+    o = orc.OracleFrameFusion(*params)
+    o.prepare(pt.clone(), P, pre, pre + F * P, F * P, L)
+    ho, peo, _ = o.forward(h, mk(), None)
+    f = ffa.FrameFusion(*params)
+    f.prepare(pt.to(DEV), P, pre, pre + F * P, F * P, L)
+    pe_in = [t.to(DEV) for t in mk()]
+    hd = h.to(DEV)
+    hg, peg, _ = f(hd, pe_in, None)
+    return h, pt, o, ho, peo, f, hg, peg
+
+
+@pytest.mark.parametrize("p_change,branch", [(0.2, "topk"), (0.5, "thr"), (0.95, "low")])
+def test_c2_metric_shape_exact(p_change, branch):
+    """[1, 64x576 + 34, 4096] bf16 on the dyadic grid: every output bit-identical to the oracle."""
+    h, pt, o, ho, peo, f, hg, peg = run_both(64, 576, 4096, p_change, sigma_hi=1.6 if branch == "thr" else None)
+    L = h.shape[1]
+    keep_g = torch.nonzero(f.last_plan()["keep"].bool()).reshape(-1).cpu()
+    assert torch.equal(keep_g, o.last_keep)                              # kept-token indices: bit-exact
+    assert (f.finish_merging, f.finish_pruning, f.sparsity_list) == (o.finish_merging, o.finish_pruning, o.sparsity_list)
+    assert {"topk": f.finish_pruning, "thr": not f.finish_merging, "low": f.finish_merging and not f.finish_pruning}[branch]
+    assert same_bits(hg.cpu(), ho)                                        # merged hidden_states: bit-exact
+    for a, b in zip(peg, peo):
+        assert same_bits(a.cpu().contiguous(), b.contiguous())
+    assert torch.equal(f.patch_type.cpu(), o.patch_type)
+    # properties
+    assert hg.shape[1] == keep_g.numel() == L - int(f.last_call["L_in"] - f.last_call["L_out"])
+    text = torch.nonzero(pt[0] == -1).reshape(-1)
+    assert bool(torch.isin(text, keep_g).all())                           # text tokens always survive
+    if branch == "topk":
+        assert L - hg.shape[1] == int(orc.budget([], 0.3) * 64 * 576)     # exactly k tokens folded
+
+
+def test_c2_gaussian_within_tolerance():
+    """Unquantised gaussian activations: fp32 reduction order may flip a bf16 rounding on ~1e-4 of the
+    pairs.  Identical similarities => identical everything; otherwise the
+    differences must be explained by those flips."""
+    h, pt, o, ho, peo, f, hg, peg = run_both(64, 576, 4096, 0.5, grid=None, sigma_hi=1.6, pre=0, post=0)
+    plan = f.last_plan()
+    sim_g, sim_o = plan["sim"].cpu().float(), o.last_sim[0].float()
+    flips = int((sim_g != sim_o).sum())
+    assert flips <= 1e-3 * sim_o.numel()
+    # a flipped rounding of one row norm moves T(na*nb) and then T(dot/den) by up to ~3 bf16 ulps,
+    # on both pairs the row takes part in (measured: 5 flips / 36864, max 3 ulps)
+    assert torch.allclose(sim_g, sim_o, rtol=2 ** -6, atol=1e-6)
+    keep_g = torch.nonzero(plan["keep"].bool()).reshape(-1).cpu()
+    if flips == 0:
+        assert torch.equal(keep_g, o.last_keep) and same_bits(hg.cpu(), ho)
+    else:
+        sym = np.setxor1d(keep_g.numpy(), o.last_keep.numpy())
+        assert sym.size <= 2 * flips
+    common, ig, io = np.intersect1d(keep_g.numpy(), o.last_keep.numpy(), return_indices=True)
+    a, b = hg[0].cpu().float()[ig], ho[0].float()[io]
+    rel = ((a - b).abs() / b.abs().clamp_min(1e-3))
+    assert float((rel > 1e-3).float().mean()) <= 1e-3                    # bf16 hidden within 1e-3 rel
+
+
+@pytest.mark.parametrize("thr", [0.3, 0.5, 0.7, 0.9])
+def test_c3_qwen2vl_shape_threshold_sweep(thr):
+    """Qwen2-VL-7B shape: 64 temporal grids x 180 tokens, d=3584, M-RoPE containers, num=4 importance."""
+    F, P, d, pre, post = 64, 180, 3584, 15, 12
+    h, pt = video_tokens(F, P, d, p_change=0.5, sigma=0.3, sigma_hi=1.8, seed=77, pre=pre, post=post, grid=0.125)
+    L = h.shape[1]
+    want, _ = harness.run_cascade(orc.OracleFrameFusion(0.3, thr, 0.1), h.clone(), pt.clone(), P,
+                                  rotary_tables(L, 128, mrope=True), None, layers=3, heads=28, num=4)
+    got, _ = harness.run_cascade(ffa.FrameFusion(0.3, thr, 0.1), h.to(DEV), pt.to(DEV), P,
+                                 [t.to(DEV) for t in rotary_tables(L, 128, mrope=True)], None, layers=3, heads=28, num=4)
+    for a, b in zip(got, want):
+        assert (a["length"], a["finish_merging"], a["finish_pruning"], a["sparsity"]) == \
+               (b["length"], b["finish_merging"], b["finish_pruning"], b["sparsity"]), a["tag"]
+        assert same_bits(a["hidden"].cpu(), b["hidden"]), a["tag"]
+        for x, y in zip(a["pos"], b["pos"]):
+            assert same_bits(x.cpu().contiguous(), y.contiguous())
+
+
+def test_c5_72b_shape_fused_importance_and_prune():
+    """LLaVA-Video-72B shape (d=8192, H=64, H_kv=8, dh=128): merge, then importance from q/k inside the
+    attention hook, then the prune call."""
+    F, P, d, pre, post = 32, 576, 8192, 14, 20
+    H, Hk, dh = 64, 8, 128
+    h, pt = video_tokens(F, P, d, p_change=0.95, sigma=0.3, seed=5, pre=pre, post=post, grid=0.125)
+    L = h.shape[1]
+    o = orc.OracleFrameFusion(0.3, 0.6, 0.1)
+    o.prepare(pt.clone(), P, pre, pre + F * P, F * P, L)
+    f = ffa.FrameFusion(0.3, 0.6, 0.1)
+    f.prepare(pt.to(DEV), P, pre, pre + F * P, F * P, L)
+    ho, po, _ = o.forward(h, torch.arange(L)[None], None)
+    hg, pg, _ = f(h.to(DEV), torch.arange(L, device=DEV)[None], None)
+    assert same_bits(hg.cpu(), ho) and torch.equal(pg.cpu(), po)
+    assert o.finish_merging and not o.finish_pruning and f.finish_merging and not f.finish_pruning
+    S = ho.shape[1]
+    g = torch.Generator().manual_seed(3)
+    q = harness.snap(torch.randn(1, H, 8, dh, generator=g), torch.bfloat16)
+    k = harness.snap(torch.randn(1, Hk, S, dh, generator=g), torch.bfloat16)
+    w_o = orc.last_query_attention(q, k, num=1, is_causal=True, enable_gqa=True)
+    w_g = ffa.scaled_dot_product_attention(q.to(DEV), k.to(DEV), None, num=1, is_causal=True, enable_gqa=True)
+    assert torch.allclose(w_g.cpu().float(), w_o.float(), rtol=2 ** -7, atol=1e-30)
+    assert float((w_g.cpu().float() != w_o.float()).float().mean()) <= 0.02
+    # feed both sides the SAME weights so the prune itself is compared exactly
+    h2 = harness.layer_stub(ho, 0)
+    ho2, po2, _ = o.forward(h2, po, None, w_o)
+    hg2, pg2, _ = f(h2.to(DEV), pg, None, w_o.to(DEV))
+    assert o.finish_pruning and f.finish_pruning
+    assert torch.equal(pg2.cpu(), po2) and same_bits(hg2.cpu(), ho2)
+    # and the fused [1, 1, 1, S] importance is accepted in place of the weights (a11)
+    imp = ffa.last_query_importance(q.to(DEV), k.to(DEV), num=1, is_causal=True)
+    f2 = ffa.FrameFusion(0.3, 0.6, 0.1)
+    f2.prepare(f.patch_type, P, pre, pre + F * P, F * P, L, finish_merging=True, sparsity_list=list(o.sparsity_list[:1]))
+    hg3, pg3, _ = f2(h2.to(DEV), pg, None, imp)
+    assert hg3.shape == hg2.shape
+    same = float((pg3.cpu() == po2).float().mean())
+    assert same >= 0.99          # ranking from HIP-computed weights: only ulp-level ties may differ

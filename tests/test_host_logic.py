@@ -1,0 +1,165 @@
+"""CPU: host-side logic of the product package that needs no GPU - the budget arithmetic, the
+attach protocol of replace_framefusion_forward / the family registry, API helpers, and the fact
+that the product refuses CPU tensors instead of falling back."""
+from types import MethodType
+
+import pytest
+import torch
+from torch import nn
+
+import framefusion_amd as ffa
+from framefusion_amd.synth import video_tokens, rotary_tables
+from oracle import ff_oracle as orc
+
+
+def test_budget_is_bit_identical_to_the_oracle(golden):
+    g = golden("primitives")
+    for lst, cost, want in zip(g["budget_lists"], g["budget_costs"], g["budget_vals"]):
+        sl = [float(x) for x in str(lst).split(",") if x]
+        got = ffa.FrameFusion._compute_pruning_ratio(sl, float(cost))
+        assert float(got) == float(want) == float(orc.budget(sl, float(cost)))
+    assert ffa.FrameFusion._compute_pruning_ratio([], 1.0) == 0
+    with pytest.raises(ValueError, match="The cost is too small"):
+        ffa.FrameFusion._compute_pruning_ratio([0] * 10, 0.3)
+
+
+def test_find_contigious_latter_index_kat(golden):
+    kat = torch.tensor([[0, 1, 1, 1, 0, 0, 1, 1]])
+    assert ffa.find_contigious_latter_index(kat).tolist() == [[0, 0, 0, 3, 0, 0, 0, 2]]   # main.py:361-363
+    g = golden("primitives")
+    x = torch.from_numpy(g["runs_in"])
+    assert torch.equal(ffa.find_contigious_latter_index(x), torch.from_numpy(g["runs_out"]))
+    assert torch.equal(ffa.find_contigious_latter_index(x.to(torch.bfloat16)).long(), torch.from_numpy(g["runs_out"]))
+
+
+def test_constants_and_surface():
+    assert (ffa.TEXT_TOKEN, ffa.IGNORE_TOKEN) == (-1, -2)
+    f = ffa.FrameFusion()
+    assert (f.cost, f.similarity_lower_bound, f.ratio_lower_bound) == (0.3, 0.6, 0.1)
+    assert list(f.parameters()) == []
+    f.prepare(torch.tensor([[-1, 0, 1]]), 2, 1, 3, 2, 3, sparsity_list=[0.2])
+    assert f.sparsity_list == [0.2] and not f.finish_merging and not f.finish_pruning
+    for name in ("patch_type", "patch_num", "image_token_start_index", "image_token_end_index",
+                 "image_token_length", "original_length"):
+        assert hasattr(f, name)
+    for name in ("compute_similarity_and_token_index_by_patch", "merge_tokens_and_get_mask", "_compute_pruning_ratio"):
+        assert callable(getattr(ffa.FrameFusion, name))
+
+
+def test_no_cpu_fallback():
+    h, pt = video_tokens(4, 6, 32, pre=1, post=1)
+    f = ffa.FrameFusion()
+    f.prepare(pt, 6, 1, 25, 24, h.shape[1])
+    with pytest.raises(ffa.FrameFusionHipError, match="MI355X only"):
+        f(h, rotary_tables(h.shape[1], 8), None)
+    with pytest.raises(ffa.FrameFusionHipError):
+        ffa.FrameFusion.compute_similarity_and_token_index_by_patch(h, pt, 6)
+    with pytest.raises(ffa.FrameFusionHipError):
+        ffa.cosine_similarity(h[0], h[0])
+    with pytest.raises(ffa.FrameFusionHipError):
+        ffa.scaled_dot_product_attention(torch.zeros(1, 2, 4, 8), torch.zeros(1, 2, 4, 8), None)
+    # decode steps and un-prepared instances behave like the reference without touching the device
+    tok = torch.zeros(1, 1, 32)
+    assert f(tok, "pos", "mask")[0] is tok
+    with pytest.raises(AttributeError):
+        ffa.FrameFusion()(h, None, None)
+
+
+def test_get_attr_by_name():
+    class Box:
+        pass
+    root = Box()
+    root.llm = Box()
+    root.llm.layers = [Box(), Box()]
+    root.llm.layers[1].self_attn = "attn1"
+    assert ffa.get_attr_by_name(root, "llm.layers.1.self_attn") == "attn1"
+
+
+class _Attn(nn.Module):
+    def forward(self, x):
+        return x
+
+
+class _Layer(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.self_attn = _Attn()
+
+    def forward(self, x):
+        return x
+
+
+class _LLM(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.layers = nn.ModuleList([_Layer(), _Layer(), _Layer()])
+
+
+class _Wrapper(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.model = _LLM()
+
+
+def test_attach_protocol():
+    """interface.py:169-214: ONE shared FrameFusion on the wrapper, the llm, every layer and every
+    attention module; forwards re-bound with MethodType."""
+    def llm_fwd(self, x): return ("llm", x)
+    def dec_fwd(self, x): return ("dec", x)
+    def att_fwd(self, x): return ("att", x)
+    m = _Wrapper()
+    ff = ffa.replace_framefusion_forward(m, 0.25, 0.7, 0.05, llm_fwd, dec_fwd, att_fwd)
+    assert isinstance(ff, ffa.FrameFusion) and (ff.cost, ff.similarity_lower_bound, ff.ratio_lower_bound) == (0.25, 0.7, 0.05)
+    assert m.framefusion is ff and m.model.framefusion is ff
+    assert isinstance(m.model.forward, MethodType) and m.model.forward(1) == ("llm", 1)
+    for layer in m.model.layers:
+        assert layer.framefusion is ff and layer.self_attn.framefusion is ff
+        assert layer.forward(2) == ("dec", 2) and layer.self_attn.forward(3) == ("att", 3)
+
+
+def test_accelerate_hook_is_preserved():
+    from accelerate.hooks import ModelHook, add_hook_to_module
+
+    class Tag(ModelHook):
+        def post_forward(self, module, output):
+            return ("hooked", output)
+
+    def dec_fwd(self, x): return ("dec", x)
+    m = _Wrapper()
+    add_hook_to_module(m.model.layers[0], Tag())
+    ffa.replace_framefusion_forward(m, 0.3, 0.6, 0.1, lambda s, x: x, dec_fwd, lambda s, x: x)
+    assert m.model.layers[0].forward(5) == ("hooked", ("dec", 5))       # interface.py:204-207
+    assert m.model.layers[1].forward(5) == ("dec", 5)
+
+
+def test_family_registry():
+    m = _Wrapper()
+    with pytest.raises(NotImplementedError):
+        ffa.apply_framefusion(m, 0.3, 0.6, 0.1)
+    calls = []
+
+    def prepare_hook(self, *a):
+        calls.append(a)
+        return "prepared"
+    fam = ffa.Family("toy", lambda mod: isinstance(mod, _Wrapper), lambda s, x: ("llm", x), lambda s, x: ("dec", x),
+                     lambda s, x: ("att", x), prepare_hook=("build_inputs", prepare_hook))
+    ffa.register_family(fam)
+    try:
+        ffa.apply_framefusion(m, 0.3, 0.6, 0.1)
+        assert m.model.layers[2].forward(1) == ("dec", 1)
+        assert m.build_inputs(7) == "prepared" and calls == [(7,)]
+        m2 = _Wrapper()
+        ffa.get_token_type(m2)
+        assert m2.build_inputs(1) == "prepared" and not hasattr(m2, "framefusion")
+    finally:
+        from framefusion_amd import interface
+        interface._FAMILIES[:] = [f for f in interface._FAMILIES if f.name != "toy"]
+
+
+def test_synthetic_generator_is_deterministic_and_on_grid():
+    a, pa = video_tokens(5, 7, 64, seed=3, pre=2, post=1, grid=0.125)
+    b, pb = video_tokens(5, 7, 64, seed=3, pre=2, post=1, grid=0.125)
+    assert torch.equal(a.view(torch.int16), b.view(torch.int16)) and torch.equal(pa, pb)
+    assert pa.tolist()[0][:3] == [-1, -1, 0] and pa.shape == (1, 2 + 35 + 1)
+    x = a.float() * 8
+    assert torch.equal(x, x.round()) and float(a.float().abs().max()) <= 4.0
