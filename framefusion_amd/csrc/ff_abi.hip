@@ -6,7 +6,13 @@
 namespace ff {
 int launch_plan_merge(const void* sim, int dtype, const int32_t* order, int64_t L, double thr, double sub,
                       double ratio_lb, uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
-                      void* ws, int64_t* host_mapped, int64_t seq, hipStream_t st);
+                      void* ws, const int* l0_copies, int* zero_next, int64_t* host_mapped, int64_t seq,
+                      hipStream_t st);
+size_t plan_ws_bytes(int64_t L);
+int* ws_l0_copies(void* ws, int64_t seq);
+int launch_similarity_any(const void* hidden, int dtype, int64_t L, int64_t d, const int64_t* ptype,
+                          const int32_t* order, const int64_t* stats, void* sim, int* l0, double thr,
+                          hipStream_t st);
 }  // namespace ff
 
 extern "C" int ff_abi_version(void) { return FF_ABI_VERSION; }
@@ -25,19 +31,26 @@ extern "C" const char* ff_error_string(int code) {
 extern "C" size_t ff_workspace_bytes(int64_t L, int64_t patch_num) {
     (void)patch_num;
     if (L < 0) return 0;
-    return (size_t)256;   // the Select record handed from k_select to k_flags
+    return ff::plan_ws_bytes(L);   // select statistics tables (see ff_plan.hip)
 }
 
 extern "C" int ff_merge_begin(const void* hidden, int dtype, int64_t L, int64_t d, const int64_t* patch_type,
-                              int64_t patch_num, int order_valid, int32_t* order, void* sim, int64_t* stats,
-                              void* ws, size_t ws_bytes, ff_stream_t stream) {
+                              int64_t patch_num, int order_valid, double threshold, int32_t* order, void* sim,
+                              int64_t* stats, int64_t seq, void* ws, size_t ws_bytes, ff_stream_t stream) {
     if (!hidden || !patch_type || !order || !sim || !stats || !ws) return FF_ERR_ARG;
     if (ws_bytes < ff_workspace_bytes(L, patch_num)) return FF_ERR_WORKSPACE;
+    if (dtype != FF_F32 && dtype != FF_BF16 && dtype != FF_F16) return FF_ERR_ARG;
+    const int64_t esz = dtype == FF_F32 ? 4 : 2;
+    if (((uintptr_t)hidden & 15) || ((d * esz) & 15) || ((uintptr_t)ws & 15)) return FF_ERR_ALIGN;
+    if (L >= (1ll << 31) || d * esz >= (1ll << 31)) return FF_ERR_UNSUPPORTED;
     if (!order_valid) {
         int rc = ff_build_order(patch_type, L, patch_num, order, stats, ws, ws_bytes, stream);
         if (rc) return rc;
     }
-    return ff_pair_similarity(hidden, dtype, L, d, patch_type, order, stats, sim, stream);
+    if (L == 0) return FF_OK;
+    // the similarity kernel also accumulates the level-0 select statistics of this call
+    return ff::launch_similarity_any(hidden, dtype, L, d, patch_type, order, stats, sim, ff::ws_l0_copies(ws, seq),
+                                     threshold, (hipStream_t)stream);
 }
 
 extern "C" int ff_merge_finish(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
@@ -51,7 +64,8 @@ extern "C" int ff_merge_finish(const void* hidden, void* hidden_out, int dtype, 
     if (dtype != FF_F32 && dtype != FF_BF16 && dtype != FF_F16) return FF_ERR_ARG;
     if (L == 0) return FF_OK;
     int rc = ff::launch_plan_merge(sim, dtype, order, L, threshold, sub, ratio_lb, member, dst, keep, stats, ws,
-                                   stats_host_mapped, seq, (hipStream_t)stream);
+                                   ff::ws_l0_copies(ws, seq), ff::ws_l0_copies(ws, seq + 1), stats_host_mapped, seq,
+                                   (hipStream_t)stream);
     if (rc) return rc;
     return ff_merge_compact(hidden, hidden_out, dtype, L, d, L_cap, order, member, 1, dst, keep, aux_host, n_aux, stream);
 }
@@ -62,8 +76,8 @@ extern "C" int ff_merge_step(const void* hidden, void* hidden_out, int dtype, in
                              int32_t* dst, uint8_t* keep, int64_t* stats, int64_t* stats_host_mapped,
                              int64_t seq, const ff_aux_t* aux_host, int n_aux, void* ws, size_t ws_bytes,
                              ff_stream_t stream) {
-    int rc = ff_merge_begin(hidden, dtype, L, d, patch_type, patch_num, order_valid, order, sim, stats, ws, ws_bytes,
-                            stream);
+    int rc = ff_merge_begin(hidden, dtype, L, d, patch_type, patch_num, order_valid, threshold, order, sim, stats,
+                            seq, ws, ws_bytes, stream);
     if (rc) return rc;
     return ff_merge_finish(hidden, hidden_out, dtype, L, d, L_cap, threshold, sub, ratio_lb, order, sim, member, dst,
                            keep, stats, stats_host_mapped, seq, aux_host, n_aux, ws, ws_bytes, stream);

@@ -8,46 +8,24 @@
 // unique/where/repeat_interleave index algebra of merge_tokens_and_get_mask (main.py:269-301)
 // and the keep-mask construction (main.py:278-279) - 17 host syncs in the reference.
 //
-// Three launches, split by what is inherently global:
-//   k_select  ONE 16-wave workgroup: count(sim >= thr), the budget decision, and for the top-k
-//             branch the k-th key (8-bit radix passes over LDS histograms) plus the index cutoff
-//             among entries equal to it.  Output: a 48-byte Select record.
-//   k_flags   many workgroups: member[t] for every by-patch slot from (similarity, Select) and
-//             the scatter keep[order[t]] = !member[t] - one CU would take a cycle per scattered
-//             byte, 256 CUs do not notice it.
-//   k_scan    many workgroups, no communication: workgroup g recounts keep[0, 4096 g) itself
-//             (<= L bytes, L2-resident) and scans its own 4096 positions into dst[]; the last
-//             workgroup knows L_out and publishes the result block.
+// Launches, split by what is inherently global (details at "multi-workgroup select" below):
+//   k_hist_level  per 4096-value slice: one byte of the radix select per launch (level 0 comes for
+//                 free from the similarity kernel in the fused path); nothing runs in the
+//                 threshold branch beyond re-deriving the decision;
+//   k_flags       per slice: member[t] for every by-patch slot and the scatter
+//                 keep[order[t]] = !member[t] - one CU would take a cycle per scattered byte,
+//                 many CUs do not notice it;
+//   k_scan        many workgroups, no communication: workgroup g recounts keep[0, 4096 g) itself
+//                 (<= L bytes, L2-resident) and scans its own 4096 positions into dst[]; the last
+//                 workgroup knows L_out and publishes the result block.
 // Run lengths are not materialised: the merge kernel derives them from 64 member flags at a time.
+#include <string.h>
+
 #include "ff_common.h"
 
 namespace ff {
 
-constexpr int kSelThreads = 1024;
-constexpr int kSelWaves = kSelThreads / kWave;
-constexpr int kEpt = 16;                          // elements per thread per round
-constexpr int kRound = kSelThreads * kEpt;        // 16384
-constexpr int kCopies = 2;                        // histogram copies per wave (lane & 3): fewer same-word hits
-
-// Selection rule for entry j of values[lo, hi):
-//   topk : key > kth || (key == kth && j <= tie_cut)       (k > 0)
-//   else : key >= thr_key && key != NaN
-struct Select {
-    int topk;
-    uint32_t thr_key, kth;
-    int tie_cut;
-    long long k;
-    int lo, hi;       // range the rule applies to
-    int invert;       // prune plan: member (= dropped) iff inside [lo, hi) and NOT selected
-    int pad;
-};
-
-struct SelLds {
-    int hist[kSelWaves][kCopies][256];
-    int tot[256];
-    int scratch[kSelWaves + 1];
-    int bcast[4];
-};
+constexpr int kEpt = 16;                          // values per thread: two/four 16-byte loads
 
 // 16 consecutive T values starting at j0 (j0 % 16 == 0) as order-preserving keys; entries at or
 // beyond `n` are flagged invalid.
@@ -100,32 +78,53 @@ __device__ inline uint32_t key_of_value(float x) {
 
 template <int DT> __device__ inline uint32_t nan_key() { return Act<DT>::kKeyBits == 32 ? 0xffffffffu : 0xffffu; }
 
-template <int DT>
-__device__ inline bool is_selected(const Select& sel, uint32_t key, int j) {
-    if (sel.topk) return sel.k > 0 && (key > sel.kth || (key == sel.kth && j <= sel.tie_cut));
-    return key >= sel.thr_key && key != nan_key<DT>();
-}
+// ---- multi-workgroup select ---------------------------------------------------------------------
+// The decision data is a handful of small histograms, so instead of one workgroup walking all
+// similarities several times, every workgroup of every stage re-derives the (deterministic)
+// decision from the partial histograms written by the previous stage:
+//   level 0 : top-byte histogram + count(sim >= thr), accumulated by the similarity kernel itself
+//             (64 copies, atomics spread over its whole run) or by k_hist_level(0);
+//   level l : k_hist_level(l) - slice g (4096 values) histograms byte l of the keys that match the
+//             l-byte prefix of the k-th key, one row per slice, no atomics across workgroups;
+//   k_flags : resolves the k-th key from all levels; the last level's per-slice rows also give the
+//             number of entries equal to it in earlier slices (lowest-index tie rule without a
+//             global scan); then member flags + the keep scatter for its slice.
+constexpr int kSliceThreads = 256;
+constexpr int kSlice = kSliceThreads * kEpt;      // 4096 values per workgroup
+constexpr int kRowStride = 260;                   // 256 bins + count + pad
+constexpr int kL0Copies = 64;
 
-__device__ inline void zero_hist(SelLds& s) {
-    for (int x = threadIdx.x; x < kSelWaves * kCopies * 256; x += kSelThreads) (&s.hist[0][0][0])[x] = 0;
-}
+struct PlanParams {
+    int mode;            // 0: merge (threshold / top-k decided from the count), 1: prune (top-k given)
+    int lo, hi;          // value range the selection runs over (merge: hi < 0 -> [0, Nv))
+    long long k_given;   // prune: k
+    double sub, ratio_lb;
+    uint32_t thr_key;
+    int l0_rows;         // rows of the level-0 table (64 copies or G slices)
+    int n_slices;
+};
 
-// After a histogram pass: fold the per-wave copies and pick, from the top, the bin in which the
-// running count reaches `remaining`; returns the bin, `above` = entries in higher bins.
-__device__ inline int pick_bin(SelLds& s, int remaining, int& above) {
-    const int tid = threadIdx.x, lane = lane_id();
-    __syncthreads();
-    if (tid < 256) {
-        int t = 0;
-#pragma unroll
-        for (int q = 0; q < kSelWaves; ++q)
-#pragma unroll
-            for (int c = 0; c < kCopies; ++c) t += s.hist[q][c][tid];
-        s.tot[tid] = t;
-    }
+struct Resolved {
+    bool topk;
+    long long k;
+    int count;
+    uint32_t prefix;     // leading `levels_done` bytes of the k-th key
+    int remaining;       // entries still to take inside the prefix
+};
+
+struct SliceLds {
+    int hist[kSliceThreads / kWave][2][256];
+    int tot[256];
+    int scratch[kSliceThreads / kWave + 1];
+    int bcast[4];
+};
+
+// pick the bin, from the top, in which the running count reaches `remaining` (s.tot filled)
+__device__ inline int pick_from_tot(SliceLds& s, int remaining, int& above) {
+    const int lane = lane_id();
     __syncthreads();
     if (wave_id() == 0) {
-        const int top = 255 - 4 * lane;   // lane covers bins top .. top-3
+        const int top = 255 - 4 * lane;
         const int v0 = s.tot[top], v1 = s.tot[top - 1], v2 = s.tot[top - 2], v3 = s.tot[top - 3];
         const int sum = v0 + v1 + v2 + v3;
         const int incl = wave_incl_scan(sum);
@@ -148,186 +147,203 @@ __device__ inline int pick_bin(SelLds& s, int remaining, int& above) {
     return bin;
 }
 
-// Top-k over values[lo, hi): 8-bit radix passes, then the index of the last selected entry among
-// those equal to the k-th value.  `top_hist_ready`: s.hist already holds the top-byte histogram.
-template <int DT>
-__device__ inline void select_topk(const void* __restrict__ values, int lo, int hi, int k, bool top_hist_ready,
-                                   SelLds& s, Select& sel, int& ties_taken) {
-    using A = Act<DT>;
-    const int tid = threadIdx.x, w = wave_id(), cp = lane_id() & (kCopies - 1);
-    const int lo_al = lo & ~(kEpt - 1);
-    uint32_t prefix = 0;
-    int remaining = k;
-    for (int shift = A::kKeyBits - 8; shift >= 0; shift -= 8) {
-        const int hi_bits = shift + 8;
-        if (!(top_hist_ready && hi_bits == A::kKeyBits)) {
-            zero_hist(s);
+// Re-derive the decision and the first `levels` bytes of the k-th key from the partial tables.
+// l0: [l0_rows][kRowStride]; lv: [levels-1][n_slices][256] (levels 1..).  Called by all threads.
+__device__ inline Resolved resolve(const PlanParams& pp, const int* __restrict__ l0, const int* __restrict__ lv,
+                                   int levels, long long ftn, int nv, SliceLds& s) {
+    const int tid = threadIdx.x;
+    Resolved r;
+    r.prefix = 0; r.remaining = 0; r.count = 0;
+    // level-0 totals
+    int t0 = 0;
+    for (int q = 0; q < pp.l0_rows; ++q) t0 += l0[q * kRowStride + tid];
+    s.tot[tid] = t0;
+    if (tid == 0) {
+        int c = 0;
+        for (int q = 0; q < pp.l0_rows; ++q) c += l0[q * kRowStride + 256];
+        s.bcast[2] = c;
+    }
+    __syncthreads();
+    r.count = s.bcast[2];
+    if (pp.mode == 0) {
+        // main.py:114-116 in double, as python: ratio = count / ftn ; ratio < sub ?
+        const double ratio = ftn > 0 ? (double)r.count / (double)ftn : 0.0;
+        r.topk = !(ratio < pp.sub);
+        long long k = 0;
+        if (r.topk) {
+            k = (long long)(pp.sub * (double)ftn);          // int(sub * ftn), main.py:122
+            if (k > nv) k = nv;
+            if (k < 0) k = 0;
+        }
+        r.k = k;
+    } else {
+        r.topk = true;
+        r.k = pp.k_given;
+    }
+    if (!r.topk || r.k <= 0 || levels <= 0) return r;
+    r.remaining = (int)r.k;
+    for (int l = 0; l < levels; ++l) {
+        if (l > 0) {
             __syncthreads();
-            for (int base = lo_al; base < hi; base += kRound) {
-                const int j0 = base + tid * kEpt;
-                uint32_t key[kEpt], valid;
-                load_keys<DT>(values, j0, hi, key, valid);
-#pragma unroll
-                for (int e = 0; e < kEpt; ++e) {
-                    const bool in = ((valid >> e) & 1u) && (j0 + e >= lo);
-                    const bool match = hi_bits >= A::kKeyBits || (key[e] >> hi_bits) == prefix;
-                    if (in && match) atomicAdd(&s.hist[w][cp][(key[e] >> shift) & 255u], 1);
-                }
-            }
+            const int* tab = lv + (size_t)(l - 1) * pp.n_slices * 256;
+            int t = 0;
+            for (int g = 0; g < pp.n_slices; ++g) t += tab[g * 256 + tid];
+            s.tot[tid] = t;
         }
         int above;
-        const int bin = pick_bin(s, remaining, above);
-        prefix = (prefix << 8) | (uint32_t)bin;
-        remaining -= above;
+        const int bin = pick_from_tot(s, r.remaining, above);
+        r.prefix = (r.prefix << 8) | (uint32_t)bin;
+        r.remaining -= above;
     }
-    sel.kth = prefix;
-    ties_taken = remaining;                       // >= 1 entries equal to kth belong to the top k
-    // the index of the `remaining`-th entry equal to kth, in ascending index order
-    int seen = 0;
-    if (tid == 0) s.bcast[2] = -1;
-    __syncthreads();
-    for (int base = lo_al; base < hi; base += kRound) {
-        const int j0 = base + tid * kEpt;
-        uint32_t key[kEpt], valid;
-        load_keys<DT>(values, j0, hi, key, valid);
-        int mine = 0;
-#pragma unroll
-        for (int e = 0; e < kEpt; ++e)
-            mine += (((valid >> e) & 1u) && (j0 + e >= lo) && key[e] == prefix) ? 1 : 0;
-        int round_total;
-        const int before = seen + block_excl_scan<kSelWaves>(mine, s.scratch, round_total);
-        if (before < remaining && before + mine >= remaining) {
-            int c = before;
-#pragma unroll
-            for (int e = 0; e < kEpt; ++e) {
-                if (((valid >> e) & 1u) && (j0 + e >= lo) && key[e] == prefix) {
-                    ++c;
-                    if (c == remaining) s.bcast[2] = j0 + e;
-                }
-            }
-        }
-        seen += round_total;
-        if (seen >= remaining) break;             // uniform
-    }
-    __syncthreads();
-    sel.tie_cut = s.bcast[2];
-    __syncthreads();
+    return r;
 }
 
-// ---- k_select (merge): main.py:112-127 -------------------------------------------------------------
+__device__ inline void slice_range(const PlanParams& pp, int nv, int& lo, int& hi) {
+    lo = pp.mode == 0 ? 0 : pp.lo;
+    hi = pp.mode == 0 ? nv : pp.hi;
+}
+
+// level `level` histogram of slice blockIdx.x (level 0 also counts values >= thr)
 template <int DT>
-__global__ __launch_bounds__(kSelThreads) void k_select_merge(
-    const void* __restrict__ sim, double thr, double sub, double ratio_lb, int64_t* __restrict__ stats,
-    Select* __restrict__ sel_out) {
+__global__ __launch_bounds__(kSliceThreads) void k_hist_level(
+    const void* __restrict__ values, PlanParams pp, int level, const int64_t* __restrict__ stats,
+    const int* __restrict__ l0, int* __restrict__ lv, int* __restrict__ l0_out) {
     using A = Act<DT>;
-    __shared__ SelLds s;
-    const int tid = threadIdx.x, w = wave_id(), cp = lane_id() & (kCopies - 1);
-    const uint64_t clk0 = __builtin_amdgcn_s_memtime();
+    __shared__ SliceLds s;
+    const int tid = threadIdx.x, w = wave_id(), cp = lane_id() & 1;
     const int nv = (int)stats[FF_STAT_NV];
     const long long ftn = stats[FF_STAT_FTN];
-    Select sel;
-    sel.topk = 0;
-    // thr is already T-valued; +-0 compare equal as floats, so a zero threshold admits both
-    sel.thr_key = key_of_value<DT>(thr == 0.0 ? -0.0f : (float)thr);
-    sel.kth = 0; sel.tie_cut = -1; sel.k = 0; sel.lo = 0; sel.hi = nv; sel.invert = 0; sel.pad = 0;
-
-    // count(sim >= T(thr)) (main.py:113; NaN compares false, -2 never passes) and the top-byte
-    // histogram the top-k branch would need
-    zero_hist(s);
+    int lo, hi;
+    slice_range(pp, nv, lo, hi);
+    uint32_t prefix = 0;
+    if (level > 0) {
+        const Resolved r = resolve(pp, l0, lv, level, ftn, nv, s);
+        if (!r.topk || r.k <= 0) return;
+        prefix = r.prefix;
+        __syncthreads();
+    }
+    for (int x = tid; x < (kSliceThreads / kWave) * 2 * 256; x += kSliceThreads) (&s.hist[0][0][0])[x] = 0;
     __syncthreads();
+    const int j0 = blockIdx.x * kSlice + tid * kEpt;
+    uint32_t key[kEpt], valid;
+    load_keys<DT>(values, j0, hi, key, valid);
+    const int shift = A::kKeyBits - 8 * (level + 1);
     int c = 0;
-    for (int base = 0; base < nv; base += kRound) {
-        const int j0 = base + tid * kEpt;
-        uint32_t key[kEpt], valid;
-        load_keys<DT>(sim, j0, nv, key, valid);
-        // similarities of neighbouring pairs share their top byte (sign + exponent): fold equal
-        // neighbours before touching LDS, and let one lane add for the wave's common bin -
-        // otherwise every lane hammers the same histogram word (64-way serialised atomics).
-        int run_bin = -1, run_cnt = 0;
 #pragma unroll
-        for (int e = 0; e < kEpt; ++e) {
-            if (!((valid >> e) & 1u)) continue;
-            c += (key[e] >= sel.thr_key && key[e] != nan_key<DT>()) ? 1 : 0;
-            const int bin = (int)(key[e] >> (A::kKeyBits - 8));
-            if (bin == run_bin) { ++run_cnt; continue; }
-            if (run_cnt) atomicAdd(&s.hist[w][cp][run_bin], run_cnt);
-            run_bin = bin; run_cnt = 1;
+    for (int e = 0; e < kEpt; ++e) {
+        const bool in = ((valid >> e) & 1u) && (j0 + e >= lo);
+        if (!in) continue;
+        if (level == 0) {
+            c += (key[e] >= pp.thr_key && key[e] != nan_key<DT>()) ? 1 : 0;
+            atomicAdd(&s.hist[w][cp][key[e] >> shift], 1);
+        } else if ((key[e] >> (shift + 8)) == prefix) {
+            atomicAdd(&s.hist[w][cp][(key[e] >> shift) & 255u], 1);
         }
-        const int lead_bin = uniform(run_bin);
-        const bool with_lead = run_cnt > 0 && run_bin == lead_bin;
-        const int lead_total = wave_sum_i(with_lead ? run_cnt : 0);
-        if (lane_id() == 0 && lead_total) atomicAdd(&s.hist[w][0][lead_bin], lead_total);
-        if (run_cnt > 0 && !with_lead) atomicAdd(&s.hist[w][cp][run_bin], run_cnt);
     }
-    const int count = block_sum_i<kSelWaves>(c, s.scratch);
-    const uint64_t clk1 = __builtin_amdgcn_s_memtime();
-
-    // main.py:114-116 in double, as python: ratio = count / ftn ; ratio < sub ?
-    const double ratio = ftn > 0 ? (double)count / (double)ftn : 0.0;
-    sel.topk = !(ratio < sub);
-    int ties_taken = 0;
-    if (sel.topk) {
-        long long k = (long long)(sub * (double)ftn);      // int(sub * ftn), main.py:122
-        if (k > nv) k = nv;
-        if (k < 0) k = 0;
-        sel.k = k;
-        if (k > 0) select_topk<DT>(sim, 0, nv, (int)k, true, s, sel, ties_taken);
-    }
-    if (tid == 0) {
-        *sel_out = sel;
-        stats[FF_STAT_COUNT] = count;
-        stats[FF_STAT_BRANCH] = sel.topk ? 1 : 0;
-        stats[FF_STAT_K] = sel.k;
-        stats[FF_STAT_BELOW_LB] = (!sel.topk && ratio < ratio_lb) ? 1 : 0;
-        stats[FF_STAT_KTH_KEY] = sel.kth;
-        stats[FF_STAT_TIES_TAKEN] = ties_taken;
-        stats[FF_STAT_T_PLAN + 0] = (int64_t)(clk1 - clk0);
-        stats[FF_STAT_T_PLAN + 1] = (int64_t)(__builtin_amdgcn_s_memtime() - clk1);
-    }
-}
-
-// ---- k_select (prune): top-k of importance[start, start + n_img) (main.py:74-79) ----------------------
-template <int DT>
-__global__ __launch_bounds__(kSelThreads) void k_select_prune(
-    const void* __restrict__ importance, int S, int start, int n_img, int k, int64_t* __restrict__ stats,
-    Select* __restrict__ sel_out) {
-    __shared__ SelLds s;
-    Select sel;
-    sel.topk = 1; sel.thr_key = 0; sel.kth = 0; sel.tie_cut = -1; sel.k = k;
-    sel.lo = start; sel.hi = start + n_img; sel.invert = 1; sel.pad = 0;
-    int ties_taken = 0;
-    if (k >= n_img) { sel.kth = 0; sel.tie_cut = 0x7fffffff; sel.k = n_img > 0 ? n_img : 1; }   // everything selected
-    else if (k > 0) select_topk<DT>(importance, start, start + n_img, k, false, s, sel, ties_taken);
-    if (threadIdx.x == 0) {
-        *sel_out = sel;
-        stats[FF_STAT_NV] = S;
-        stats[FF_STAT_K] = k;
-        stats[FF_STAT_KTH_KEY] = sel.kth;
-        stats[FF_STAT_TIES_TAKEN] = ties_taken;
+    if (level == 0) c = block_sum_i<kSliceThreads / kWave>(c, s.scratch);
+    __syncthreads();
+    int t = 0;
+#pragma unroll
+    for (int q = 0; q < kSliceThreads / kWave; ++q) t += s.hist[q][0][tid] + s.hist[q][1][tid];
+    if (level == 0) {
+        l0_out[blockIdx.x * kRowStride + tid] = t;
+        if (tid == 0) l0_out[blockIdx.x * kRowStride + 256] = c;
+    } else {
+        lv[((size_t)(level - 1) * pp.n_slices + blockIdx.x) * 256 + tid] = t;
     }
 }
 
 // ---- k_flags ----------------------------------------------------------------------------------------
-// One thread per by-patch slot t (then the non-visual tail of `order`).  Slot 0 never folds: it has
+// Slice g of the by-patch slots (then the non-visual tail of `order`).  Slot 0 never folds: it has
 // no predecessor (the reference would wrap to order[-1], main.py:290; reachable only when top-k
 // exceeds the number of valid pairs).
 template <int DT>
-__global__ __launch_bounds__(256) void k_flags(const void* __restrict__ values, const Select* __restrict__ selp,
-                                               const int64_t* __restrict__ stats, const int32_t* __restrict__ order,
-                                               int L, uint8_t* __restrict__ member, uint8_t* __restrict__ keep) {
+__global__ __launch_bounds__(kSliceThreads) void k_flags(
+    const void* __restrict__ values, PlanParams pp, const int* __restrict__ l0, const int* __restrict__ lv,
+    int64_t* __restrict__ stats, const int32_t* __restrict__ order, int L,
+    uint8_t* __restrict__ member, uint8_t* __restrict__ keep) {
     using A = Act<DT>;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= L) return;
-    const int n_flag = (int)stats[FF_STAT_NV];
-    const Select sel = *selp;
-    uint8_t m = 0;
-    if (t < n_flag) {
-        const uint32_t key = order_key<DT>(A::bits1(values, t));
-        if (sel.invert) m = (t >= sel.lo && t < sel.hi) && !is_selected<DT>(sel, key, t);
-        else m = is_selected<DT>(sel, key, t) && t > 0;
+    constexpr int kLevels = A::kKeyBits / 8;
+    __shared__ SliceLds s;
+    const int tid = threadIdx.x;
+    const int nv = (int)stats[FF_STAT_NV];
+    const long long ftn = stats[FF_STAT_FTN];
+    int lo, hi;
+    slice_range(pp, nv, lo, hi);
+    const Resolved r = resolve(pp, l0, lv, kLevels, ftn, nv, s);
+    const bool select_topk = r.topk;
+    const uint32_t kth = r.prefix;
+    const int need = r.remaining;                 // entries equal to kth that belong to the top k
+    // entries equal to kth in earlier slices (rows of the last level count exactly those)
+    int ties_before = 0;
+    if (select_topk && r.k > 0) {
+        const int* last = lv + (size_t)(kLevels - 2) * pp.n_slices * 256;
+        for (int g = 0; g < (int)blockIdx.x; ++g) ties_before += last[g * 256 + (kth & 255u)];
     }
-    member[t] = m;
-    keep[order ? order[t] : t] = m ? 0 : 1;
+    const int j0 = blockIdx.x * kSlice + tid * kEpt;
+    const int n_flag = pp.mode == 0 ? nv : L;
+    uint32_t key[kEpt], valid;
+    load_keys<DT>(values, j0, n_flag, key, valid);
+    int mine = 0;
+    if (select_topk && r.k > 0) {
+#pragma unroll
+        for (int e = 0; e < kEpt; ++e)
+            mine += (((valid >> e) & 1u) && j0 + e >= lo && j0 + e < hi && key[e] == kth) ? 1 : 0;
+    }
+    int slice_ties;
+    int rank = ties_before + block_excl_scan<kSliceThreads / kWave>(mine, s.scratch, slice_ties);
+    uint32_t mem = 0;
+#pragma unroll
+    for (int e = 0; e < kEpt; ++e) {
+        const int j = j0 + e;
+        if (!((valid >> e) & 1u)) continue;
+        const bool in = j >= lo && j < hi;
+        bool sel;
+        if (select_topk) {
+            sel = false;
+            if (in && r.k > 0) {
+                if (key[e] > kth) sel = true;
+                else if (key[e] == kth) { sel = rank < need; ++rank; }
+            }
+        } else {
+            sel = key[e] >= pp.thr_key && key[e] != nan_key<DT>();
+        }
+        const bool m = pp.mode == 0 ? (sel && j > 0) : (in && !sel);
+        if (m) mem |= 1u << e;
+    }
+    if (j0 < L) {
+        const int n_here = min(L - j0, kEpt);
+        if (n_here == kEpt && (((uintptr_t)(member + j0)) & 15) == 0) {
+            uint32_t mb[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                mb[q] = 0;
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) mb[q] |= ((mem >> (4 * q + bb)) & 1u) << (8 * bb);
+            }
+            *(uint4*)(member + j0) = make_uint4(mb[0], mb[1], mb[2], mb[3]);
+        } else {
+            for (int e = 0; e < n_here; ++e) member[j0 + e] = (mem >> e) & 1u;
+        }
+        if (order) {
+            for (int e = 0; e < n_here; ++e) keep[order[j0 + e]] = ((mem >> e) & 1u) ? 0 : 1;
+        } else {
+            for (int e = 0; e < n_here; ++e) keep[j0 + e] = ((mem >> e) & 1u) ? 0 : 1;
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        if (pp.mode == 0) {
+            const double ratio = ftn > 0 ? (double)r.count / (double)ftn : 0.0;
+            stats[FF_STAT_COUNT] = r.count;
+            stats[FF_STAT_BRANCH] = r.topk ? 1 : 0;
+            stats[FF_STAT_BELOW_LB] = (!r.topk && ratio < pp.ratio_lb) ? 1 : 0;
+        } else {
+            stats[FF_STAT_NV] = L;
+        }
+        stats[FF_STAT_K] = r.k;
+        stats[FF_STAT_KTH_KEY] = kth;
+        stats[FF_STAT_TIES_TAKEN] = (select_topk && r.k > 0) ? need : 0;
+    }
 }
 
 // Explicit merge set (merge_tokens_and_get_mask, main.py:243-319): member bytes were zeroed, set them.
@@ -350,19 +366,25 @@ __global__ __launch_bounds__(256) void k_keep_from_member(const uint8_t* __restr
 constexpr int kScanThreads = 256;
 constexpr int kScanSpan = kScanThreads * kEpt;     // 4096 positions per workgroup
 
+// Copy of the result block into device-visible pinned host memory: one lane per word (a single
+// store instruction crosses PCIe once), a system fence, then the sequence word the host polls.
 __device__ inline void publish(const int64_t* __restrict__ stats, int64_t* host_mapped, int64_t seq) {
-    // Optional copy of the result block into device-visible pinned host memory, sequence word last.
-    if (!host_mapped) return;
-    for (int q = 0; q < FF_STAT_WORDS; ++q)
-        if (q != FF_STAT_SEQ) __hip_atomic_store(&host_mapped[q], stats[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(&host_mapped[FF_STAT_SEQ], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const int lane = threadIdx.x;          // called by wave 0
+    if (lane < FF_STAT_WORDS && lane != FF_STAT_SEQ)
+        __hip_atomic_store(&host_mapped[lane], stats[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    if (lane == 0) __hip_atomic_store(&host_mapped[FF_STAT_SEQ], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ __launch_bounds__(kScanThreads) void k_scan(const uint8_t* __restrict__ keep, int L,
                                                        int32_t* __restrict__ dst, int64_t* __restrict__ stats,
-                                                       int64_t* host_mapped, int64_t seq) {
+                                                       int64_t* host_mapped, int64_t seq, int* __restrict__ zero_me) {
     __shared__ int scratch[kScanThreads / kWave + 1];
     const int tid = threadIdx.x;
+    // the level-0 statistics table the NEXT call's similarity kernel will accumulate into
+    if (zero_me)
+        for (int x = blockIdx.x * kScanThreads + tid; x < kL0Copies * kRowStride; x += gridDim.x * kScanThreads)
+            zero_me[x] = 0;
     const int base = blockIdx.x * kScanSpan;
     // kept positions before my span: keep bytes are 0/1, so popcount of the words counts them
     int before = 0;
@@ -401,68 +423,125 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const uint8_t* __restrict
                 if (e < n_here) dst[i0 + e] = d[e];
         }
     }
-    if (blockIdx.x == gridDim.x - 1 && tid == 0) {
-        const int l_out = before + span_total;
-        stats[FF_STAT_LOUT] = l_out;
-        stats[FF_STAT_MERGED] = L - l_out;
-        publish(stats, host_mapped, seq);
+    if (blockIdx.x == gridDim.x - 1) {
+        if (tid == 0) {
+            const int l_out = before + span_total;
+            stats[FF_STAT_LOUT] = l_out;
+            stats[FF_STAT_MERGED] = L - l_out;
+        }
+        __syncthreads();
+        if (host_mapped && tid < kWave) publish(stats, host_mapped, seq);
     }
 }
 
 // ---- launchers (also used by the fused step in ff_abi.hip) ------------------------------------------
 static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
 
+// Workspace layout (ints): [2][kL0Copies][kRowStride] level-0 tables filled by the similarity kernel
+// (double-buffered by call parity), [G][kRowStride] level-0 rows for the stand-alone entry points,
+// [3][G][256] rows of levels 1..3;  G = ceil(L / 4096).
+size_t plan_ws_bytes(int64_t L) {
+    const size_t G = (size_t)((L + kSlice - 1) / kSlice) + 1;
+    return (2 * (size_t)kL0Copies * kRowStride + G * kRowStride + 3 * G * 256) * sizeof(int) + 256;
+}
+int* ws_l0_copies(void* ws, int64_t seq) { return (int*)ws + (size_t)(seq & 1) * kL0Copies * kRowStride; }
+static int* ws_l0_rows(void* ws) { return (int*)ws + 2 * (size_t)kL0Copies * kRowStride; }
+static int* ws_levels(void* ws, int64_t L) {
+    const size_t G = (size_t)((L + kSlice - 1) / kSlice) + 1;
+    return ws_l0_rows(ws) + G * kRowStride;
+}
+
 static int launch_scan(const uint8_t* keep, int64_t L, int32_t* dst, int64_t* stats, int64_t* host_mapped,
-                       int64_t seq, hipStream_t st) {
+                       int64_t seq, int* zero_me, hipStream_t st) {
     hipLaunchKernelGGL(k_scan, dim3(cdiv(L, kScanSpan)), dim3(kScanThreads), 0, st, keep, (int)L, dst, stats,
-                       host_mapped, seq);
+                       host_mapped, seq, zero_me);
     return (int)hipGetLastError();
 }
 
+template <int DT>
+static uint32_t host_thr_key(double thr);   // order-preserving key of T(thr) computed on the host
+template <> uint32_t host_thr_key<FF_F32>(double thr) {
+    float f = thr == 0.0 ? -0.0f : (float)thr;
+    uint32_t b; memcpy(&b, &f, 4);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+template <> uint32_t host_thr_key<FF_BF16>(double thr) {
+    float f = thr == 0.0 ? -0.0f : (float)thr;   // already bf16-valued: low 16 bits are zero
+    uint32_t b; memcpy(&b, &f, 4);
+    b >>= 16;
+    return (b & 0x8000u) ? (~b & 0xffffu) : (b | 0x8000u);
+}
+template <> uint32_t host_thr_key<FF_F16>(double thr) {
+    _Float16 h = (_Float16)(thr == 0.0 ? -0.0f : (float)thr);
+    uint16_t b; memcpy(&b, &h, 2);
+    return (b & 0x8000u) ? ((uint32_t)(~b) & 0xffffu) : ((uint32_t)b | 0x8000u);
+}
+
+// values/selection -> member, keep.  l0 == nullptr: level 0 is computed here (k_hist_level(0)).
+template <int DT>
+static int launch_select_flags(const void* values, PlanParams pp, const int* l0, int64_t n_range_hi, int64_t L,
+                               const int32_t* order, uint8_t* member, uint8_t* keep, int64_t* stats, void* ws,
+                               hipStream_t st) {
+    constexpr int kLevels = Act<DT>::kKeyBits / 8;
+    const unsigned G = cdiv(L, kSlice);
+    pp.n_slices = (int)G;
+    int* lv = ws_levels(ws, L);
+    (void)n_range_hi;
+    if (!l0) {
+        int* rows = ws_l0_rows(ws);
+        pp.l0_rows = (int)G;
+        hipLaunchKernelGGL(k_hist_level<DT>, dim3(G), dim3(kSliceThreads), 0, st, values, pp, 0, stats,
+                           (const int*)nullptr, lv, rows);
+        l0 = rows;
+    }
+    for (int level = 1; level < kLevels; ++level)
+        hipLaunchKernelGGL(k_hist_level<DT>, dim3(G), dim3(kSliceThreads), 0, st, values, pp, level, stats, l0, lv,
+                           (int*)nullptr);
+    hipLaunchKernelGGL(k_flags<DT>, dim3(G), dim3(kSliceThreads), 0, st, values, pp, l0, (const int*)lv, stats, order,
+                       (int)L, member, keep);
+    return (int)hipGetLastError();
+}
+
+// l0_copies: the table the similarity kernel filled for this call (fused path) or nullptr.
 int launch_plan_merge(const void* sim, int dtype, const int32_t* order, int64_t L, double thr, double sub,
                       double ratio_lb, uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
-                      void* ws, int64_t* host_mapped, int64_t seq, hipStream_t st) {
-    Select* sel = (Select*)ws;
-    const dim3 fg(cdiv(L, 256));
+                      void* ws, const int* l0_copies, int* zero_next, int64_t* host_mapped, int64_t seq,
+                      hipStream_t st) {
+    PlanParams pp;
+    pp.mode = 0; pp.lo = 0; pp.hi = -1; pp.k_given = 0; pp.sub = sub; pp.ratio_lb = ratio_lb;
+    pp.l0_rows = kL0Copies; pp.n_slices = 0;
+    int rc;
     switch (dtype) {
         case FF_F32:
-            hipLaunchKernelGGL(k_select_merge<FF_F32>, dim3(1), dim3(kSelThreads), 0, st, sim, thr, sub, ratio_lb, stats, sel);
-            hipLaunchKernelGGL(k_flags<FF_F32>, fg, dim3(256), 0, st, sim, sel, stats, order, (int)L, member, keep);
+            pp.thr_key = host_thr_key<FF_F32>(thr);
+            rc = launch_select_flags<FF_F32>(sim, pp, l0_copies, L, L, order, member, keep, stats, ws, st);
             break;
         case FF_BF16:
-            hipLaunchKernelGGL(k_select_merge<FF_BF16>, dim3(1), dim3(kSelThreads), 0, st, sim, thr, sub, ratio_lb, stats, sel);
-            hipLaunchKernelGGL(k_flags<FF_BF16>, fg, dim3(256), 0, st, sim, sel, stats, order, (int)L, member, keep);
+            pp.thr_key = host_thr_key<FF_BF16>(thr);
+            rc = launch_select_flags<FF_BF16>(sim, pp, l0_copies, L, L, order, member, keep, stats, ws, st);
             break;
         default:
-            hipLaunchKernelGGL(k_select_merge<FF_F16>, dim3(1), dim3(kSelThreads), 0, st, sim, thr, sub, ratio_lb, stats, sel);
-            hipLaunchKernelGGL(k_flags<FF_F16>, fg, dim3(256), 0, st, sim, sel, stats, order, (int)L, member, keep);
+            pp.thr_key = host_thr_key<FF_F16>(thr);
+            rc = launch_select_flags<FF_F16>(sim, pp, l0_copies, L, L, order, member, keep, stats, ws, st);
     }
-    int rc = (int)hipGetLastError();
     if (rc) return rc;
-    return launch_scan(keep, L, dst, stats, host_mapped, seq, st);
+    return launch_scan(keep, L, dst, stats, host_mapped, seq, zero_next, st);
 }
 
 int launch_plan_prune(const void* imp, int dtype, int64_t S, int64_t start, int64_t n_img, int64_t k,
                       uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats, void* ws,
                       int64_t* host_mapped, int64_t seq, hipStream_t st) {
-    Select* sel = (Select*)ws;
-    const dim3 fg(cdiv(S, 256));
+    PlanParams pp;
+    pp.mode = 1; pp.lo = (int)start; pp.hi = (int)(start + n_img); pp.k_given = k; pp.sub = 0; pp.ratio_lb = 0;
+    pp.thr_key = 0; pp.l0_rows = 0; pp.n_slices = 0;
+    int rc;
     switch (dtype) {
-        case FF_F32:
-            hipLaunchKernelGGL(k_select_prune<FF_F32>, dim3(1), dim3(kSelThreads), 0, st, imp, (int)S, (int)start, (int)n_img, (int)k, stats, sel);
-            hipLaunchKernelGGL(k_flags<FF_F32>, fg, dim3(256), 0, st, imp, sel, stats, (const int32_t*)nullptr, (int)S, member, keep);
-            break;
-        case FF_BF16:
-            hipLaunchKernelGGL(k_select_prune<FF_BF16>, dim3(1), dim3(kSelThreads), 0, st, imp, (int)S, (int)start, (int)n_img, (int)k, stats, sel);
-            hipLaunchKernelGGL(k_flags<FF_BF16>, fg, dim3(256), 0, st, imp, sel, stats, (const int32_t*)nullptr, (int)S, member, keep);
-            break;
-        default:
-            hipLaunchKernelGGL(k_select_prune<FF_F16>, dim3(1), dim3(kSelThreads), 0, st, imp, (int)S, (int)start, (int)n_img, (int)k, stats, sel);
-            hipLaunchKernelGGL(k_flags<FF_F16>, fg, dim3(256), 0, st, imp, sel, stats, (const int32_t*)nullptr, (int)S, member, keep);
+        case FF_F32: rc = launch_select_flags<FF_F32>(imp, pp, nullptr, S, S, nullptr, member, keep, stats, ws, st); break;
+        case FF_BF16: rc = launch_select_flags<FF_BF16>(imp, pp, nullptr, S, S, nullptr, member, keep, stats, ws, st); break;
+        default: rc = launch_select_flags<FF_F16>(imp, pp, nullptr, S, S, nullptr, member, keep, stats, ws, st);
     }
-    int rc = (int)hipGetLastError();
     if (rc) return rc;
-    return launch_scan(keep, S, dst, stats, host_mapped, seq, st);
+    return launch_scan(keep, S, dst, stats, host_mapped, seq, nullptr, st);
 }
 
 int launch_plan_from_index(const int64_t* merge_index, int64_t n_merge, const int32_t* order, int64_t L,
@@ -474,7 +553,7 @@ int launch_plan_from_index(const int64_t* merge_index, int64_t n_merge, const in
     hipLaunchKernelGGL(k_keep_from_member, dim3(cdiv(L, 256)), dim3(256), 0, st, member, order, (int)L, keep);
     int rc = (int)hipGetLastError();
     if (rc) return rc;
-    return launch_scan(keep, L, dst, stats, nullptr, 0, st);
+    return launch_scan(keep, L, dst, stats, nullptr, 0, nullptr, st);
 }
 
 }  // namespace ff
@@ -482,8 +561,8 @@ int launch_plan_from_index(const int64_t* merge_index, int64_t n_merge, const in
 static int check_plan_args(const void* a, const void* b, const void* c, const void* d, const void* e,
                            int64_t L, void* ws, size_t ws_bytes) {
     if (!a || !b || !c || !d || !e || !ws || L < 0) return FF_ERR_ARG;
-    if (L >= (1ll << 31) - ff::kRound) return FF_ERR_UNSUPPORTED;
-    if (ws_bytes < 256) return FF_ERR_WORKSPACE;
+    if (L >= (1ll << 31) - 65536) return FF_ERR_UNSUPPORTED;
+    if (ws_bytes < ff::plan_ws_bytes(L)) return FF_ERR_WORKSPACE;
     return FF_OK;
 }
 
@@ -499,7 +578,7 @@ extern "C" int ff_plan_merge(const void* sim, int dtype, const int32_t* order, i
     if (!aligned16(sim) || !aligned16(dst) || !aligned16(keep) || !aligned16(ws)) return FF_ERR_ALIGN;
     if (L == 0) return FF_OK;
     return ff::launch_plan_merge(sim, dtype, order, L, threshold, sub, ratio_lb, member, dst, keep, stats, ws,
-                                 nullptr, 0, (hipStream_t)stream);
+                                 nullptr, nullptr, nullptr, 0, (hipStream_t)stream);
 }
 
 extern "C" int ff_plan_from_index(const int64_t* merge_index, int64_t n_merge, const int32_t* order, int64_t L,

@@ -25,7 +25,8 @@ constexpr int kSimWaves = kSimThreads / kWave;
 template <int DT, int kPairs>
 __global__ __launch_bounds__(kSimThreads) void k_pair_similarity(
     const char* __restrict__ hidden, uint32_t row_bytes, const int64_t* __restrict__ ptype,
-    const int32_t* __restrict__ order, const int64_t* __restrict__ stats, void* __restrict__ sim) {
+    const int32_t* __restrict__ order, const int64_t* __restrict__ stats, void* __restrict__ sim,
+    int* __restrict__ l0, float thr) {
     using A = Act<DT>;
     constexpr int E = A::kPer16;
     constexpr int R = kPairs + 1;
@@ -96,6 +97,19 @@ __global__ __launch_bounds__(kSimThreads) void k_pair_similarity(
                     s = A::rnd(d / den);
                 }
                 A::store1(sim, j, s);
+                if (l0) {
+                    // level-0 statistics of the select that follows (ff_plan.hip): top byte of the
+                    // order-preserving key + count(sim >= thr), in one of 64 table copies so that
+                    // the (non-returning) atomics never pile up on one L2 word
+                    int* tab = l0 + (blockIdx.x & 63) * 260;
+                    uint32_t bits;
+                    if constexpr (DT == FF_F32) bits = __float_as_uint(s);
+                    else if constexpr (DT == FF_BF16) bits = __float_as_uint(s) >> 16;
+                    else { _Float16 h = (_Float16)s; bits = (uint32_t)__builtin_bit_cast(uint16_t, h); }
+                    const uint32_t key = order_key<DT>(bits);
+                    atomicAdd(&tab[key >> (A::kKeyBits - 8)], 1);
+                    if (s >= thr) atomicAdd(&tab[256], 1);
+                }
             }
         }
     }
@@ -103,12 +117,13 @@ __global__ __launch_bounds__(kSimThreads) void k_pair_similarity(
 
 template <int DT, int kPairs>
 static int launch_similarity_p(const void* hidden, int64_t L, int64_t d, const int64_t* ptype,
-                               const int32_t* order, const int64_t* stats, void* sim, hipStream_t st) {
+                               const int32_t* order, const int64_t* stats, void* sim, int* l0, float thr,
+                               hipStream_t st) {
     const int64_t row_bytes = d * Act<DT>::kBytes;
     const int64_t per_block = (int64_t)kSimWaves * kPairs;
     const int64_t blocks = (L + per_block - 1) / per_block;
     hipLaunchKernelGGL((k_pair_similarity<DT, kPairs>), dim3((unsigned)blocks), dim3(kSimThreads), 0, st,
-                       (const char*)hidden, (uint32_t)row_bytes, ptype, order, stats, sim);
+                       (const char*)hidden, (uint32_t)row_bytes, ptype, order, stats, sim, l0, thr);
     return (int)hipGetLastError();
 }
 
@@ -123,11 +138,22 @@ static int tune_pairs() {
 
 template <int DT>
 static int launch_similarity(const void* hidden, int64_t L, int64_t d, const int64_t* ptype,
-                             const int32_t* order, const int64_t* stats, void* sim, hipStream_t st) {
+                             const int32_t* order, const int64_t* stats, void* sim, int* l0, float thr,
+                             hipStream_t st) {
     switch (tune_pairs()) {
-        case 2: return launch_similarity_p<DT, 2>(hidden, L, d, ptype, order, stats, sim, st);
-        case 8: return launch_similarity_p<DT, 8>(hidden, L, d, ptype, order, stats, sim, st);
-        default: return launch_similarity_p<DT, 4>(hidden, L, d, ptype, order, stats, sim, st);
+        case 2: return launch_similarity_p<DT, 2>(hidden, L, d, ptype, order, stats, sim, l0, thr, st);
+        case 8: return launch_similarity_p<DT, 8>(hidden, L, d, ptype, order, stats, sim, l0, thr, st);
+        default: return launch_similarity_p<DT, 4>(hidden, L, d, ptype, order, stats, sim, l0, thr, st);
+    }
+}
+
+int launch_similarity_any(const void* hidden, int dtype, int64_t L, int64_t d, const int64_t* ptype,
+                          const int32_t* order, const int64_t* stats, void* sim, int* l0, double thr,
+                          hipStream_t st) {
+    switch (dtype) {
+        case FF_F32: return launch_similarity<FF_F32>(hidden, L, d, ptype, order, stats, sim, l0, (float)thr, st);
+        case FF_BF16: return launch_similarity<FF_BF16>(hidden, L, d, ptype, order, stats, sim, l0, (float)thr, st);
+        default: return launch_similarity<FF_F16>(hidden, L, d, ptype, order, stats, sim, l0, (float)thr, st);
     }
 }
 
@@ -142,10 +168,6 @@ extern "C" int ff_pair_similarity(const void* hidden, int dtype, int64_t L, int6
     if (((uintptr_t)hidden & 15) || ((d * esz) & 15)) return FF_ERR_ALIGN;
     if (L >= (1ll << 31) || d * esz >= (1ll << 31)) return FF_ERR_UNSUPPORTED;
     if (L == 0) return FF_OK;
-    hipStream_t st = (hipStream_t)stream;
-    switch (dtype) {
-        case FF_F32: return ff::launch_similarity<FF_F32>(hidden, L, d, patch_type, order, stats, sim, st);
-        case FF_BF16: return ff::launch_similarity<FF_BF16>(hidden, L, d, patch_type, order, stats, sim, st);
-        default: return ff::launch_similarity<FF_F16>(hidden, L, d, patch_type, order, stats, sim, st);
-    }
+    return ff::launch_similarity_any(hidden, dtype, L, d, patch_type, order, stats, sim, nullptr, 0.0,
+                                     (hipStream_t)stream);
 }

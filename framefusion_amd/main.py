@@ -60,7 +60,7 @@ class _Scratch:
             self.keep = torch.empty(cap, dtype=torch.uint8, device=dev)
             self.sim32 = torch.empty(cap, dtype=torch.float32, device=dev)   # viewed as T
             self.ws_bytes = int(_lib.load().ff_workspace_bytes(cap, 1))
-            self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+            self.ws = torch.zeros(self.ws_bytes, dtype=torch.uint8, device=dev)   # select tables start clean
             self.stats = torch.zeros(_lib.STAT_WORDS, dtype=torch.int64, device=dev)
             self.stats_host = torch.zeros(_lib.STAT_WORDS, dtype=torch.int64).pin_memory()
             self.stats_host_ptr = self.stats_host.data_ptr()     # device-visible (pinned, UVA)
@@ -128,6 +128,12 @@ class FrameFusion(nn.Module):
         return hidden_states, position_embeddings, attention_mask
 
     # ---- helpers -------------------------------------------------------------------------------
+    def _threshold_for(self, dtype) -> float:
+        key = (self.similarity_lower_bound, dtype)
+        if getattr(self, "_thr_cache_key", None) != key:
+            self._thr_cache_key, self._thr_cache = key, _round_to(self.similarity_lower_bound, dtype)
+        return self._thr_cache
+
     def _scratch_for(self, device, L, dtype) -> _Scratch:
         key = (device.type, device.index)
         s = self._scratch.get(key)
@@ -215,12 +221,14 @@ class FrameFusion(nn.Module):
 
         # first half (K0 + K1) goes out before any output tensor exists: the allocations below
         # overlap the similarity pass
+        thr = self._threshold_for(dtype)
+        sc.seq += 1
+        seq = sc.seq
         rc = lib.ff_merge_begin(hidden.data_ptr(), code, L, d, ptype.data_ptr(), int(self.patch_num), order_valid,
-                                sc.order.data_ptr(), sim_ptr, sc.stats.data_ptr(), sc.ws.data_ptr(), sc.ws_bytes,
-                                stream)
+                                thr, sc.order.data_ptr(), sim_ptr, sc.stats.data_ptr(), seq, sc.ws.data_ptr(),
+                                sc.ws_bytes, stream)
         _lib.check(rc, "ff_merge_begin")
 
-        thr = _round_to(self.similarity_lower_bound, dtype)
         L_cap = L
         out = torch.empty(1, L_cap, d, dtype=dtype, device=device)
         ptype_out = torch.empty(1, L_cap, dtype=torch.int64, device=device)
@@ -228,8 +236,6 @@ class FrameFusion(nn.Module):
         aux = (FFAux * _lib.MAX_AUX)()
         n_aux = self._fill_aux(aux, 0, [ptype.view(1, L)], [ptype_out], L)
         n_aux = self._fill_aux(aux, n_aux, srcs, outs, L)
-        sc.seq += 1
-        seq = sc.seq
         rc = lib.ff_merge_finish(hidden.data_ptr(), out.data_ptr(), code, L, d, L_cap,
                                  float(thr), float(sub), float(self.ratio_lower_bound),
                                  sc.order.data_ptr(), sim_ptr, sc.member.data_ptr(), sc.dst.data_ptr(),

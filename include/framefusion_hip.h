@@ -179,10 +179,13 @@ int ff_merge_step(const void* hidden, void* hidden_out, int dtype, int64_t L, in
                   void* ws, size_t ws_bytes, ff_stream_t stream);
 
 /* The same step in two halves, so the host can allocate the output tensors while the first
- * streaming pass runs: begin = K0 (unless order_valid) + K1, finish = K2+K3 + K4. */
+ * streaming pass runs: begin = K0 (unless order_valid) + K1, finish = K2+K3 + K4.  `ws` must be the
+ * SAME zero-initialised workspace for every call of a sequence and `seq` must increase by one per
+ * call: the similarity kernel accumulates the select's level-0 statistics into the table of parity
+ * (seq & 1) and the scan kernel of the call clears the other table for the next call. */
 int ff_merge_begin(const void* hidden, int dtype, int64_t L, int64_t d,
-                   const int64_t* patch_type, int64_t patch_num, int order_valid,
-                   int32_t* order, void* sim, int64_t* stats, void* ws, size_t ws_bytes,
+                   const int64_t* patch_type, int64_t patch_num, int order_valid, double threshold,
+                   int32_t* order, void* sim, int64_t* stats, int64_t seq, void* ws, size_t ws_bytes,
                    ff_stream_t stream);
 int ff_merge_finish(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
                     double threshold, double sub, double ratio_lb,
