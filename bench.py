@@ -122,7 +122,7 @@ def main():
         sub = float(ff._compute_pruning_ratio([], COST))
         stages = {
             "order": lambda: lib.ff_build_order(ptype.data_ptr(), L, P, sc.order.data_ptr(), sc.stats.data_ptr(),
-                                                None, 0, stream),
+                                                sc.ws.data_ptr(), sc.ws_bytes, stream),
             "similarity": lambda: lib.ff_pair_similarity(hidden.data_ptr(), _lib.FF_BF16, L, d, ptype.data_ptr(),
                                                          sc.order.data_ptr(), sc.stats.data_ptr(), sim.data_ptr(), stream),
             "plan": lambda: lib.ff_plan_merge(sim.data_ptr(), _lib.FF_BF16, sc.order.data_ptr(), L, thr, sub, RATIO_LB,

@@ -31,7 +31,8 @@ extern "C" const char* ff_error_string(int code) {
 extern "C" size_t ff_workspace_bytes(int64_t L, int64_t patch_num) {
     (void)patch_num;
     if (L < 0) return 0;
-    return ff::plan_ws_bytes(L);   // select statistics tables (see ff_plan.hip)
+    // select statistics tables (ff_plan.hip) followed by the per-slice rows of the order kernel
+    return ff::plan_ws_bytes(L) + ((size_t)(L / 4096) + 1) * 64 + 256;
 }
 
 extern "C" int ff_merge_begin(const void* hidden, int dtype, int64_t L, int64_t d, const int64_t* patch_type,

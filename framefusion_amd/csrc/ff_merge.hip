@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
     const char* __restrict__ hidden, char* __restrict__ out, uint32_t row_bytes, int L, int64_t L_cap,
     const int32_t* __restrict__ order, const uint8_t* __restrict__ member, int fold,
     const int32_t* __restrict__ dst, const uint8_t* __restrict__ keep, AuxPack aux, int kSlots, int n_main,
-    int ablate) {
+    int ablate, int reverse) {
     using A = Act<DT>;
     constexpr int E = A::kPer16;
     const int lane = lane_id();
@@ -96,7 +96,10 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
         }
         return;
     }
-    const int t0 = blockIdx.x * kSlots;
+    // slot groups are walked from the END of the by-patch order: the similarity pass read the rows
+    // in ascending order, so its most recently fetched rows - the ones the 256 MiB Infinity Cache
+    // still holds - are the first ones this pass asks for
+    const int t0 = (reverse ? (n_main - 1 - (int)blockIdx.x) : (int)blockIdx.x) * kSlots;
     const int cb = uniform(blockIdx.y * kMergeWaves + wave_id());     // 1 KiB column tile
     const uint32_t col = (uint32_t)cb * 1024u;
     if (col >= row_bytes) return;
@@ -230,13 +233,13 @@ __global__ __launch_bounds__(256) void k_head_mean(const void* __restrict__ w, i
 template <int DT>
 static void launch_mc(dim3 grid, hipStream_t st, int depth, const char* h, char* o, uint32_t row_bytes, int L,
                       int64_t L_cap, const int32_t* order, const uint8_t* member, int fold, const int32_t* dst,
-                      const uint8_t* keep, const AuxPack& pack, int slots, int n_main, int ablate) {
+                      const uint8_t* keep, const AuxPack& pack, int slots, int n_main, int ablate, int reverse) {
     if (depth == 4)
         hipLaunchKernelGGL((k_merge_compact<DT, 4>), grid, dim3(kMergeThreads), 0, st, h, o, row_bytes, L, L_cap, order,
-                           member, fold, dst, keep, pack, slots, n_main, ablate);
+                           member, fold, dst, keep, pack, slots, n_main, ablate, reverse);
     else
         hipLaunchKernelGGL((k_merge_compact<DT, 8>), grid, dim3(kMergeThreads), 0, st, h, o, row_bytes, L, L_cap, order,
-                           member, fold, dst, keep, pack, slots, n_main, ablate);
+                           member, fold, dst, keep, pack, slots, n_main, ablate, reverse);
 }
 
 int launch_merge_compact(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
@@ -248,7 +251,7 @@ int launch_merge_compact(const void* hidden, void* hidden_out, int dtype, int64_
     for (int x = pack.n; x < FF_MAX_AUX; ++x) pack.a[x] = ff_aux_t{nullptr, nullptr, 0, 0};
     const int64_t row_bytes = d * (dtype == FF_F32 ? 4 : 2);
     const int nblk = (int)((row_bytes + 1023) / 1024);
-    static int slots = 0, depth = 0, ablate = 0;
+    static int slots = 0, depth = 0, ablate = 0, reverse = 1;
     if (!slots) {
         const char* e1 = getenv("FF_MERGE_SLOTS");
         const char* e2 = getenv("FF_MERGE_DEPTH");
@@ -256,6 +259,8 @@ int launch_merge_compact(const void* hidden, void* hidden_out, int dtype, int64_
         slots = e1 ? atoi(e1) : kSlotsDefault;
         depth = e2 ? atoi(e2) : 4;
         ablate = e3 ? atoi(e3) : 0;
+        const char* e4 = getenv("FF_MERGE_REVERSE");
+        reverse = e4 ? atoi(e4) : 1;
         if (slots < 1 || slots > 56) slots = kSlotsDefault;
     }
     const int n_main = (int)((L + slots - 1) / slots);
@@ -264,9 +269,9 @@ int launch_merge_compact(const void* hidden, void* hidden_out, int dtype, int64_
     const char* h = (const char*)hidden;
     char* o = (char*)hidden_out;
     switch (dtype) {
-        case FF_F32: launch_mc<FF_F32>(grid, st, depth, h, o, (uint32_t)row_bytes, (int)L, L_cap, order, member, fold, dst, keep, pack, slots, n_main, ablate); break;
-        case FF_BF16: launch_mc<FF_BF16>(grid, st, depth, h, o, (uint32_t)row_bytes, (int)L, L_cap, order, member, fold, dst, keep, pack, slots, n_main, ablate); break;
-        default: launch_mc<FF_F16>(grid, st, depth, h, o, (uint32_t)row_bytes, (int)L, L_cap, order, member, fold, dst, keep, pack, slots, n_main, ablate);
+        case FF_F32: launch_mc<FF_F32>(grid, st, depth, h, o, (uint32_t)row_bytes, (int)L, L_cap, order, member, fold, dst, keep, pack, slots, n_main, ablate, reverse); break;
+        case FF_BF16: launch_mc<FF_BF16>(grid, st, depth, h, o, (uint32_t)row_bytes, (int)L, L_cap, order, member, fold, dst, keep, pack, slots, n_main, ablate, reverse); break;
+        default: launch_mc<FF_F16>(grid, st, depth, h, o, (uint32_t)row_bytes, (int)L, L_cap, order, member, fold, dst, keep, pack, slots, n_main, ablate, reverse);
     }
     return (int)hipGetLastError();
 }

@@ -27,45 +27,62 @@ namespace ff {
 
 constexpr int kEpt = 16;                          // values per thread: two/four 16-byte loads
 
-// 16 consecutive T values starting at j0 (j0 % 16 == 0) as order-preserving keys; entries at or
-// beyond `n` are flagged invalid.
+// 16 consecutive T values starting at j0 (j0 % 16 == 0): the raw 16-byte words first (so the loads
+// can be issued before anything they do not depend on), then the order-preserving keys; entries at
+// or beyond `n` are flagged invalid.  `cap` = number of readable elements of the array.
+template <int DT> struct RawKeys { uint4 w[Act<DT>::kBytes == 2 ? 2 : 4]; };
+
 template <int DT>
-__device__ inline void load_keys(const void* __restrict__ v, int j0, int n, uint32_t* key, uint32_t& valid_mask) {
+__device__ inline RawKeys<DT> load_raw(const void* __restrict__ v, int j0, int cap) {
     using A = Act<DT>;
-    valid_mask = 0;
-    if (j0 >= n) {
+    constexpr int W = A::kBytes == 2 ? 2 : 4;
+    RawKeys<DT> r;
+    if (j0 + kEpt <= cap) {
+        const uint4* p = (const uint4*)((const char*)v + (size_t)j0 * A::kBytes);
 #pragma unroll
-        for (int e = 0; e < kEpt; ++e) key[e] = 0;
-        return;
-    }
-    if (j0 + kEpt <= n) {
-        valid_mask = 0xffffu;
-        if constexpr (A::kBytes == 2) {
-            const uint4* p = (const uint4*)((const uint16_t*)v + j0);
-            const uint4 a = p[0], b = p[1];
-            const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        for (int q = 0; q < W; ++q) r.w[q] = p[q];
+    } else {
+        uint32_t x[W * 4];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                key[2 * q] = order_key<DT>(w[q] & 0xffffu);
-                key[2 * q + 1] = order_key<DT>(w[q] >> 16);
-            }
-        } else {
-            const uint4* p = (const uint4*)((const uint32_t*)v + j0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint4 a = p[q];
-                key[4 * q] = order_key<DT>(a.x); key[4 * q + 1] = order_key<DT>(a.y);
-                key[4 * q + 2] = order_key<DT>(a.z); key[4 * q + 3] = order_key<DT>(a.w);
+        for (int q = 0; q < W * 4; ++q) x[q] = 0;
+        for (int e = 0; e < kEpt; ++e) {
+            if (j0 + e < cap) {
+                const uint32_t b = A::bits1(v, j0 + e);
+                if constexpr (A::kBytes == 2) x[e >> 1] |= b << (16 * (e & 1));
+                else x[e] = b;
             }
         }
-        return;
-    }
 #pragma unroll
-    for (int e = 0; e < kEpt; ++e) {
-        const bool ok = j0 + e < n;
-        key[e] = ok ? order_key<DT>(A::bits1(v, j0 + e)) : 0;
-        valid_mask |= ok ? (1u << e) : 0u;
+        for (int q = 0; q < W; ++q) r.w[q] = make_uint4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
     }
+    return r;
+}
+
+template <int DT>
+__device__ inline void keys_of(const RawKeys<DT>& r, int j0, int n, uint32_t* key, uint32_t& valid_mask) {
+    using A = Act<DT>;
+    if constexpr (A::kBytes == 2) {
+        const uint32_t w[8] = {r.w[0].x, r.w[0].y, r.w[0].z, r.w[0].w, r.w[1].x, r.w[1].y, r.w[1].z, r.w[1].w};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            key[2 * q] = order_key<DT>(w[q] & 0xffffu);
+            key[2 * q + 1] = order_key<DT>(w[q] >> 16);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            key[4 * q] = order_key<DT>(r.w[q].x); key[4 * q + 1] = order_key<DT>(r.w[q].y);
+            key[4 * q + 2] = order_key<DT>(r.w[q].z); key[4 * q + 3] = order_key<DT>(r.w[q].w);
+        }
+    }
+    const int left = n - j0;
+    valid_mask = left >= kEpt ? 0xffffu : (left <= 0 ? 0u : ((1u << left) - 1u));
+}
+
+template <int DT>
+__device__ inline void load_keys(const void* __restrict__ v, int j0, int n, uint32_t* key, uint32_t& valid_mask) {
+    const RawKeys<DT> r = load_raw<DT>(v, j0, n);
+    keys_of<DT>(r, j0, n, key, valid_mask);
 }
 
 // key of a T-valued float (the threshold): entries with key >= this and not NaN satisfy sim >= thr
@@ -92,7 +109,7 @@ template <int DT> __device__ inline uint32_t nan_key() { return Act<DT>::kKeyBit
 constexpr int kSliceThreads = 256;
 constexpr int kSlice = kSliceThreads * kEpt;      // 4096 values per workgroup
 constexpr int kRowStride = 260;                   // 256 bins + count + pad
-constexpr int kL0Copies = 64;
+constexpr int kL0Copies = 16;
 
 struct PlanParams {
     int mode;            // 0: merge (threshold / top-k decided from the count), 1: prune (top-k given)
@@ -147,24 +164,52 @@ __device__ inline int pick_from_tot(SliceLds& s, int remaining, int& above) {
     return bin;
 }
 
+// Column `tid` of the level-0 table summed over its rows, plus this thread's share of the count
+// column.  Straight-line loads (all 64 in flight) for the table the similarity kernel fills.
+__device__ inline void sum_l0(const PlanParams& pp, const int* __restrict__ l0, int& col, int& cnt_part) {
+    const int tid = threadIdx.x;
+    int t0 = 0;
+    if (pp.l0_rows == kL0Copies) {
+        int v[kL0Copies];
+#pragma unroll
+        for (int q = 0; q < kL0Copies; ++q) v[q] = l0[q * kRowStride + tid];
+#pragma unroll
+        for (int q = 0; q < kL0Copies; ++q) t0 += v[q];
+    } else {
+#pragma unroll 16
+        for (int q = 0; q < pp.l0_rows; ++q) t0 += l0[q * kRowStride + tid];
+    }
+    int c = 0;
+    for (int q = tid; q < pp.l0_rows; q += kSliceThreads) c += l0[q * kRowStride + 256];
+    col = t0;
+    cnt_part = c;
+}
+
+// Column `tid` of every row of level table `l` (1-based) into regs[0..n_slices) is not possible with
+// a runtime count, so levels are summed on the fly; `before` = the rows of slices < my_slice only.
+__device__ inline void sum_level(const int* __restrict__ tab, int n_slices, int my_slice, int& all, int& before) {
+    const int tid = threadIdx.x;
+    int a = 0, b = 0;
+#pragma unroll 16
+    for (int g = 0; g < n_slices; ++g) {
+        const int x = tab[g * 256 + tid];
+        a += x;
+        b += g < my_slice ? x : 0;
+    }
+    all = a;
+    before = b;
+}
+
 // Re-derive the decision and the first `levels` bytes of the k-th key from the partial tables.
-// l0: [l0_rows][kRowStride]; lv: [levels-1][n_slices][256] (levels 1..).  Called by all threads.
-__device__ inline Resolved resolve(const PlanParams& pp, const int* __restrict__ l0, const int* __restrict__ lv,
-                                   int levels, long long ftn, int nv, SliceLds& s) {
+// l0col / l0cnt: this thread's sums from sum_l0; lvcol[l-1]: column sums of level l (sum_level).
+__device__ inline Resolved resolve(const PlanParams& pp, int l0col, int l0cnt, const int* lvcol, int levels,
+                                   long long ftn, int nv, SliceLds& s) {
     const int tid = threadIdx.x;
     Resolved r;
     r.prefix = 0; r.remaining = 0; r.count = 0;
-    // level-0 totals
-    int t0 = 0;
-    for (int q = 0; q < pp.l0_rows; ++q) t0 += l0[q * kRowStride + tid];
-    s.tot[tid] = t0;
-    if (tid == 0) {
-        int c = 0;
-        for (int q = 0; q < pp.l0_rows; ++q) c += l0[q * kRowStride + 256];
-        s.bcast[2] = c;
-    }
-    __syncthreads();
-    r.count = s.bcast[2];
+    s.tot[tid] = l0col;
+    const int c = block_sum_i<kSliceThreads / kWave>(l0cnt, s.scratch);
+    r.count = c;
     if (pp.mode == 0) {
         // main.py:114-116 in double, as python: ratio = count / ftn ; ratio < sub ?
         const double ratio = ftn > 0 ? (double)r.count / (double)ftn : 0.0;
@@ -185,10 +230,7 @@ __device__ inline Resolved resolve(const PlanParams& pp, const int* __restrict__
     for (int l = 0; l < levels; ++l) {
         if (l > 0) {
             __syncthreads();
-            const int* tab = lv + (size_t)(l - 1) * pp.n_slices * 256;
-            int t = 0;
-            for (int g = 0; g < pp.n_slices; ++g) t += tab[g * 256 + tid];
-            s.tot[tid] = t;
+            s.tot[tid] = lvcol[l - 1];
         }
         int above;
         const int bin = pick_from_tot(s, r.remaining, above);
@@ -206,27 +248,34 @@ __device__ inline void slice_range(const PlanParams& pp, int nv, int& lo, int& h
 // level `level` histogram of slice blockIdx.x (level 0 also counts values >= thr)
 template <int DT>
 __global__ __launch_bounds__(kSliceThreads) void k_hist_level(
-    const void* __restrict__ values, PlanParams pp, int level, const int64_t* __restrict__ stats,
+    const void* __restrict__ values, int cap, PlanParams pp, int level, const int64_t* __restrict__ stats,
     const int* __restrict__ l0, int* __restrict__ lv, int* __restrict__ l0_out) {
     using A = Act<DT>;
     __shared__ SliceLds s;
     const int tid = threadIdx.x, w = wave_id(), cp = lane_id() & 1;
+    // every load this workgroup needs is independent of the others: issue them all first
+    const int j0 = blockIdx.x * kSlice + tid * kEpt;
+    const RawKeys<DT> raw = load_raw<DT>(values, j0, cap);
     const int nv = (int)stats[FF_STAT_NV];
     const long long ftn = stats[FF_STAT_FTN];
+    int l0col = 0, l0cnt = 0, lvcol[3] = {0, 0, 0}, dummy;
+    if (level > 0) {
+        sum_l0(pp, l0, l0col, l0cnt);
+        for (int l = 1; l < level; ++l) sum_level(lv + (size_t)(l - 1) * pp.n_slices * 256, pp.n_slices, 0, lvcol[l - 1], dummy);
+    }
     int lo, hi;
     slice_range(pp, nv, lo, hi);
     uint32_t prefix = 0;
     if (level > 0) {
-        const Resolved r = resolve(pp, l0, lv, level, ftn, nv, s);
+        const Resolved r = resolve(pp, l0col, l0cnt, lvcol, level, ftn, nv, s);
         if (!r.topk || r.k <= 0) return;
         prefix = r.prefix;
         __syncthreads();
     }
     for (int x = tid; x < (kSliceThreads / kWave) * 2 * 256; x += kSliceThreads) (&s.hist[0][0][0])[x] = 0;
     __syncthreads();
-    const int j0 = blockIdx.x * kSlice + tid * kEpt;
     uint32_t key[kEpt], valid;
-    load_keys<DT>(values, j0, hi, key, valid);
+    keys_of<DT>(raw, j0, hi, key, valid);
     const int shift = A::kKeyBits - 8 * (level + 1);
     int c = 0;
 #pragma unroll
@@ -259,31 +308,56 @@ __global__ __launch_bounds__(kSliceThreads) void k_hist_level(
 // exceeds the number of valid pairs).
 template <int DT>
 __global__ __launch_bounds__(kSliceThreads) void k_flags(
-    const void* __restrict__ values, PlanParams pp, const int* __restrict__ l0, const int* __restrict__ lv,
+    const void* __restrict__ values, int cap, PlanParams pp, const int* __restrict__ l0, const int* __restrict__ lv,
     int64_t* __restrict__ stats, const int32_t* __restrict__ order, int L,
     uint8_t* __restrict__ member, uint8_t* __restrict__ keep) {
     using A = Act<DT>;
     constexpr int kLevels = A::kKeyBits / 8;
     __shared__ SliceLds s;
     const int tid = threadIdx.x;
+    // every load is independent of the others: values, row indices, counts and all tables first
+    const int j0 = blockIdx.x * kSlice + tid * kEpt;
+    const RawKeys<DT> raw = load_raw<DT>(values, j0, cap);
+    int ord[kEpt];
+    const int n_here = min(max(L - j0, 0), kEpt);
+    if (order) {
+        if (n_here == kEpt) {
+            const uint4* po = (const uint4*)(order + j0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint4 o4 = po[q];
+                ord[4 * q] = o4.x; ord[4 * q + 1] = o4.y; ord[4 * q + 2] = o4.z; ord[4 * q + 3] = o4.w;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < kEpt; ++e) ord[e] = e < n_here ? order[j0 + e] : 0;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < kEpt; ++e) ord[e] = j0 + e;
+    }
     const int nv = (int)stats[FF_STAT_NV];
     const long long ftn = stats[FF_STAT_FTN];
+    int l0col, l0cnt, lvcol[3] = {0, 0, 0}, lvbefore[3] = {0, 0, 0};
+    sum_l0(pp, l0, l0col, l0cnt);
+#pragma unroll
+    for (int l = 1; l < kLevels; ++l)
+        sum_level(lv + (size_t)(l - 1) * pp.n_slices * 256, pp.n_slices, (int)blockIdx.x, lvcol[l - 1], lvbefore[l - 1]);
     int lo, hi;
     slice_range(pp, nv, lo, hi);
-    const Resolved r = resolve(pp, l0, lv, kLevels, ftn, nv, s);
+    const Resolved r = resolve(pp, l0col, l0cnt, lvcol, kLevels, ftn, nv, s);
     const bool select_topk = r.topk;
     const uint32_t kth = r.prefix;
     const int need = r.remaining;                 // entries equal to kth that belong to the top k
-    // entries equal to kth in earlier slices (rows of the last level count exactly those)
-    int ties_before = 0;
-    if (select_topk && r.k > 0) {
-        const int* last = lv + (size_t)(kLevels - 2) * pp.n_slices * 256;
-        for (int g = 0; g < (int)blockIdx.x; ++g) ties_before += last[g * 256 + (kth & 255u)];
-    }
-    const int j0 = blockIdx.x * kSlice + tid * kEpt;
+    // entries equal to kth in earlier slices: the last level's rows count exactly those, and the
+    // thread that owns column (kth & 255) already holds their sum
+    __syncthreads();
+    if (tid == (int)(kth & 255u)) s.bcast[3] = lvbefore[kLevels - 2];
+    __syncthreads();
+    const int ties_before = (select_topk && r.k > 0) ? s.bcast[3] : 0;
     const int n_flag = pp.mode == 0 ? nv : L;
     uint32_t key[kEpt], valid;
-    load_keys<DT>(values, j0, n_flag, key, valid);
+    keys_of<DT>(raw, j0, n_flag, key, valid);
     int mine = 0;
     if (select_topk && r.k > 0) {
 #pragma unroll
@@ -312,7 +386,6 @@ __global__ __launch_bounds__(kSliceThreads) void k_flags(
         if (m) mem |= 1u << e;
     }
     if (j0 < L) {
-        const int n_here = min(L - j0, kEpt);
         if (n_here == kEpt && (((uintptr_t)(member + j0)) & 15) == 0) {
             uint32_t mb[4];
 #pragma unroll
@@ -325,11 +398,9 @@ __global__ __launch_bounds__(kSliceThreads) void k_flags(
         } else {
             for (int e = 0; e < n_here; ++e) member[j0 + e] = (mem >> e) & 1u;
         }
-        if (order) {
-            for (int e = 0; e < n_here; ++e) keep[order[j0 + e]] = ((mem >> e) & 1u) ? 0 : 1;
-        } else {
-            for (int e = 0; e < n_here; ++e) keep[j0 + e] = ((mem >> e) & 1u) ? 0 : 1;
-        }
+#pragma unroll
+        for (int e = 0; e < kEpt; ++e)
+            if (e < n_here) keep[ord[e]] = ((mem >> e) & 1u) ? 0 : 1;
     }
     if (blockIdx.x == 0 && tid == 0) {
         if (pp.mode == 0) {
@@ -442,7 +513,8 @@ static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1
 // [3][G][256] rows of levels 1..3;  G = ceil(L / 4096).
 size_t plan_ws_bytes(int64_t L) {
     const size_t G = (size_t)((L + kSlice - 1) / kSlice) + 1;
-    return (2 * (size_t)kL0Copies * kRowStride + G * kRowStride + 3 * G * 256) * sizeof(int) + 256;
+    const size_t b = (2 * (size_t)kL0Copies * kRowStride + G * kRowStride + 3 * G * 256) * sizeof(int) + 256;
+    return (b + 255) & ~(size_t)255;
 }
 int* ws_l0_copies(void* ws, int64_t seq) { return (int*)ws + (size_t)(seq & 1) * kL0Copies * kRowStride; }
 static int* ws_l0_rows(void* ws) { return (int*)ws + 2 * (size_t)kL0Copies * kRowStride; }
@@ -479,25 +551,24 @@ template <> uint32_t host_thr_key<FF_F16>(double thr) {
 
 // values/selection -> member, keep.  l0 == nullptr: level 0 is computed here (k_hist_level(0)).
 template <int DT>
-static int launch_select_flags(const void* values, PlanParams pp, const int* l0, int64_t n_range_hi, int64_t L,
+static int launch_select_flags(const void* values, PlanParams pp, const int* l0, int64_t cap, int64_t L,
                                const int32_t* order, uint8_t* member, uint8_t* keep, int64_t* stats, void* ws,
                                hipStream_t st) {
     constexpr int kLevels = Act<DT>::kKeyBits / 8;
     const unsigned G = cdiv(L, kSlice);
     pp.n_slices = (int)G;
     int* lv = ws_levels(ws, L);
-    (void)n_range_hi;
     if (!l0) {
         int* rows = ws_l0_rows(ws);
         pp.l0_rows = (int)G;
-        hipLaunchKernelGGL(k_hist_level<DT>, dim3(G), dim3(kSliceThreads), 0, st, values, pp, 0, stats,
+        hipLaunchKernelGGL(k_hist_level<DT>, dim3(G), dim3(kSliceThreads), 0, st, values, (int)cap, pp, 0, stats,
                            (const int*)nullptr, lv, rows);
         l0 = rows;
     }
     for (int level = 1; level < kLevels; ++level)
-        hipLaunchKernelGGL(k_hist_level<DT>, dim3(G), dim3(kSliceThreads), 0, st, values, pp, level, stats, l0, lv,
+        hipLaunchKernelGGL(k_hist_level<DT>, dim3(G), dim3(kSliceThreads), 0, st, values, (int)cap, pp, level, stats, l0, lv,
                            (int*)nullptr);
-    hipLaunchKernelGGL(k_flags<DT>, dim3(G), dim3(kSliceThreads), 0, st, values, pp, l0, (const int*)lv, stats, order,
+    hipLaunchKernelGGL(k_flags<DT>, dim3(G), dim3(kSliceThreads), 0, st, values, (int)cap, pp, l0, (const int*)lv, stats, order,
                        (int)L, member, keep);
     return (int)hipGetLastError();
 }

@@ -83,6 +83,8 @@ __global__ __launch_bounds__(kSimThreads) void k_pair_similarity(
 #pragma unroll
     for (int r = 0; r < kPairs; ++r) dot[r] = wave_sum(dot[r]);
 
+    float mine = -2.0f;
+    bool have = false;
 #pragma unroll
     for (int r = 0; r < kPairs; ++r) {
         if (lane == r) {
@@ -97,21 +99,35 @@ __global__ __launch_bounds__(kSimThreads) void k_pair_similarity(
                     s = A::rnd(d / den);
                 }
                 A::store1(sim, j, s);
-                if (l0) {
-                    // level-0 statistics of the select that follows (ff_plan.hip): top byte of the
-                    // order-preserving key + count(sim >= thr), in one of 64 table copies so that
-                    // the (non-returning) atomics never pile up on one L2 word
-                    int* tab = l0 + (blockIdx.x & 63) * 260;
-                    uint32_t bits;
-                    if constexpr (DT == FF_F32) bits = __float_as_uint(s);
-                    else if constexpr (DT == FF_BF16) bits = __float_as_uint(s) >> 16;
-                    else { _Float16 h = (_Float16)s; bits = (uint32_t)__builtin_bit_cast(uint16_t, h); }
-                    const uint32_t key = order_key<DT>(bits);
-                    atomicAdd(&tab[key >> (A::kKeyBits - 8)], 1);
-                    if (s >= thr) atomicAdd(&tab[256], 1);
-                }
+                mine = s;
+                have = true;
             }
         }
+    }
+    if (l0) {
+        // level-0 statistics of the select that follows (ff_plan.hip): top byte of the
+        // order-preserving key + count(sim >= thr), folded over the wave's kPairs values and added
+        // to one of 16 table copies so the (non-returning) atomics never pile up on one L2 word
+        int* tab = l0 + (blockIdx.x & 15) * 260;
+        uint32_t bits;
+        if constexpr (DT == FF_F32) bits = __float_as_uint(mine);
+        else if constexpr (DT == FF_BF16) bits = __float_as_uint(mine) >> 16;
+        else { _Float16 h = (_Float16)mine; bits = (uint32_t)__builtin_bit_cast(uint16_t, h); }
+        const int bin = (int)(order_key<DT>(bits) >> (A::kKeyBits - 8));
+        const unsigned long long vm = __ballot(have);
+        const int n_ge = __popcll(__ballot(have && mine >= thr));
+        if (lane == 0 && n_ge) atomicAdd(&tab[256], n_ge);
+        int mult = 0;
+        bool leader = have;
+#pragma unroll
+        for (int q = 0; q < kPairs; ++q) {
+            const int bq = __builtin_amdgcn_readlane(bin, q);
+            if (((vm >> q) & 1ull) && bq == bin) {
+                ++mult;
+                if (q < lane) leader = false;
+            }
+        }
+        if (leader) atomicAdd(&tab[bin], mult);
     }
 }
 

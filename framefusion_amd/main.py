@@ -343,9 +343,11 @@ class FrameFusion(nn.Module):
         order = torch.empty(L, dtype=torch.int32, device=device)
         sim = torch.empty(L, dtype=dtype, device=device)
         stats = torch.zeros(_lib.STAT_WORDS, dtype=torch.int64, device=device)
+        ws_bytes = int(lib.ff_workspace_bytes(L, int(patch_num)))
+        ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=device)
         stream = _lib.stream_ptr()
         _lib.check(lib.ff_build_order(ptype.data_ptr(), L, int(patch_num), order.data_ptr(), stats.data_ptr(),
-                                      None, 0, stream), "ff_build_order")
+                                      ws.data_ptr(), ws_bytes, stream), "ff_build_order")
         _lib.check(lib.ff_pair_similarity(hidden.data_ptr(), code, L, d, ptype.data_ptr(), order.data_ptr(),
                                           stats.data_ptr(), sim.data_ptr(), stream), "ff_pair_similarity")
         nv = int(stats[_lib.STAT_NV])

@@ -35,7 +35,9 @@ def hip_order(pt, P):
     ptd = dev(pt.reshape(-1).contiguous())
     order = torch.full((L,), -7, dtype=torch.int32, device=DEV)
     stats = torch.zeros(_lib.STAT_WORDS, dtype=torch.int64, device=DEV)
-    _lib.check(lib.ff_build_order(ptd.data_ptr(), L, P, order.data_ptr(), stats.data_ptr(), None, 0,
+    wsb = int(lib.ff_workspace_bytes(L, P))
+    ws = torch.zeros(wsb, dtype=torch.uint8, device=DEV)
+    _lib.check(lib.ff_build_order(ptd.data_ptr(), L, P, order.data_ptr(), stats.data_ptr(), ws.data_ptr(), wsb,
                                   _lib.stream_ptr()), "ff_build_order")
     torch.cuda.synchronize()
     return order.cpu().long(), stats.cpu()

@@ -1,0 +1,38 @@
+#!/usr/bin/env python
+"""Summarise a rocprofv3 --kernel-trace CSV into the per-call timeline of the merge step:
+kernel durations and the gaps between consecutive kernels of one FrameFusion.forward call."""
+import csv
+import sys
+from collections import defaultdict
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows = [r for r in rows if "ff::" in r["Kernel_Name"]]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+def short(n):
+    n = n.replace("void ", "")
+    return n.split("<")[0].split("(")[0].replace("ff::", "")
+calls = []
+cur = []
+for r in rows:
+    k = short(r["Kernel_Name"])
+    if k == "k_order_stats" and cur:
+        calls.append(cur)
+        cur = []
+    cur.append((k, int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+if cur:
+    calls.append(cur)
+want = ["k_order_stats", "k_build_order", "k_pair_similarity", "k_hist_level", "k_flags", "k_scan", "k_merge_compact"]
+calls = [c for c in calls if [k for k, _, _ in c] == want][5:]
+dur = defaultdict(list)
+gap = defaultdict(list)
+span = []
+for c in calls:
+    for i, (k, s, e) in enumerate(c):
+        dur[(i, k)].append((e - s) / 1e3)
+        if i:
+            gap[(i, k)].append((s - c[i - 1][2]) / 1e3)
+    span.append((c[-1][2] - c[0][1]) / 1e3)
+print(f"{len(calls)} calls; first-kernel-start to last-kernel-end: mean {sum(span)/len(span):.1f} us  min {min(span):.1f}")
+for (i, k), v in sorted(dur.items()):
+    g = gap.get((i, k), [0])
+    print(f"  {i} {k:18s} dur {sum(v)/len(v):7.1f} us   gap before {sum(g)/len(g):6.1f} us")
