@@ -107,6 +107,7 @@ def main():
         # ---- per-kernel timing with events on the launch stream (stage entry points) -------------
         lib = _lib.load()
         sc = ff._scratch[(dev.type, dev.index)]
+        order_buf = info["order"]
         stream = _lib.stream_ptr()
         elt = hidden.element_size()
         nv = info["nv"]
@@ -121,29 +122,34 @@ def main():
         thr = float(torch.tensor(THRESHOLD, dtype=hidden.dtype))
         sub = float(ff._compute_pruning_ratio([], COST))
         stages = {
-            "order": lambda: lib.ff_build_order(ptype.data_ptr(), L, P, sc.order.data_ptr(), sc.stats.data_ptr(),
+            "order": lambda: lib.ff_build_order(ptype.data_ptr(), L, P, order_buf.data_ptr(), sc.stats.data_ptr(),
                                                 sc.ws.data_ptr(), sc.ws_bytes, stream),
             "similarity": lambda: lib.ff_pair_similarity(hidden.data_ptr(), _lib.FF_BF16, L, d, ptype.data_ptr(),
-                                                         sc.order.data_ptr(), sc.stats.data_ptr(), sim.data_ptr(), stream),
-            "plan": lambda: lib.ff_plan_merge(sim.data_ptr(), _lib.FF_BF16, sc.order.data_ptr(), L, thr, sub, RATIO_LB,
+                                                         order_buf.data_ptr(), sc.stats.data_ptr(), sim.data_ptr(), stream),
+            "plan": lambda: lib.ff_plan_merge(sim.data_ptr(), _lib.FF_BF16, order_buf.data_ptr(), L, thr, sub, RATIO_LB,
                                               sc.member.data_ptr(), sc.dst.data_ptr(), sc.keep.data_ptr(),
                                               sc.stats.data_ptr(), sc.ws.data_ptr(), sc.ws_bytes, stream),
             "merge_compact": lambda: lib.ff_merge_compact(hidden.data_ptr(), out_buf.data_ptr(), _lib.FF_BF16, L, d, L,
-                                                          sc.order.data_ptr(), sc.member.data_ptr(), 1, sc.dst.data_ptr(),
+                                                          order_buf.data_ptr(), sc.member.data_ptr(), 1, sc.dst.data_ptr(),
                                                           sc.keep.data_ptr(), aux, 3, stream),
         }
-        reps = max(10, min(args.steps, 50))
-        kernel_us = {}
-        for name, fn in stages.items():
-            for _ in range(3):
-                _lib.check(fn(), name)
-            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-            for a, b in ev:
-                a.record()
-                _lib.check(fn(), name)
-                b.record()
-            torch.cuda.synchronize()
-            kernel_us[name] = sum(a.elapsed_time(b) for a, b in ev) / reps * 1e3
+        # per-kernel durations: the four stages in the order of a real step (each kernel sees the
+        # cache state its predecessor leaves behind), hipEvents between the stages on the launch
+        # stream, launches queued ahead so host latency is not billed to a kernel
+        reps = max(10, min(args.steps, 30))
+        names = list(stages)
+        for name in names:
+            _lib.check(stages[name](), name)
+        torch.cuda.synchronize()
+        marks = [[torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)] for _ in range(reps)]
+        for r in range(reps):
+            marks[r][0].record()
+            for q, name in enumerate(names):
+                _lib.check(stages[name](), name)
+                marks[r][q + 1].record()
+        torch.cuda.synchronize()
+        kernel_us = {name: sum(marks[r][q].elapsed_time(marks[r][q + 1]) for r in range(reps)) / reps * 1e3
+                     for q, name in enumerate(names)}
         alg = algorithmic_bytes(L, L_out, nv, d, elt, HEAD_DIM)
         dominant = max(("similarity", "merge_compact"), key=lambda k: kernel_us[k])
         achieved = alg[dominant] / (kernel_us[dominant] * 1e-6) / 1e9
@@ -167,7 +173,8 @@ def main():
                        "tokens_in": L, "tokens_out": L_out, "tokens_processed_per_s": world * L * args.steps / t_max,
                        "parallelism": f"dp{world} (independent samples)"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": profiled_traffic(dominant) if (F, P, d) == (FRAMES, PATCHES, DIM) else None,
                          "algorithmic_bytes": alg[dominant], "kernel_us": kernel_us[dominant]},
             "kernels_us": kernel_us,
             "step_roofline": {"algorithmic_bytes": alg["step"], "achieved": alg["step"] / (ms_per_step * 1e-3) / 1e9,
@@ -180,6 +187,27 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))
+
+
+def profiled_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/rNN_pmc_*):
+    2 x FETCH_SIZE (gfx950 counts 64 B per 128-B request for 16 B/lane streams, MI355X_MICROARCH.md
+    section HBM) + WRITE_SIZE, both reported in KiB.  None when no profile is committed."""
+    import glob
+    pat = {"merge_compact": "k_merge_compact", "similarity": "k_pair_similarity"}[kernel]
+    total = 0.0
+    for kind, scale in (("fetch", 2.0), ("write", 1.0)):
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{kind}_summary.csv")))
+        if not files:
+            return None
+        val = None
+        for line in open(files[-1]):
+            if pat in line:
+                val = float(line.strip().split(",")[-1])
+        if val is None:
+            return None
+        total += scale * val * 1024.0
+    return total
 
 
 def cpu_baseline(hidden, ptype, cos, sin, P, L, calls):

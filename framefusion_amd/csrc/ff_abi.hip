@@ -10,6 +10,10 @@ int launch_plan_merge(const void* sim, int dtype, const int32_t* order, int64_t 
                       hipStream_t st);
 size_t plan_ws_bytes(int64_t L);
 int* ws_l0_copies(void* ws, int64_t seq);
+int launch_merge_compact(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
+                         const int32_t* order, const uint8_t* member, int fold, const int32_t* dst,
+                         const uint8_t* keep, const ff_aux_t* aux_host, int n_aux, int32_t* order_next,
+                         int64_t* stats, hipStream_t st);
 int launch_similarity_any(const void* hidden, int dtype, int64_t L, int64_t d, const int64_t* ptype,
                           const int32_t* order, const int64_t* stats, void* sim, int* l0, double thr,
                           hipStream_t st);
@@ -58,7 +62,7 @@ extern "C" int ff_merge_finish(const void* hidden, void* hidden_out, int dtype, 
                                double threshold, double sub, double ratio_lb, const int32_t* order, const void* sim,
                                uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
                                int64_t* stats_host_mapped, int64_t seq, const ff_aux_t* aux_host, int n_aux,
-                               void* ws, size_t ws_bytes, ff_stream_t stream) {
+                               int32_t* order_next, void* ws, size_t ws_bytes, ff_stream_t stream) {
     if (!hidden || !hidden_out || !order || !sim || !member || !dst || !keep || !stats || !ws) return FF_ERR_ARG;
     if (ws_bytes < ff_workspace_bytes(L, 1)) return FF_ERR_WORKSPACE;
     if (L_cap < L) return FF_ERR_ARG;
@@ -68,7 +72,12 @@ extern "C" int ff_merge_finish(const void* hidden, void* hidden_out, int dtype, 
                                    ff::ws_l0_copies(ws, seq), ff::ws_l0_copies(ws, seq + 1), stats_host_mapped, seq,
                                    (hipStream_t)stream);
     if (rc) return rc;
-    return ff_merge_compact(hidden, hidden_out, dtype, L, d, L_cap, order, member, 1, dst, keep, aux_host, n_aux, stream);
+    if (n_aux < 0 || n_aux > FF_MAX_AUX || (n_aux > 0 && !aux_host)) return FF_ERR_ARG;
+    const int64_t esz = dtype == FF_F32 ? 4 : 2;
+    if (((uintptr_t)hidden & 15) || ((uintptr_t)hidden_out & 15) || ((d * esz) & 15)) return FF_ERR_ALIGN;
+    if (order_next && ((uintptr_t)member & 15)) return FF_ERR_ALIGN;
+    return ff::launch_merge_compact(hidden, hidden_out, dtype, L, d, L_cap, order, member, 1, dst, keep, aux_host,
+                                    n_aux, order_next, stats, (hipStream_t)stream);
 }
 
 extern "C" int ff_merge_step(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
@@ -81,5 +90,5 @@ extern "C" int ff_merge_step(const void* hidden, void* hidden_out, int dtype, in
                             seq, ws, ws_bytes, stream);
     if (rc) return rc;
     return ff_merge_finish(hidden, hidden_out, dtype, L, d, L_cap, threshold, sub, ratio_lb, order, sim, member, dst,
-                           keep, stats, stats_host_mapped, seq, aux_host, n_aux, ws, ws_bytes, stream);
+                           keep, stats, stats_host_mapped, seq, aux_host, n_aux, nullptr, ws, ws_bytes, stream);
 }

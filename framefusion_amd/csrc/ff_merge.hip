@@ -76,10 +76,41 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
     const char* __restrict__ hidden, char* __restrict__ out, uint32_t row_bytes, int L, int64_t L_cap,
     const int32_t* __restrict__ order, const uint8_t* __restrict__ member, int fold,
     const int32_t* __restrict__ dst, const uint8_t* __restrict__ keep, AuxPack aux, int kSlots, int n_main,
-    int ablate, int reverse) {
+    int ablate, int reverse, int n_aux_blocks, int32_t* __restrict__ order_next, int64_t* __restrict__ stats) {
     using A = Act<DT>;
     constexpr int E = A::kPer16;
     const int lane = lane_id();
+    if ((int)blockIdx.x >= n_main + n_aux_blocks) {
+        // ---- by-patch order of the COMPACTED sequence, for the next merge call (order maintenance):
+        // the surviving slots keep their relative by-patch order and dst[] is monotonic in the
+        // sequence position, so new_order = dst[order[t]] compacted over the non-member slots.
+        // Same communication-free scan as k_scan: this workgroup recounts the slots before its own.
+        if (blockIdx.y != 0) return;
+        __shared__ int scratch[kMergeWaves + 1];
+        const int tid = threadIdx.x;
+        const int base = ((int)blockIdx.x - n_main - n_aux_blocks) * (kMergeThreads * 16);
+        int before = 0;
+        for (int off = tid * 16; off < base; off += kMergeThreads * 16) {
+            const uint4 m4 = *(const uint4*)(member + off);
+            before += 16 - (__popc(m4.x) + __popc(m4.y) + __popc(m4.z) + __popc(m4.w));
+        }
+        before = block_sum_i<kMergeWaves>(before, scratch);
+        const int s0 = base + tid * 16;
+        const int n_here = min(max(L - s0, 0), 16);
+        unsigned nonmem = 0;
+        for (int e = 0; e < n_here; ++e) nonmem |= (member[s0 + e] ? 0u : 1u) << e;
+        int total;
+        int pos = before + block_excl_scan<kMergeWaves>(__popc(nonmem), scratch, total);
+        for (int e = 0; e < n_here; ++e) {
+            if ((nonmem >> e) & 1u) order_next[pos++] = dst[order[s0 + e]];
+        }
+        if (base + kMergeThreads * 16 >= L && tid == 0) {
+            const int64_t merged = stats[FF_STAT_MERGED];
+            stats[FF_STAT_NV] -= merged;        // the next call (order_valid) skips K0, which would set these
+            stats[FF_STAT_FTN] -= merged;
+        }
+        return;
+    }
     if ((int)blockIdx.x >= n_main) {
         // ---- auxiliary rows (position embeddings, patch types, position ids): plain compaction by
         // SEQUENCE position - reads coalesced, writes in increasing order.  Only blockIdx.y == 0.
@@ -233,18 +264,20 @@ __global__ __launch_bounds__(256) void k_head_mean(const void* __restrict__ w, i
 template <int DT>
 static void launch_mc(dim3 grid, hipStream_t st, int depth, const char* h, char* o, uint32_t row_bytes, int L,
                       int64_t L_cap, const int32_t* order, const uint8_t* member, int fold, const int32_t* dst,
-                      const uint8_t* keep, const AuxPack& pack, int slots, int n_main, int ablate, int reverse) {
+                      const uint8_t* keep, const AuxPack& pack, int slots, int n_main, int ablate, int reverse,
+                      int n_aux_blocks, int32_t* order_next, int64_t* stats) {
     if (depth == 4)
         hipLaunchKernelGGL((k_merge_compact<DT, 4>), grid, dim3(kMergeThreads), 0, st, h, o, row_bytes, L, L_cap, order,
-                           member, fold, dst, keep, pack, slots, n_main, ablate, reverse);
+                           member, fold, dst, keep, pack, slots, n_main, ablate, reverse, n_aux_blocks, order_next, stats);
     else
         hipLaunchKernelGGL((k_merge_compact<DT, 8>), grid, dim3(kMergeThreads), 0, st, h, o, row_bytes, L, L_cap, order,
-                           member, fold, dst, keep, pack, slots, n_main, ablate, reverse);
+                           member, fold, dst, keep, pack, slots, n_main, ablate, reverse, n_aux_blocks, order_next, stats);
 }
 
 int launch_merge_compact(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
                          const int32_t* order, const uint8_t* member, int fold, const int32_t* dst,
-                         const uint8_t* keep, const ff_aux_t* aux_host, int n_aux, hipStream_t st) {
+                         const uint8_t* keep, const ff_aux_t* aux_host, int n_aux, int32_t* order_next,
+                         int64_t* stats, hipStream_t st) {
     AuxPack pack;
     pack.n = keep ? n_aux : 0;
     for (int x = 0; x < pack.n; ++x) pack.a[x] = aux_host[x];
@@ -265,13 +298,15 @@ int launch_merge_compact(const void* hidden, void* hidden_out, int dtype, int64_
     }
     const int n_main = (int)((L + slots - 1) / slots);
     const int n_aux_blocks = pack.n ? (int)((L + kMergeWaves * 4 - 1) / (kMergeWaves * 4)) : 0;
-    const dim3 grid((unsigned)(n_main + n_aux_blocks), (unsigned)((nblk + kMergeWaves - 1) / kMergeWaves));
+    if (!order || !stats) order_next = nullptr;
+    const int n_next_blocks = order_next ? (int)((L + kMergeThreads * 16 - 1) / (kMergeThreads * 16)) : 0;
+    const dim3 grid((unsigned)(n_main + n_aux_blocks + n_next_blocks), (unsigned)((nblk + kMergeWaves - 1) / kMergeWaves));
     const char* h = (const char*)hidden;
     char* o = (char*)hidden_out;
     switch (dtype) {
-        case FF_F32: launch_mc<FF_F32>(grid, st, depth, h, o, (uint32_t)row_bytes, (int)L, L_cap, order, member, fold, dst, keep, pack, slots, n_main, ablate, reverse); break;
-        case FF_BF16: launch_mc<FF_BF16>(grid, st, depth, h, o, (uint32_t)row_bytes, (int)L, L_cap, order, member, fold, dst, keep, pack, slots, n_main, ablate, reverse); break;
-        default: launch_mc<FF_F16>(grid, st, depth, h, o, (uint32_t)row_bytes, (int)L, L_cap, order, member, fold, dst, keep, pack, slots, n_main, ablate, reverse);
+        case FF_F32: launch_mc<FF_F32>(grid, st, depth, h, o, (uint32_t)row_bytes, (int)L, L_cap, order, member, fold, dst, keep, pack, slots, n_main, ablate, reverse, n_aux_blocks, order_next, stats); break;
+        case FF_BF16: launch_mc<FF_BF16>(grid, st, depth, h, o, (uint32_t)row_bytes, (int)L, L_cap, order, member, fold, dst, keep, pack, slots, n_main, ablate, reverse, n_aux_blocks, order_next, stats); break;
+        default: launch_mc<FF_F16>(grid, st, depth, h, o, (uint32_t)row_bytes, (int)L, L_cap, order, member, fold, dst, keep, pack, slots, n_main, ablate, reverse, n_aux_blocks, order_next, stats);
     }
     return (int)hipGetLastError();
 }
@@ -295,6 +330,7 @@ extern "C" int ff_merge_compact(const void* hidden, void* hidden_out, int dtype,
     if (L >= (1ll << 29) || d * esz >= (1ll << 31)) return FF_ERR_UNSUPPORTED;
     if (L == 0) return FF_OK;
     return ff::launch_merge_compact(hidden, hidden_out, dtype, L, d, L_cap, order, member, fold, dst, keep, aux_host, n_aux,
+                                    nullptr, nullptr,
                                     (hipStream_t)stream);
 }
 

@@ -19,6 +19,7 @@
 //                 (<= L bytes, L2-resident) and scans its own 4096 positions into dst[]; the last
 //                 workgroup knows L_out and publishes the result block.
 // Run lengths are not materialised: the merge kernel derives them from 64 member flags at a time.
+#include <stdlib.h>
 #include <string.h>
 
 #include "ff_common.h"
@@ -247,11 +248,9 @@ __device__ inline void slice_range(const PlanParams& pp, int nv, int& lo, int& h
 
 // level `level` histogram of slice blockIdx.x (level 0 also counts values >= thr)
 template <int DT>
-__global__ __launch_bounds__(kSliceThreads) void k_hist_level(
-    const void* __restrict__ values, int cap, PlanParams pp, int level, const int64_t* __restrict__ stats,
-    const int* __restrict__ l0, int* __restrict__ lv, int* __restrict__ l0_out) {
+__device__ inline void hist_level_body(const void* values, int cap, const PlanParams& pp, int level,
+                                       const int64_t* stats, const int* l0, int* lv, int* l0_out, SliceLds& s) {
     using A = Act<DT>;
-    __shared__ SliceLds s;
     const int tid = threadIdx.x, w = wave_id(), cp = lane_id() & 1;
     // every load this workgroup needs is independent of the others: issue them all first
     const int j0 = blockIdx.x * kSlice + tid * kEpt;
@@ -268,7 +267,7 @@ __global__ __launch_bounds__(kSliceThreads) void k_hist_level(
     uint32_t prefix = 0;
     if (level > 0) {
         const Resolved r = resolve(pp, l0col, l0cnt, lvcol, level, ftn, nv, s);
-        if (!r.topk || r.k <= 0) return;
+        if (!r.topk || r.k <= 0) return;          // uniform over the whole grid
         prefix = r.prefix;
         __syncthreads();
     }
@@ -302,18 +301,24 @@ __global__ __launch_bounds__(kSliceThreads) void k_hist_level(
     }
 }
 
+template <int DT>
+__global__ __launch_bounds__(kSliceThreads) void k_hist_level(
+    const void* __restrict__ values, int cap, PlanParams pp, int level, const int64_t* __restrict__ stats,
+    const int* __restrict__ l0, int* __restrict__ lv, int* __restrict__ l0_out) {
+    __shared__ SliceLds s;
+    hist_level_body<DT>(values, cap, pp, level, stats, l0, lv, l0_out, s);
+}
+
 // ---- k_flags ----------------------------------------------------------------------------------------
 // Slice g of the by-patch slots (then the non-visual tail of `order`).  Slot 0 never folds: it has
 // no predecessor (the reference would wrap to order[-1], main.py:290; reachable only when top-k
 // exceeds the number of valid pairs).
 template <int DT>
-__global__ __launch_bounds__(kSliceThreads) void k_flags(
-    const void* __restrict__ values, int cap, PlanParams pp, const int* __restrict__ l0, const int* __restrict__ lv,
-    int64_t* __restrict__ stats, const int32_t* __restrict__ order, int L,
-    uint8_t* __restrict__ member, uint8_t* __restrict__ keep) {
+__device__ inline void flags_body(const void* values, int cap, const PlanParams& pp, const int* l0, const int* lv,
+                                  int64_t* stats, const int32_t* order, int L, uint8_t* member, uint8_t* keep,
+                                  SliceLds& s) {
     using A = Act<DT>;
     constexpr int kLevels = A::kKeyBits / 8;
-    __shared__ SliceLds s;
     const int tid = threadIdx.x;
     // every load is independent of the others: values, row indices, counts and all tables first
     const int j0 = blockIdx.x * kSlice + tid * kEpt;
@@ -417,6 +422,15 @@ __global__ __launch_bounds__(kSliceThreads) void k_flags(
     }
 }
 
+template <int DT>
+__global__ __launch_bounds__(kSliceThreads) void k_flags(
+    const void* __restrict__ values, int cap, PlanParams pp, const int* __restrict__ l0, const int* __restrict__ lv,
+    int64_t* __restrict__ stats, const int32_t* __restrict__ order, int L,
+    uint8_t* __restrict__ member, uint8_t* __restrict__ keep) {
+    __shared__ SliceLds s;
+    flags_body<DT>(values, cap, pp, l0, lv, stats, order, L, member, keep, s);
+}
+
 // Explicit merge set (merge_tokens_and_get_mask, main.py:243-319): member bytes were zeroed, set them.
 __global__ __launch_bounds__(256) void k_mark_index(const int64_t* __restrict__ merge_index, int n_merge,
                                                     const int64_t* __restrict__ stats, uint8_t* __restrict__ member) {
@@ -447,10 +461,8 @@ __device__ inline void publish(const int64_t* __restrict__ stats, int64_t* host_
     if (lane == 0) __hip_atomic_store(&host_mapped[FF_STAT_SEQ], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-__global__ __launch_bounds__(kScanThreads) void k_scan(const uint8_t* __restrict__ keep, int L,
-                                                       int32_t* __restrict__ dst, int64_t* __restrict__ stats,
-                                                       int64_t* host_mapped, int64_t seq, int* __restrict__ zero_me) {
-    __shared__ int scratch[kScanThreads / kWave + 1];
+__device__ inline void scan_body(const uint8_t* keep, int L, int32_t* dst, int64_t* stats, int64_t* host_mapped,
+                                 int64_t seq, int* zero_me, int* scratch) {
     const int tid = threadIdx.x;
     // the level-0 statistics table the NEXT call's similarity kernel will accumulate into
     if (zero_me)
@@ -505,19 +517,78 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const uint8_t* __restrict
     }
 }
 
+__global__ __launch_bounds__(kScanThreads) void k_scan(const uint8_t* __restrict__ keep, int L,
+                                                       int32_t* __restrict__ dst, int64_t* __restrict__ stats,
+                                                       int64_t* host_mapped, int64_t seq, int* __restrict__ zero_me) {
+    __shared__ int scratch[kScanThreads / kWave + 1];
+    scan_body(keep, L, dst, stats, host_mapped, seq, zero_me, scratch);
+}
+
+// ---- fused plan: the radix levels, the flags and the scan in ONE launch ----------------------------------
+// The three stages need the results of ALL workgroups of the previous stage, so they are separated by
+// a grid barrier instead of a kernel boundary: only ceil(L / 4096) workgroups exist (9 at 64 x 576),
+// all co-resident on a 256-CU chip, and a kernel boundary costs a cold start per stage (the two
+// streaming passes flush the instruction lines of these tiny kernels out of L2 every call).
+// Barrier = the counter form of the release/acquire hand-off (cdna_hip_programming.md, G16): stores ->
+// __syncthreads -> lane 0: agent release + vmcnt(0) + relaxed agent add, relaxed poll with s_sleep,
+// agent acquire -> __syncthreads -> plain loads.  The counter is monotonic within a call and the
+// last stage clears the other parity's counter for the next call; a bounded spin turns a lost
+// workgroup into an error word instead of a hang.
+constexpr int kMaxFusedSlices = 64;
+
+__device__ inline void grid_barrier(int* counter, int target, int64_t* stats) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 24)) { stats[FF_STAT_ERROR] = 1; break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+
+template <int DT>
+__global__ __launch_bounds__(kSliceThreads) void k_plan_fused(
+    const void* values, int cap, PlanParams pp, const int* l0, int* lv, int64_t* stats, const int32_t* order, int L,
+    uint8_t* member, uint8_t* keep, int32_t* dst, int64_t* host_mapped, int64_t seq, int* zero_l0,
+    int* bar, int* bar_next) {
+    constexpr int kLevels = Act<DT>::kKeyBits / 8;
+    __shared__ SliceLds s;
+    const int G = (int)gridDim.x;
+    int phase = 0;
+    for (int level = 1; level < kLevels; ++level) {
+        hist_level_body<DT>(values, cap, pp, level, stats, l0, lv, (int*)nullptr, s);
+        grid_barrier(bar, ++phase * G, stats);
+    }
+    flags_body<DT>(values, cap, pp, l0, lv, stats, order, L, member, keep, s);
+    grid_barrier(bar, ++phase * G, stats);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *bar_next = 0;
+    scan_body(keep, L, dst, stats, host_mapped, seq, zero_l0, s.scratch);
+}
+
 // ---- launchers (also used by the fused step in ff_abi.hip) ------------------------------------------
 static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
 
 // Workspace layout (ints): [2][kL0Copies][kRowStride] level-0 tables filled by the similarity kernel
-// (double-buffered by call parity), [G][kRowStride] level-0 rows for the stand-alone entry points,
+// (double-buffered by call parity), 64 ints for the grid-barrier counters, [G][kRowStride] level-0 rows for the stand-alone entry points,
 // [3][G][256] rows of levels 1..3;  G = ceil(L / 4096).
+constexpr int kBarrierInts = 64;
 size_t plan_ws_bytes(int64_t L) {
     const size_t G = (size_t)((L + kSlice - 1) / kSlice) + 1;
-    const size_t b = (2 * (size_t)kL0Copies * kRowStride + G * kRowStride + 3 * G * 256) * sizeof(int) + 256;
+    const size_t b = (2 * (size_t)kL0Copies * kRowStride + kBarrierInts + G * kRowStride + 3 * G * 256) * sizeof(int) + 256;
     return (b + 255) & ~(size_t)255;
 }
+// the two grid-barrier counters sit at a FIXED offset (they persist across calls of any length)
+static int* ws_barrier(void* ws, int64_t seq) {
+    return (int*)ws + 2 * (size_t)kL0Copies * kRowStride + 16 * (seq & 1);
+}
 int* ws_l0_copies(void* ws, int64_t seq) { return (int*)ws + (size_t)(seq & 1) * kL0Copies * kRowStride; }
-static int* ws_l0_rows(void* ws) { return (int*)ws + 2 * (size_t)kL0Copies * kRowStride; }
+static int* ws_l0_rows(void* ws) { return (int*)ws + 2 * (size_t)kL0Copies * kRowStride + kBarrierInts; }
 static int* ws_levels(void* ws, int64_t L) {
     const size_t G = (size_t)((L + kSlice - 1) / kSlice) + 1;
     return ws_l0_rows(ws) + G * kRowStride;
@@ -549,11 +620,21 @@ template <> uint32_t host_thr_key<FF_F16>(double thr) {
     return (b & 0x8000u) ? ((uint32_t)(~b) & 0xffffu) : ((uint32_t)b | 0x8000u);
 }
 
-// values/selection -> member, keep.  l0 == nullptr: level 0 is computed here (k_hist_level(0)).
+struct FusedTail {          // what the fused launch needs to also run the scan stage
+    int32_t* dst;
+    int64_t* host_mapped;
+    int64_t seq;
+    int* zero_l0;
+    int* bar;
+    int* bar_next;
+    bool done;
+};
+
+// values/selection -> member, keep (+ dst when fused).  l0 == nullptr: level 0 is computed here.
 template <int DT>
 static int launch_select_flags(const void* values, PlanParams pp, const int* l0, int64_t cap, int64_t L,
                                const int32_t* order, uint8_t* member, uint8_t* keep, int64_t* stats, void* ws,
-                               hipStream_t st) {
+                               FusedTail* fused, hipStream_t st) {
     constexpr int kLevels = Act<DT>::kKeyBits / 8;
     const unsigned G = cdiv(L, kSlice);
     pp.n_slices = (int)G;
@@ -564,6 +645,14 @@ static int launch_select_flags(const void* values, PlanParams pp, const int* l0,
         hipLaunchKernelGGL(k_hist_level<DT>, dim3(G), dim3(kSliceThreads), 0, st, values, (int)cap, pp, 0, stats,
                            (const int*)nullptr, lv, rows);
         l0 = rows;
+    }
+    if (fused && G <= (unsigned)kMaxFusedSlices) {
+        // radix levels + flags + scan in one launch (grid barriers between the stages)
+        hipLaunchKernelGGL(k_plan_fused<DT>, dim3(G), dim3(kSliceThreads), 0, st, values, (int)cap, pp, l0, lv, stats,
+                           order, (int)L, member, keep, fused->dst, fused->host_mapped, fused->seq, fused->zero_l0,
+                           fused->bar, fused->bar_next);
+        fused->done = true;
+        return (int)hipGetLastError();
     }
     for (int level = 1; level < kLevels; ++level)
         hipLaunchKernelGGL(k_hist_level<DT>, dim3(G), dim3(kSliceThreads), 0, st, values, (int)cap, pp, level, stats, l0, lv,
@@ -582,20 +671,25 @@ int launch_plan_merge(const void* sim, int dtype, const int32_t* order, int64_t 
     pp.mode = 0; pp.lo = 0; pp.hi = -1; pp.k_given = 0; pp.sub = sub; pp.ratio_lb = ratio_lb;
     pp.l0_rows = kL0Copies; pp.n_slices = 0;
     int rc;
+    static int use_fused = -1;
+    if (use_fused < 0) { const char* e = getenv("FF_PLAN_FUSED"); use_fused = e ? atoi(e) : 0; }
+    FusedTail tail{dst, host_mapped, seq, zero_next, ws_barrier(ws, seq), ws_barrier(ws, seq + 1), false};
+    FusedTail* ft = (use_fused && l0_copies) ? &tail : nullptr;     // only with the per-call workspace protocol
     switch (dtype) {
         case FF_F32:
             pp.thr_key = host_thr_key<FF_F32>(thr);
-            rc = launch_select_flags<FF_F32>(sim, pp, l0_copies, L, L, order, member, keep, stats, ws, st);
+            rc = launch_select_flags<FF_F32>(sim, pp, l0_copies, L, L, order, member, keep, stats, ws, ft, st);
             break;
         case FF_BF16:
             pp.thr_key = host_thr_key<FF_BF16>(thr);
-            rc = launch_select_flags<FF_BF16>(sim, pp, l0_copies, L, L, order, member, keep, stats, ws, st);
+            rc = launch_select_flags<FF_BF16>(sim, pp, l0_copies, L, L, order, member, keep, stats, ws, ft, st);
             break;
         default:
             pp.thr_key = host_thr_key<FF_F16>(thr);
-            rc = launch_select_flags<FF_F16>(sim, pp, l0_copies, L, L, order, member, keep, stats, ws, st);
+            rc = launch_select_flags<FF_F16>(sim, pp, l0_copies, L, L, order, member, keep, stats, ws, ft, st);
     }
     if (rc) return rc;
+    if (tail.done) return FF_OK;
     return launch_scan(keep, L, dst, stats, host_mapped, seq, zero_next, st);
 }
 
@@ -607,9 +701,9 @@ int launch_plan_prune(const void* imp, int dtype, int64_t S, int64_t start, int6
     pp.thr_key = 0; pp.l0_rows = 0; pp.n_slices = 0;
     int rc;
     switch (dtype) {
-        case FF_F32: rc = launch_select_flags<FF_F32>(imp, pp, nullptr, S, S, nullptr, member, keep, stats, ws, st); break;
-        case FF_BF16: rc = launch_select_flags<FF_BF16>(imp, pp, nullptr, S, S, nullptr, member, keep, stats, ws, st); break;
-        default: rc = launch_select_flags<FF_F16>(imp, pp, nullptr, S, S, nullptr, member, keep, stats, ws, st);
+        case FF_F32: rc = launch_select_flags<FF_F32>(imp, pp, nullptr, S, S, nullptr, member, keep, stats, ws, nullptr, st); break;
+        case FF_BF16: rc = launch_select_flags<FF_BF16>(imp, pp, nullptr, S, S, nullptr, member, keep, stats, ws, nullptr, st); break;
+        default: rc = launch_select_flags<FF_F16>(imp, pp, nullptr, S, S, nullptr, member, keep, stats, ws, nullptr, st);
     }
     if (rc) return rc;
     return launch_scan(keep, S, dst, stats, host_mapped, seq, nullptr, st);

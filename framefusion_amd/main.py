@@ -55,6 +55,7 @@ class _Scratch:
             cap = max(L, 1024)
             dev = self.device
             self.order = torch.empty(cap, dtype=torch.int32, device=dev)
+            self.order_next = torch.empty(cap, dtype=torch.int32, device=dev)
             self.member = torch.empty(cap, dtype=torch.uint8, device=dev)
             self.dst = torch.empty(cap, dtype=torch.int32, device=dev)
             self.keep = torch.empty(cap, dtype=torch.uint8, device=dev)
@@ -240,7 +241,7 @@ class FrameFusion(nn.Module):
                                  float(thr), float(sub), float(self.ratio_lower_bound),
                                  sc.order.data_ptr(), sim_ptr, sc.member.data_ptr(), sc.dst.data_ptr(),
                                  sc.keep.data_ptr(), sc.stats.data_ptr(), sc.stats_host_ptr, seq,
-                                 aux, n_aux, sc.ws.data_ptr(), sc.ws_bytes, stream)
+                                 aux, n_aux, sc.order_next.data_ptr(), sc.ws.data_ptr(), sc.ws_bytes, stream)
         _lib.check(rc, "ff_merge_finish")
         mask_out = None
         if attention_mask is not None:
@@ -265,9 +266,12 @@ class FrameFusion(nn.Module):
             self.finish_pruning = True
 
         self.patch_type = ptype_out[:, :L_out]                                      # main.py:132
-        sc.order_valid_for = None
+        # order maintenance: the merge kernel also wrote the by-patch order of the compacted
+        # sequence, so the next merge call of this prefill skips K0
         self.last_call = dict(kind="merge", L_in=L, L_out=L_out, nv=nv, ftn=ftn, count=count, branch=branch,
-                              k=int(st[_lib.STAT_K]), scratch=sc, dtype=dtype)
+                              k=int(st[_lib.STAT_K]), scratch=sc, dtype=dtype, order=sc.order)
+        sc.order, sc.order_next = sc.order_next, sc.order
+        sc.order_valid_for = (ptype_out.data_ptr(), L_out)
         hidden_states = out[:, :L_out]
         position_embeddings = rebuild(L_out)
         if mask_out is not None:
@@ -279,7 +283,7 @@ class FrameFusion(nn.Module):
         the next call): keep mask by sequence position, similarities, by-patch order, member flags."""
         c = self.last_call
         sc, L, nv = c["scratch"], c["L_in"], c["nv"]
-        return dict(keep=sc.keep[:L], sim=sc.sim(c["dtype"], nv), order=sc.order[:nv], member=sc.member[:L])
+        return dict(keep=sc.keep[:L], sim=sc.sim(c["dtype"], nv), order=c["order"][:nv], member=sc.member[:L])
 
     # ---- prune call: main.py:61-101 ----------------------------------------------------------------
     def _prune(self, hidden_states, position_embeddings, attention_mask, self_attn_weights):

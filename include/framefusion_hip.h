@@ -55,6 +55,7 @@ enum {
     FF_STAT_KTH_KEY = 8,   /* debug: order-preserving key of the k-th largest similarity          */
     FF_STAT_TIES_TAKEN = 9,/* debug: entries equal to the k-th value that were selected           */
     FF_STAT_SEQ = 10,      /* sequence number, copied from the call (host polling)                */
+    FF_STAT_ERROR = 11,    /* nonzero: a device-side consistency check failed (grid barrier timeout) */
     FF_STAT_T_ORDER = 16,  /* 4 words: shader-clock cycles of K0's phases (diagnostics)           */
     FF_STAT_T_PLAN = 24,   /* 5 words: shader-clock cycles of the plan kernel's passes            */
     FF_STAT_WORDS = 32
@@ -182,7 +183,10 @@ int ff_merge_step(const void* hidden, void* hidden_out, int dtype, int64_t L, in
  * streaming pass runs: begin = K0 (unless order_valid) + K1, finish = K2+K3 + K4.  `ws` must be the
  * SAME zero-initialised workspace for every call of a sequence and `seq` must increase by one per
  * call: the similarity kernel accumulates the select's level-0 statistics into the table of parity
- * (seq & 1) and the scan kernel of the call clears the other table for the next call. */
+ * (seq & 1) and the scan kernel of the call clears the other table for the next call.
+ * order_next (optional, [L] int32): receives the by-patch order of the COMPACTED sequence and
+ * stats[NV]/stats[FTN] are advanced to it, so the next merge call on the reduced sequence can pass
+ * it as `order` with order_valid = 1 and skip K0 (surviving tokens keep their relative order). */
 int ff_merge_begin(const void* hidden, int dtype, int64_t L, int64_t d,
                    const int64_t* patch_type, int64_t patch_num, int order_valid, double threshold,
                    int32_t* order, void* sim, int64_t* stats, int64_t seq, void* ws, size_t ws_bytes,
@@ -191,7 +195,7 @@ int ff_merge_finish(const void* hidden, void* hidden_out, int dtype, int64_t L, 
                     double threshold, double sub, double ratio_lb,
                     const int32_t* order, const void* sim, uint8_t* member, int32_t* dst, uint8_t* keep,
                     int64_t* stats, int64_t* stats_host_mapped, int64_t seq,
-                    const ff_aux_t* aux_host, int n_aux,
+                    const ff_aux_t* aux_host, int n_aux, int32_t* order_next,
                     void* ws, size_t ws_bytes, ff_stream_t stream);
 
 #ifdef __cplusplus

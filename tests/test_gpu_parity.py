@@ -353,6 +353,36 @@ def test_edges_and_errors():
         f(torch.ones(1, 4, 8), torch.arange(4)[None], None)
 
 
+def test_order_maintenance():
+    """The merge kernel hands the next call the by-patch order of the compacted sequence (K0 is then
+    skipped): it must equal what K0 computes from the new patch_type, call after call."""
+    h, pt = video_tokens(20, 37, 256, p_change=0.6, sigma=0.3, sigma_hi=1.6, seed=4, pre=6, post=9, grid=0.125)
+    L = h.shape[1]
+    f = ffa.FrameFusion(0.3, 0.6, 0.01)
+    f.prepare(dev(pt), 37, 6, 6 + 20 * 37, 20 * 37, L)
+    o = orc.OracleFrameFusion(0.3, 0.6, 0.01)
+    o.prepare(pt.clone(), 37, 6, 6 + 20 * 37, 20 * 37, L)
+    hg, pg = dev(h), dev(torch.arange(L)[None])
+    ho, po = h, torch.arange(L)[None]
+    merges = 0
+    for layer in range(4):
+        if f.finish_merging:
+            break
+        hg, pg, _ = f(hg, pg, None)
+        ho, po, _ = o.forward(ho, po, None)
+        merges += 1
+        assert torch.equal(pg.cpu(), po) and same_bits(hg.cpu(), ho)
+        sc = f.last_call["scratch"]
+        n = hg.shape[1]
+        assert sc.order_valid_for == (f.patch_type.data_ptr(), n)
+        fresh, stats = hip_order(f.patch_type.cpu(), 37)
+        assert torch.equal(sc.order[:n].cpu().long(), fresh)
+        assert int(sc.stats[_lib.STAT_NV]) == int(stats[_lib.STAT_NV])
+        assert int(sc.stats[_lib.STAT_FTN]) == int(stats[_lib.STAT_FTN])
+        hg, ho = harness.layer_stub(hg, layer), harness.layer_stub(ho, layer)
+    assert merges >= 2          # at least one call ran on a maintained order
+
+
 def test_determinism():
     h, pt = video_tokens(16, 48, 1024, p_change=0.3, sigma_hi=1.5, seed=9, pre=5, post=5)
     outs = []

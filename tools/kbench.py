@@ -47,6 +47,7 @@ def main():
 
     lib = _lib.load()
     sc = ff._scratch[(dev.type, dev.index)]
+    order_buf = info["order"]
     stream = _lib.stream_ptr()
     code = _lib.DTYPE_CODE[dtype]
     elt = hidden.element_size()
@@ -61,14 +62,14 @@ def main():
     thr = float(torch.tensor(0.6, dtype=dtype))
     sub = float(ff._compute_pruning_ratio([], 0.3))
     stages = {
-        "order": (lambda: lib.ff_build_order(ptype.data_ptr(), L, P, sc.order.data_ptr(), sc.stats.data_ptr(), sc.ws.data_ptr(), sc.ws_bytes, stream),
+        "order": (lambda: lib.ff_build_order(ptype.data_ptr(), L, P, order_buf.data_ptr(), sc.stats.data_ptr(), sc.ws.data_ptr(), sc.ws_bytes, stream),
                   8 * L + 4 * L),
-        "similarity": (lambda: lib.ff_pair_similarity(hidden.data_ptr(), code, L, d, ptype.data_ptr(), sc.order.data_ptr(),
+        "similarity": (lambda: lib.ff_pair_similarity(hidden.data_ptr(), code, L, d, ptype.data_ptr(), order_buf.data_ptr(),
                                                       sc.stats.data_ptr(), sim.data_ptr(), stream), nv * d * elt),
-        "plan": (lambda: lib.ff_plan_merge(sim.data_ptr(), code, sc.order.data_ptr(), L, thr, sub, 0.1, sc.member.data_ptr(),
+        "plan": (lambda: lib.ff_plan_merge(sim.data_ptr(), code, order_buf.data_ptr(), L, thr, sub, 0.1, sc.member.data_ptr(),
                                            sc.dst.data_ptr(), sc.keep.data_ptr(), sc.stats.data_ptr(), sc.ws.data_ptr(),
                                            sc.ws_bytes, stream), nv * elt + 4 * L * 3),
-        "merge_compact": (lambda: lib.ff_merge_compact(hidden.data_ptr(), out_buf.data_ptr(), code, L, d, L, sc.order.data_ptr(),
+        "merge_compact": (lambda: lib.ff_merge_compact(hidden.data_ptr(), out_buf.data_ptr(), code, L, d, L, order_buf.data_ptr(),
                                                        sc.member.data_ptr(), 1, sc.dst.data_ptr(), sc.keep.data_ptr(), aux, 3, stream),
                           (L + L_out) * d * elt + 2 * (L + L_out) * 128 * elt),
     }
