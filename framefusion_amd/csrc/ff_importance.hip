@@ -4,9 +4,9 @@
 // feeding the prune of main.py:69-92.
 //
 // The reference repeats K to all H heads first (repeat_kv, modeling_qwen2.py:147) and materialises
-// a [1, H, num, S] tensor; here one workgroup reads a 64-key tile of ONE kv head once and scores it
-// against every query head of the GQA group, so K traffic is H_kv*S*dh*sizeof(T) (11 MB at
-// S = 11k, H_kv = 4, dh = 128), negligible next to the activation passes.
+// a [1, H, num, S] tensor; here a key row of ONE kv head is scored against the query heads of its
+// GQA group, so K traffic is ~H_kv*S*dh*sizeof(T) (11 MB at S = 11k, H_kv = 4, dh = 128),
+// negligible next to the activation passes.
 //
 // Staged rounding, T = activation dtype:
 //   s = T(sum_fp32 q_i*k_i);  s = T(fp32(s) * fp32(scale));  s = T(s + bias);  p = T(exp(s - max) / sum)
@@ -14,41 +14,56 @@
 
 namespace ff {
 
-// scores[h, n, s] as float holding T values.  grid: (ceil(S/64), H_kv); block 256 = 4 waves, each
-// wave takes 16 keys of the tile, a key row is spread over the 64 lanes.
+// scores[h, n, s] as float holding T values.  grid: (ceil(S/256), H_kv, row groups); one LANE per
+// key: the lane streams its own key row (dh * sizeof(T) bytes, 16 B at a time) and dots it with up
+// to kRowsPerBlock query rows of the GQA group that sit in LDS as fp32 (wave-uniform broadcast
+// reads) - no cross-lane reduction, stores coalesced over s.
+constexpr int kRowsPerBlock = 8;
+
 template <int DT>
 __global__ __launch_bounds__(256) void k_lq_scores(const void* __restrict__ q, const void* __restrict__ k,
                                                    int H, int H_kv, int num, int S, int dh, float scale,
                                                    int causal, float* __restrict__ scores) {
     using A = Act<DT>;
-    extern __shared__ __attribute__((aligned(16))) float q_lds[];   // [group*num][dh]
+    constexpr int E = A::kPer16;
+    extern __shared__ __attribute__((aligned(16))) float q_lds[];   // [rows_here][dh]
     const int hk = blockIdx.y;
     const int group = H / H_kv;
     const int rows = group * num;
-    for (int x = threadIdx.x; x < rows * dh; x += blockDim.x) {
-        const int r = x / dh, e = x - r * dh;
+    const int r0 = blockIdx.z * kRowsPerBlock;
+    const int rows_here = min(kRowsPerBlock, rows - r0);
+    for (int x = threadIdx.x; x < rows_here * dh; x += blockDim.x) {
+        const int r = r0 + x / dh, e = x % dh;
         const int h = hk * group + r / num, n = r % num;
         q_lds[x] = A::load1(q, ((int64_t)h * num + n) * dh + e);
     }
     __syncthreads();
-    const int lane = lane_id(), w = wave_id();
-    const int s_base = blockIdx.x * 64 + w * 16;
-    for (int ks = 0; ks < 16; ++ks) {
-        const int s = s_base + ks;
-        if (s >= S) break;
-        const int64_t krow = ((int64_t)hk * S + s) * dh;
-        for (int r = 0; r < rows; ++r) {
-            float acc = 0.f;
-            for (int e = lane; e < dh; e += kWave)
-                acc = __builtin_fmaf(q_lds[r * dh + e], A::load1(k, krow + e), acc);
-            acc = wave_sum(acc);
-            if (lane == 0) {
-                const int h = hk * group + r / num, n = r % num;
-                float v = A::rnd(acc);
-                v = A::rnd(v * scale);
-                if (causal && s > S - num + n) v = A::rnd(v + (-INFINITY));
-                scores[((int64_t)h * num + n) * S + s] = v;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const char* krow = (const char*)k + ((int64_t)hk * S + s) * dh * A::kBytes;
+    float acc[kRowsPerBlock];
+#pragma unroll
+    for (int r = 0; r < kRowsPerBlock; ++r) acc[r] = 0.f;
+    for (int c = 0; c < dh; c += E) {                 // dh % E == 0 (checked by the launcher)
+        float kv[E];
+        A::unpack(*(const uint4*)(krow + (size_t)c * A::kBytes), kv);
+#pragma unroll
+        for (int r = 0; r < kRowsPerBlock; ++r) {
+            if (r < rows_here) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) acc[r] = __builtin_fmaf(q_lds[r * dh + c + e], kv[e], acc[r]);
             }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < kRowsPerBlock; ++r) {
+        if (r < rows_here) {
+            const int rr = r0 + r;
+            const int h = hk * group + rr / num, n = rr % num;
+            float v = A::rnd(acc[r]);
+            v = A::rnd(v * scale);
+            if (causal && s > S - num + n) v = A::rnd(v + (-INFINITY));
+            scores[((int64_t)h * num + n) * S + s] = v;
         }
     }
 }
@@ -97,9 +112,12 @@ static int launch_lq(const void* q, const void* k, int64_t H, int64_t H_kv, int6
                      double scale, int causal, void* weights, void* importance, void* ws, hipStream_t st) {
     float* scores = (float*)ws;
     float* probs = scores + H * num * S;
-    const size_t lds = (size_t)(H / H_kv) * num * dh * sizeof(float);
-    hipLaunchKernelGGL(k_lq_scores<DT>, dim3((unsigned)((S + 63) / 64), (unsigned)H_kv), dim3(256), lds, st, q, k,
-                       (int)H, (int)H_kv, (int)num, (int)S, (int)dh, (float)scale, causal, scores);
+    const int rows = (int)((H / H_kv) * num);
+    const size_t lds = (size_t)kRowsPerBlock * dh * sizeof(float);
+    hipLaunchKernelGGL(k_lq_scores<DT>, dim3((unsigned)((S + 255) / 256), (unsigned)H_kv,
+                                             (unsigned)((rows + kRowsPerBlock - 1) / kRowsPerBlock)),
+                       dim3(256), lds, st, q, k, (int)H, (int)H_kv, (int)num, (int)S, (int)dh, (float)scale, causal,
+                       scores);
     hipLaunchKernelGGL(k_lq_softmax<DT>, dim3((unsigned)(H * num)), dim3(256), 0, st, scores, (int)S, probs, weights);
     if (importance)
         hipLaunchKernelGGL(k_lq_mean<DT>, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, probs, (int)(H * num),
@@ -117,7 +135,9 @@ extern "C" int ff_last_query_attention(const void* q_last, const void* k, int dt
     if (H % H_kv) return FF_ERR_ARG;
     if (!weights && !importance) return FF_ERR_ARG;
     if (S >= (1ll << 31) || H * num * S >= (1ll << 40)) return FF_ERR_UNSUPPORTED;
-    if ((size_t)(H / H_kv) * num * dh * sizeof(float) > 64 * 1024) return FF_ERR_UNSUPPORTED;
+    if ((size_t)ff::kRowsPerBlock * dh * sizeof(float) > 64 * 1024) return FF_ERR_UNSUPPORTED;
+    const int64_t esz = dtype == FF_F32 ? 4 : 2;
+    if (((dh * esz) & 15) || ((uintptr_t)k & 15)) return FF_ERR_ALIGN;
     if (ws_bytes < (size_t)(2 * H * num * S) * sizeof(float)) return FF_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     switch (dtype) {

@@ -67,6 +67,7 @@ class _Scratch:
             self.stats_host_ptr = self.stats_host.data_ptr()     # device-visible (pinned, UVA)
             self.stats_np = self.stats_host.numpy()              # shares the pinned memory
             self.seq = 0
+            self.dirty = False          # a call died between begin and finish: the select tables need a reset
             self.cap = cap
             self.order_valid_for = None
         return self
@@ -223,8 +224,12 @@ class FrameFusion(nn.Module):
         # first half (K0 + K1) goes out before any output tensor exists: the allocations below
         # overlap the similarity pass
         thr = self._threshold_for(dtype)
+        if sc.dirty:                 # restore the workspace protocol (zeroed tables, fresh parity)
+            sc.ws.zero_()
+            sc.dirty = False
         sc.seq += 1
         seq = sc.seq
+        sc.dirty = True              # cleared once ff_merge_finish has been enqueued
         rc = lib.ff_merge_begin(hidden.data_ptr(), code, L, d, ptype.data_ptr(), int(self.patch_num), order_valid,
                                 thr, sc.order.data_ptr(), sim_ptr, sc.stats.data_ptr(), seq, sc.ws.data_ptr(),
                                 sc.ws_bytes, stream)
@@ -243,6 +248,7 @@ class FrameFusion(nn.Module):
                                  sc.keep.data_ptr(), sc.stats.data_ptr(), sc.stats_host_ptr, seq,
                                  aux, n_aux, sc.order_next.data_ptr(), sc.ws.data_ptr(), sc.ws_bytes, stream)
         _lib.check(rc, "ff_merge_finish")
+        sc.dirty = False
         mask_out = None
         if attention_mask is not None:
             mask_out = self._gather_mask(attention_mask, L, L_cap, sc.dst, stream)

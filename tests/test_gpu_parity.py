@@ -383,6 +383,24 @@ def test_order_maintenance():
     assert merges >= 2          # at least one call ran on a maintained order
 
 
+def test_recovery_after_a_failed_call():
+    """A call that dies between the two halves of the step (bad position container) must not poison
+    the next one: the select tables accumulated by its similarity pass are reset."""
+    h, pt = video_tokens(10, 20, 128, p_change=0.2, seed=8, pre=2, post=3, grid=0.125)
+    L = h.shape[1]
+    f = ffa.FrameFusion(0.3, 0.6, 0.1)
+    o = orc.OracleFrameFusion(0.3, 0.6, 0.1)
+    o.prepare(pt.clone(), 20, 2, 202, 200, L)
+    ho, po, _ = o.forward(h, torch.arange(L)[None], None)
+    for attempt in range(3):
+        f.prepare(dev(pt), 20, 2, 202, 200, L)
+        with pytest.raises(NotImplementedError):
+            f(dev(h), torch.zeros(1, L, 2, device=DEV), None)          # 3-D tensor container: rejected
+        f.prepare(dev(pt), 20, 2, 202, 200, L)
+        hg, pg, _ = f(dev(h), dev(torch.arange(L)[None]), None)
+        assert torch.equal(pg.cpu(), po) and same_bits(hg.cpu(), ho), attempt
+
+
 def test_determinism():
     h, pt = video_tokens(16, 48, 1024, p_change=0.3, sigma_hi=1.5, seed=9, pre=5, post=5)
     outs = []
