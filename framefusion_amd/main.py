@@ -198,6 +198,12 @@ class FrameFusion(nn.Module):
 
     # ---- merge call: main.py:104-138 -------------------------------------------------------------
     def _merge(self, hidden_states, position_embeddings, attention_mask):
+        return self._merge_complete(self._merge_launch(hidden_states, position_embeddings, attention_mask))
+
+    def _merge_launch(self, hidden_states, position_embeddings, attention_mask):
+        """Enqueue the whole merge call on the current stream and return without waiting: the
+        state machine is advanced by _merge_complete.  (batch.forward_many launches several
+        samples on their own streams before completing any of them.)"""
         _lib.require_gpu(hidden_states, "FrameFusion.forward")
         lib = _lib.load()
         bsz, L, d = hidden_states.size()
@@ -253,6 +259,13 @@ class FrameFusion(nn.Module):
         if attention_mask is not None:
             mask_out = self._gather_mask(attention_mask, L, L_cap, sc.dst, stream)
 
+        return dict(sc=sc, seq=seq, L=L, dtype=dtype, out=out, ptype_out=ptype_out, rebuild=rebuild,
+                    mask_out=mask_out)
+
+    def _merge_complete(self, pending):
+        sc, seq, L, dtype = pending["sc"], pending["seq"], pending["L"], pending["dtype"]
+        out, ptype_out, rebuild, mask_out = pending["out"], pending["ptype_out"], pending["rebuild"], pending["mask_out"]
+        attention_mask = None
         # The one device->host hand-off of the call: the scan kernel stores the result block into
         # pinned host memory (sequence word last) BEFORE the merge kernel runs, so the host learns
         # L_out while the second streaming pass is still in flight and returns without waiting for it.
