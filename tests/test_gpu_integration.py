@@ -77,3 +77,43 @@ def test_tiny_decoder_prefill_with_shadow_oracle(dtype, p_change):
     # decode step: q_len == 1 is a no-op
     tok = torch.zeros(1, 1, d, dtype=dtype, device=DEV)
     assert ff(tok, "pos", None)[0] is tok
+
+
+def test_hf_qwen2_prefill_and_decode():
+    """The installed transformers' Qwen2ForCausalLM (random weights) patched with apply_framefusion:
+    prefill shrinks the sequence layer by layer, per-layer KV lengths follow, decode is untouched."""
+    from transformers import Qwen2Config, Qwen2ForCausalLM
+    from transformers.cache_utils import DynamicCache
+    from framefusion_amd.models.qwen2 import register_hf_qwen2
+    torch.manual_seed(0)
+    cfg = Qwen2Config(vocab_size=128, hidden_size=256, intermediate_size=512, num_hidden_layers=4,
+                      num_attention_heads=8, num_key_value_heads=2, max_position_embeddings=4096)
+    cfg._attn_implementation = "sdpa"
+    model = Qwen2ForCausalLM(cfg).to(DEV).to(torch.bfloat16).eval()
+    register_hf_qwen2()
+    ffa.apply_framefusion(model, cost=0.3, similarity_lower_bound=0.6, ratio_lower_bound=0.1)
+    ff = model.framefusion
+    shadow = Shadow(ff)
+    ff.forward = shadow
+    F_, P, pre, post = 12, 24, 5, 7
+    emb, pt = video_tokens(F_, P, 256, p_change=0.5, sigma=0.3, sigma_hi=1.2, seed=11, pre=pre, post=post)
+    L = emb.shape[1]
+    ff.prepare(pt.to(DEV), P, pre, pre + F_ * P, F_ * P, L)
+    cache = DynamicCache(config=cfg)
+    with torch.no_grad():
+        out = model.model(inputs_embeds=emb.to(DEV), past_key_values=cache, use_cache=True)
+    lengths = model.model.framefusion_lengths
+    assert out.last_hidden_state.shape[1] == lengths[-1] < L
+    assert lengths == sorted(lengths, reverse=True) and ff.finish_merging and ff.finish_pruning
+    kv = [cache.layers[i].keys.shape[2] for i in range(4)]
+    assert kv[0] <= L and kv == sorted(kv, reverse=True) and kv[-1] >= lengths[-1]   # per-layer KV lengths differ
+    assert [r["kind"] for r in shadow.log].count("prune") == 1
+    for r in shadow.log:
+        assert r["flags"] and r["sym"] <= 2, r
+    # decode step: one new token, FrameFusion is a no-op, the cache keeps its per-layer lengths + 1
+    with torch.no_grad():
+        step = model.model(inputs_embeds=torch.zeros(1, 1, 256, dtype=torch.bfloat16, device=DEV),
+                           past_key_values=cache, use_cache=True,
+                           position_ids=torch.tensor([[L]], device=DEV))
+    assert step.last_hidden_state.shape[1] == 1
+    assert [cache.layers[i].keys.shape[2] for i in range(4)] == [n + 1 for n in kv]
