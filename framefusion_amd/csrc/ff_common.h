@@ -20,13 +20,16 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
+// kAux: cache policy bits of the buffer instruction (2 = nt: streamed once, do not keep it cached)
+template <int kAux = 0>
 __device__ inline uint4 buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t voffset) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voffset, 0, 0);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voffset, 0, kAux);
     return make_uint4(v.x, v.y, v.z, v.w);
 }
+template <int kAux = 0>
 __device__ inline void buf_store16(__amdgpu_buffer_rsrc_t r, uint32_t voffset, const uint4& x) {
     u32x4 v; v.x = x.x; v.y = x.y; v.z = x.z; v.w = x.w;
-    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voffset, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voffset, 0, kAux);
 }
 __device__ inline int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 

@@ -71,7 +71,7 @@ struct Batch {
     bool last;
 };
 
-template <int DT, int kDepth>
+template <int DT, int kDepth, int kNt>
 __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
     const char* __restrict__ hidden, char* __restrict__ out, uint32_t row_bytes, int L, int64_t L_cap,
     const int32_t* __restrict__ order, const uint8_t* __restrict__ member, int fold,
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
 #pragma unroll
         for (int u = 0; u < kDepth; ++u) {
             const bool is_mem = (mem_bits >> u) & 1u;
-            if (u < take && (fold || !is_mem)) b.buf[u] = buf_load16(piece(b.idx[u]), voff);
+            if (u < take && (fold || !is_mem)) b.buf[u] = buf_load16<(kNt & 2) ? 2 : 0>(piece(b.idx[u]), voff);
         }
     };
 
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
 #pragma unroll
             for (int e = 0; e < E; ++e) o[e] = acc[e];
         }
-        if (!(ablate & 1)) buf_store16(make_rsrc(out + (int64_t)open_r * row_bytes + col, blk_bytes), voff, A::pack(o));
+        if (!(ablate & 1)) buf_store16<(kNt & 1) ? 2 : 0>(make_rsrc(out + (int64_t)open_r * row_bytes + col, blk_bytes), voff, A::pack(o));
         else if (o[0] == 1.2345f) buf_store16(make_rsrc(out, 16), 0, A::pack(o));
     };
     auto fold_batch = [&](Batch<kDepth>& b) {
@@ -266,12 +266,19 @@ static void launch_mc(dim3 grid, hipStream_t st, int depth, const char* h, char*
                       int64_t L_cap, const int32_t* order, const uint8_t* member, int fold, const int32_t* dst,
                       const uint8_t* keep, const AuxPack& pack, int slots, int n_main, int ablate, int reverse,
                       int n_aux_blocks, int32_t* order_next, int64_t* stats) {
-    if (depth == 4)
-        hipLaunchKernelGGL((k_merge_compact<DT, 4>), grid, dim3(kMergeThreads), 0, st, h, o, row_bytes, L, L_cap, order,
-                           member, fold, dst, keep, pack, slots, n_main, ablate, reverse, n_aux_blocks, order_next, stats);
-    else
-        hipLaunchKernelGGL((k_merge_compact<DT, 8>), grid, dim3(kMergeThreads), 0, st, h, o, row_bytes, L, L_cap, order,
-                           member, fold, dst, keep, pack, slots, n_main, ablate, reverse, n_aux_blocks, order_next, stats);
+    static int nt = -1;
+    if (nt < 0) { const char* e = getenv("FF_MERGE_NT"); nt = e ? atoi(e) : 3; }
+#define FF_MC_LAUNCH(DEPTH, NT)                                                                                    \
+    hipLaunchKernelGGL((k_merge_compact<DT, DEPTH, NT>), grid, dim3(kMergeThreads), 0, st, h, o, row_bytes, L, L_cap, \
+                       order, member, fold, dst, keep, pack, slots, n_main, ablate, reverse, n_aux_blocks, order_next, stats)
+    if (depth == 8) { FF_MC_LAUNCH(8, 0); return; }
+    switch (nt) {
+        case 1: FF_MC_LAUNCH(4, 1); break;
+        case 2: FF_MC_LAUNCH(4, 2); break;
+        case 3: FF_MC_LAUNCH(4, 3); break;
+        default: FF_MC_LAUNCH(4, 0);
+    }
+#undef FF_MC_LAUNCH
 }
 
 int launch_merge_compact(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
