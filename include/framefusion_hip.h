@@ -56,8 +56,8 @@ enum {
     FF_STAT_TIES_TAKEN = 9,/* debug: entries equal to the k-th value that were selected           */
     FF_STAT_SEQ = 10,      /* sequence number, copied from the call (host polling)                */
     FF_STAT_ERROR = 11,    /* nonzero: a device-side consistency check failed (grid barrier timeout) */
-    FF_STAT_T_ORDER = 16,  /* 4 words: shader-clock cycles of K0's phases (diagnostics)           */
-    FF_STAT_T_PLAN = 24,   /* 5 words: shader-clock cycles of the plan kernel's passes            */
+    FF_STAT_T_ORDER = 16,  /* 2 words: shader-clock cycles of K0's second launch (diagnostics)    */
+    FF_STAT_T_PLAN = 24,   /* reserved for plan-kernel diagnostics                                */
     FF_STAT_WORDS = 32
 };
 
@@ -74,7 +74,9 @@ size_t ff_workspace_bytes(int64_t L, int64_t patch_num);
  * order[0 .. Nv)  = sequence index of the visual tokens, stable-sorted by patch type;
  * order[Nv .. L)  = the remaining (text / out-of-range) positions in sequence order, so that
  *                   `order` is a permutation of 0..L-1 that later stages can walk uniformly.
- * stats[FF_STAT_NV], stats[FF_STAT_FTN] are written.  patch_num <= 32768. */
+ * stats[FF_STAT_NV], stats[FF_STAT_FTN] are written.  patch_num <= 32768; patch_type, order and ws
+ * 16-byte aligned, ws >= ff_workspace_bytes(L, patch_num) (two launches: per-slice facts, then the
+ * closed form of the frame-major layout on every workgroup or the counting sort on one). */
 int ff_build_order(const int64_t* patch_type, int64_t L, int64_t patch_num,
                    int32_t* order, int64_t* stats, void* ws, size_t ws_bytes, ff_stream_t stream);
 
@@ -170,7 +172,8 @@ int ff_last_query_attention(const void* q_last, const void* k, int dtype, int64_
  * One FrameFusion.forward merge call (main.py:104-138): K0 (skipped when order_valid != 0) ->
  * K1 -> K2+K3 -> K4, all enqueued by one host call.  `stats_host_mapped` (may be NULL) is a
  * device-visible pinned host pointer that receives a copy of the stats block, its FF_STAT_SEQ
- * word written last with `seq`, so the host can poll instead of synchronising the stream. */
+ * word written last with `seq`, so the host can poll instead of synchronising the stream.
+ * Workspace protocol as for ff_merge_begin / ff_merge_finish below. */
 int ff_merge_step(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
                   const int64_t* patch_type, int64_t patch_num, int order_valid,
                   double threshold, double sub, double ratio_lb,
