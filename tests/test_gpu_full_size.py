@@ -131,3 +131,42 @@ def test_c5_72b_shape_fused_importance_and_prune():
     assert hg3.shape == hg2.shape
     same = float((pg3.cpu() == po2).float().mean())
     assert same >= 0.99          # ranking from HIP-computed weights: only ulp-level ties may differ
+
+
+def test_128_frames_cascade_and_large_ragged_order():
+    """128 frames x 576 tokens (73 762 positions, the longest configuration of BASELINE.json): a
+    two-merge cascade against the oracle, and the general (counting-sort) order kernel on the ragged
+    patch_type that the first merge leaves behind."""
+    from framefusion_amd import _lib
+    F, P, d, pre, post = 128, 576, 1024, 14, 20
+    h, pt = video_tokens(F, P, d, p_change=0.55, sigma=0.3, sigma_hi=1.6, seed=9, pre=pre, post=post, grid=0.125)
+    L = h.shape[1]
+    o = orc.OracleFrameFusion(0.3, 0.6, 0.01)
+    o.prepare(pt.clone(), P, pre, pre + F * P, F * P, L)
+    f = ffa.FrameFusion(0.3, 0.6, 0.01)
+    f.prepare(pt.to(DEV), P, pre, pre + F * P, F * P, L)
+    ho, po = h, torch.arange(L)[None]
+    hg, pg = h.to(DEV), torch.arange(L, device=DEV)[None]
+    for call in range(2):
+        ho, po, _ = o.forward(ho, po, None)
+        hg, pg, _ = f(hg, pg, None)
+        assert torch.equal(pg.cpu(), po), call
+        assert same_bits(hg.cpu(), ho), call
+        assert (f.finish_merging, f.finish_pruning, f.sparsity_list) == (o.finish_merging, o.finish_pruning, o.sparsity_list)
+        if call == 0:
+            assert not f.finish_merging                      # the second call runs on the maintained order
+            # the general order kernel on this ragged layout == the maintained order == the oracle's
+            lib = _lib.load()
+            n = hg.shape[1]
+            order = torch.empty(n, dtype=torch.int32, device=DEV)
+            stats = torch.zeros(_lib.STAT_WORDS, dtype=torch.int64, device=DEV)
+            wsb = int(lib.ff_workspace_bytes(n, P))
+            ws = torch.zeros(wsb, dtype=torch.uint8, device=DEV)
+            _lib.check(lib.ff_build_order(f.patch_type.data_ptr(), n, P, order.data_ptr(), stats.data_ptr(),
+                                          ws.data_ptr(), wsb, _lib.stream_ptr()), "ff_build_order")
+            want, _ = orc.by_patch_order(o.patch_type, P)
+            nv = want.numel()
+            assert int(stats[_lib.STAT_NV]) == nv
+            assert torch.equal(order[:nv].cpu().long(), want)
+            assert torch.equal(f.last_call["scratch"].order[:nv].cpu().long(), want)
+        ho, hg = harness.layer_stub(ho, call), harness.layer_stub(hg, call)
