@@ -57,6 +57,8 @@ PROTOTYPES = {
     "ff_merge_begin": (_i32, [_vp, _i32, _i64, _i64, _vp, _i64, _i32, _f64, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
     "ff_merge_finish": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                _i64, C.POINTER(FFAux), _i32, _vp, _vp, _sz, _vp]),
+    "ff_prune_step": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp,
+                             _vp, C.POINTER(FFAux), _i32, _vp, _sz, _vp]),
     "ff_merge_step": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _i64, _i32, _f64, _f64, _f64, _vp, _vp, _vp,
                              _vp, _vp, _vp, _vp, _i64, C.POINTER(FFAux), _i32, _vp, _sz, _vp]),
 }

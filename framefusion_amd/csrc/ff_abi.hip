@@ -92,3 +92,20 @@ extern "C" int ff_merge_step(const void* hidden, void* hidden_out, int dtype, in
     return ff_merge_finish(hidden, hidden_out, dtype, L, d, L_cap, threshold, sub, ratio_lb, order, sim, member, dst,
                            keep, stats, stats_host_mapped, seq, aux_host, n_aux, nullptr, ws, ws_bytes, stream);
 }
+
+extern "C" int ff_prune_step(const void* hidden, void* hidden_out, int dtype, int64_t S, int64_t d, int64_t L_cap,
+                             const void* attn_w, int64_t H, int64_t num, void* importance, int64_t start,
+                             int64_t n_img, int64_t k, uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
+                             const ff_aux_t* aux_host, int n_aux, void* ws, size_t ws_bytes, ff_stream_t stream) {
+    if (!attn_w || !importance) return FF_ERR_ARG;
+    const void* imp = attn_w;
+    if (H * num != 1) {
+        int rc = ff_head_mean(attn_w, dtype, H, num, S, importance, stream);
+        if (rc) return rc;
+        imp = importance;
+    }
+    int rc = ff_plan_prune(imp, dtype, S, start, n_img, k, member, dst, keep, stats, ws, ws_bytes, stream);
+    if (rc) return rc;
+    return ff_merge_compact(hidden, hidden_out, dtype, S, d, L_cap, nullptr, member, 0, dst, keep, aux_host, n_aux,
+                            stream);
+}

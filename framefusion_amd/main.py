@@ -328,26 +328,31 @@ class FrameFusion(nn.Module):
         if w.dtype != dtype:
             w = w.to(dtype)
         w = w.contiguous()
+        if w.data_ptr() & 15:
+            w = w.clone()
         imp = sc.sim(dtype, q_len)
-        _lib.check(lib.ff_head_mean(w.data_ptr(), code, w.shape[1], w.shape[2], q_len, imp.data_ptr(), stream),
-                   "ff_head_mean")
-
         pruning_ratio = self._compute_pruning_ratio(self.sparsity_list, self.cost)  # main.py:73
         k = round(n_img * (1 - pruning_ratio))                                      # main.py:76
         if k < 0 or k > n_img:
             raise RuntimeError("selected index k out of range")                     # torch.topk's error
         L_out = q_len - n_img + k
-        _lib.check(lib.ff_plan_prune(imp.data_ptr(), code, q_len, start, n_img, k, sc.member.data_ptr(),
-                                     sc.dst.data_ptr(), sc.keep.data_ptr(), sc.stats.data_ptr(),
-                                     sc.ws.data_ptr(), sc.ws_bytes, stream), "ff_plan_prune")
+        # the index kernels go out first (head mean, main.py:69-70, + top-k plan): they need no output
+        # tensor, so the allocations below overlap them; nothing is read back (L_out is known)
+        imp_ptr = w.data_ptr()
+        if w.shape[1] * w.shape[2] != 1:
+            _lib.check(lib.ff_head_mean(w.data_ptr(), code, w.shape[1], w.shape[2], q_len, imp.data_ptr(), stream),
+                       "ff_head_mean")
+            imp_ptr = imp.data_ptr()
+        _lib.check(lib.ff_plan_prune(imp_ptr, code, q_len, start, n_img, k, sc.member.data_ptr(), sc.dst.data_ptr(),
+                                     sc.keep.data_ptr(), sc.stats.data_ptr(), sc.ws.data_ptr(), sc.ws_bytes, stream),
+                   "ff_plan_prune")
         out = torch.empty(1, L_out, d, dtype=dtype, device=device)
         srcs, outs, rebuild = self._aux_for_positions(position_embeddings, q_len, L_out)
         aux = (FFAux * _lib.MAX_AUX)()
         n_aux = self._fill_aux(aux, 0, srcs, outs, q_len)
         _lib.check(lib.ff_merge_compact(hidden.data_ptr(), out.data_ptr(), code, q_len, d, L_out, None,
                                         sc.member.data_ptr(), 0, sc.dst.data_ptr(), sc.keep.data_ptr(), aux, n_aux,
-                                        stream),
-                   "ff_merge_compact")
+                                        stream), "ff_merge_compact")
         if attention_mask is not None:
             attention_mask = self._gather_mask(attention_mask, q_len, L_out, sc.dst, stream)
         self.finish_pruning = True                                                  # main.py:101

@@ -201,6 +201,16 @@ int ff_merge_finish(const void* hidden, void* hidden_out, int dtype, int64_t L, 
                     const ff_aux_t* aux_host, int n_aux, int32_t* order_next,
                     void* ws, size_t ws_bytes, ff_stream_t stream);
 
+/* One FrameFusion.forward prune call (main.py:61-101) from a single host call: head mean of the
+ * attention weights (skipped when H*num == 1: the weights are then already the importance),
+ * ff_plan_prune, ff_merge_compact(order = NULL, fold = 0).  The output length
+ * S - n_img + k is known to the host, so nothing is read back. */
+int ff_prune_step(const void* hidden, void* hidden_out, int dtype, int64_t S, int64_t d, int64_t L_cap,
+                  const void* attn_w, int64_t H, int64_t num, void* importance,
+                  int64_t start, int64_t n_img, int64_t k,
+                  uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
+                  const ff_aux_t* aux_host, int n_aux, void* ws, size_t ws_bytes, ff_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
