@@ -117,3 +117,39 @@ def test_hf_qwen2_prefill_and_decode():
                            position_ids=torch.tensor([[L]], device=DEV))
     assert step.last_hidden_state.shape[1] == 1
     assert [cache.layers[i].keys.shape[2] for i in range(4)] == [n + 1 for n in kv]
+
+
+def test_hf_qwen2_vl_text_prefill():
+    """transformers' Qwen2VLTextModel (random weights, M-RoPE [3, 1, L, dh] position embeddings,
+    num=4 importance queries) patched with apply_framefusion."""
+    from transformers.models.qwen2_vl.modeling_qwen2_vl import Qwen2VLTextConfig, Qwen2VLTextModel
+    from transformers.cache_utils import DynamicCache
+    from framefusion_amd.models.qwen2_vl import register_hf_qwen2_vl
+    torch.manual_seed(0)
+    cfg = Qwen2VLTextConfig(vocab_size=128, hidden_size=256, intermediate_size=512, num_hidden_layers=4,
+                            num_attention_heads=8, num_key_value_heads=2, max_position_embeddings=4096,
+                            rope_parameters={"rope_type": "default", "rope_theta": 1e6, "mrope_section": [4, 6, 6]})
+    cfg._attn_implementation = "sdpa"
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.model = Qwen2VLTextModel(cfg)
+    m = Holder().to(DEV).to(torch.bfloat16).eval()
+    register_hf_qwen2_vl()
+    ffa.apply_framefusion(m, cost=0.3, similarity_lower_bound=0.5, ratio_lower_bound=0.1)
+    ff = m.framefusion
+    shadow = Shadow(ff)
+    ff.forward = shadow
+    F_, P, pre, post = 12, 24, 5, 7
+    emb, pt = video_tokens(F_, P, 256, p_change=0.5, sigma=0.3, sigma_hi=1.2, seed=12, pre=pre, post=post)
+    L = emb.shape[1]
+    ff.prepare(pt.to(DEV), P, pre, pre + F_ * P, F_ * P, L)
+    with torch.no_grad():
+        out = m.model(inputs_embeds=emb.to(DEV), past_key_values=DynamicCache(config=cfg), use_cache=True)
+    lengths = m.model.framefusion_lengths
+    assert out.last_hidden_state.shape[1] == lengths[-1] < L
+    assert lengths == sorted(lengths, reverse=True) and ff.finish_merging and ff.finish_pruning
+    assert [r["kind"] for r in shadow.log].count("prune") == 1
+    for r in shadow.log:
+        assert r["flags"] and r["sym"] <= 2, r
