@@ -68,6 +68,8 @@ _lib = None
 
 def build(verbose: bool = False) -> str:
     """Compile the HIP sources in csrc/ for gfx950 (hipcc cross-compiles without a GPU)."""
+    if not os.path.isdir(CSRC):
+        raise FrameFusionHipError(f"{CSRC} not found")
     res = subprocess.run(["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 1))],
                          capture_output=True, text=True)
     if verbose or res.returncode:
@@ -83,9 +85,13 @@ def load():
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
-        raise FrameFusionHipError(
-            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
-            f"(or `make -C {CSRC}`). framefusion_amd has no CPU/eager fallback.")
+        # not built yet (fresh checkout): compile the HIP sources once, in-tree; there is no other path
+        try:
+            build()
+        except Exception as e:
+            raise FrameFusionHipError(
+                f"{LIB_PATH} is missing and could not be built ({e}): run `python -c 'import __graft_entry__ as g; "
+                f"g.build()'` (or `make -C {CSRC}`). framefusion_amd has no CPU/eager fallback.") from e
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover

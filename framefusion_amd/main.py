@@ -141,6 +141,13 @@ class FrameFusion(nn.Module):
         s = self._scratch.get(key)
         if s is None:
             s = self._scratch[key] = _Scratch(device)
+        # the scratch is reused call after call: if the caller switched streams, order the new
+        # stream behind the one that last touched it
+        cur = torch.cuda.current_stream(device)
+        last = getattr(s, "last_stream", None)
+        if last is not None and last != cur:
+            cur.wait_stream(last)
+        s.last_stream = cur
         return s.ensure(L, dtype)
 
     @staticmethod

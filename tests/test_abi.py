@@ -73,5 +73,6 @@ def test_argument_validation_without_gpu():
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    monkeypatch.setattr(_lib, "CSRC", str(tmp_path / "no_sources"))       # nothing to build from either
     with pytest.raises(_lib.FrameFusionHipError, match="no CPU/eager fallback"):
         _lib.load()
