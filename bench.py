@@ -30,6 +30,7 @@ FRAMES, PATCHES, DIM, HEAD_DIM = 64, 576, 4096, 128
 COST, THRESHOLD, RATIO_LB = 0.3, 0.6, 0.1          # reference operating point (README.md:123)
 P_CHANGE, SIGMA = 0.2, 0.3                         # top-k regime 36864 -> 11060
 HBM_PEAK_GBS = 8000.0                              # MI355X_MICROARCH.md: 8 TB/s spec
+BASELINE_METRIC = "vision tokens reduced/sec (64 frames\u00d7576 tok, d=4096 bf16), 1\u21928 MI355X"   # BASELINE.json
 
 
 def parse():
@@ -185,7 +186,7 @@ def main():
         achieved = alg[dominant] / (kernel_us[dominant] * 1e-6) / 1e9
         ms_per_step = t_max / args.steps * 1e3
         result = {
-            "metric": "vision tokens reduced/sec (64 frames x 576 tok, d=4096 bf16)",
+            "metric": BASELINE_METRIC,
             "value": tok_all / t_max,
             "unit": "tokens/s",
             "n_gpus": world,

@@ -170,3 +170,25 @@ def test_128_frames_cascade_and_large_ragged_order():
             assert torch.equal(order[:nv].cpu().long(), want)
             assert torch.equal(f.last_call["scratch"].order[:nv].cpu().long(), want)
         ho, hg = harness.layer_stub(ho, call), harness.layer_stub(hg, call)
+
+
+@pytest.mark.parametrize("dt", ["fp16", "fp32"])
+@pytest.mark.parametrize("p_change", [0.2, 0.6])
+def test_other_dtypes_cascade_exact(dt, p_change):
+    """fp16 / fp32 activations (the dtype only changes where the recipe rounds): whole cascades at a
+    medium size, bit-exact on grid data, through merge (both branches) and prune."""
+    from tests.conftest import DT
+    dtype = DT[dt]
+    F, P, d, pre, post = 32, 100, 1024, 9, 11
+    h, pt = video_tokens(F, P, d, p_change=p_change, sigma=0.3, sigma_hi=1.6, seed=21, pre=pre, post=post,
+                         dtype=dtype, grid=0.125)
+    L = h.shape[1]
+    want, _ = harness.run_cascade(orc.OracleFrameFusion(0.3, 0.6, 0.1), h.clone(), pt.clone(), P,
+                                  rotary_tables(L, 64, dtype), None, layers=3, heads=8, num=1)
+    got, _ = harness.run_cascade(ffa.FrameFusion(0.3, 0.6, 0.1), h.to(DEV), pt.to(DEV), P,
+                                 [t.to(DEV) for t in rotary_tables(L, 64, dtype)], None, layers=3, heads=8, num=1)
+    assert got[-1]["finish_merging"] and got[-1]["finish_pruning"]
+    for a, b in zip(got, want):
+        assert (a["length"], a["finish_merging"], a["finish_pruning"], a["sparsity"]) == \
+               (b["length"], b["finish_merging"], b["finish_pruning"], b["sparsity"]), a["tag"]
+        assert same_bits(a["hidden"].cpu(), b["hidden"]), a["tag"]
