@@ -19,10 +19,7 @@
 
 namespace ff {
 
-constexpr int kSimThreads = 256;
-constexpr int kSimWaves = kSimThreads / kWave;
-
-template <int DT, int kPairs>
+template <int DT, int kPairs, int kSimThreads>
 __global__ __launch_bounds__(kSimThreads) void k_pair_similarity(
     const char* __restrict__ hidden, uint32_t row_bytes, const int64_t* __restrict__ ptype,
     const int32_t* __restrict__ order, const int64_t* __restrict__ stats, void* __restrict__ sim,
@@ -30,6 +27,7 @@ __global__ __launch_bounds__(kSimThreads) void k_pair_similarity(
     using A = Act<DT>;
     constexpr int E = A::kPer16;
     constexpr int R = kPairs + 1;
+    constexpr int kSimWaves = kSimThreads / kWave;
     const int nv = (int)stats[FF_STAT_NV];
     const int lane = lane_id();
     const int j0 = uniform((blockIdx.x * kSimWaves + wave_id()) * kPairs);
@@ -131,16 +129,27 @@ __global__ __launch_bounds__(kSimThreads) void k_pair_similarity(
     }
 }
 
+template <int DT, int kPairs, int kSimThreads>
+static int launch_similarity_pt(const void* hidden, int64_t L, int64_t d, const int64_t* ptype,
+                                const int32_t* order, const int64_t* stats, void* sim, int* l0, float thr,
+                                hipStream_t st) {
+    const int64_t row_bytes = d * Act<DT>::kBytes;
+    const int64_t per_block = (int64_t)(kSimThreads / kWave) * kPairs;
+    const int64_t blocks = (L + per_block - 1) / per_block;
+    hipLaunchKernelGGL((k_pair_similarity<DT, kPairs, kSimThreads>), dim3((unsigned)blocks), dim3(kSimThreads), 0, st,
+                       (const char*)hidden, (uint32_t)row_bytes, ptype, order, stats, sim, l0, thr);
+    return (int)hipGetLastError();
+}
+
 template <int DT, int kPairs>
 static int launch_similarity_p(const void* hidden, int64_t L, int64_t d, const int64_t* ptype,
                                const int32_t* order, const int64_t* stats, void* sim, int* l0, float thr,
                                hipStream_t st) {
-    const int64_t row_bytes = d * Act<DT>::kBytes;
-    const int64_t per_block = (int64_t)kSimWaves * kPairs;
-    const int64_t blocks = (L + per_block - 1) / per_block;
-    hipLaunchKernelGGL((k_pair_similarity<DT, kPairs>), dim3((unsigned)blocks), dim3(kSimThreads), 0, st,
-                       (const char*)hidden, (uint32_t)row_bytes, ptype, order, stats, sim, l0, thr);
-    return (int)hipGetLastError();
+    static int waves = 0;
+    if (!waves) { const char* e = getenv("FF_SIM_WAVES"); waves = e ? atoi(e) : 4; }
+    if (waves == 8) return launch_similarity_pt<DT, kPairs, 512>(hidden, L, d, ptype, order, stats, sim, l0, thr, st);
+    if (waves == 2) return launch_similarity_pt<DT, kPairs, 128>(hidden, L, d, ptype, order, stats, sim, l0, thr, st);
+    return launch_similarity_pt<DT, kPairs, 256>(hidden, L, d, ptype, order, stats, sim, l0, thr, st);
 }
 
 static int tune_pairs() {
