@@ -32,6 +32,10 @@ class FFAux(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("row_bytes", C.c_int64), ("outer", C.c_int64)]
 
 
+class FFSegment(C.Structure):
+    _fields_ = [("begin", C.c_int32), ("count", C.c_int32), ("first", C.c_int32), ("period", C.c_int32)]
+
+
 class FrameFusionHipError(RuntimeError):
     pass
 
@@ -59,6 +63,9 @@ PROTOTYPES = {
                                _i64, C.POINTER(FFAux), _i32, _vp, _vp, _sz, _vp]),
     "ff_prune_step": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp,
                              _vp, C.POINTER(FFAux), _i32, _vp, _sz, _vp]),
+    "ff_token_span": (_i32, [_vp, _i64, _i64, _vp, _vp]),
+    "ff_fill_patch_type": (_i32, [_vp, _i64, C.POINTER(FFSegment), _i64, _vp]),
+    "ff_patch_type_from_mask": (_i32, [_vp, _i64, _i64, _vp, _vp, _vp]),
     "ff_merge_step": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _i64, _i32, _f64, _f64, _f64, _vp, _vp, _vp,
                              _vp, _vp, _vp, _vp, _i64, C.POINTER(FFAux), _i32, _vp, _sz, _vp]),
 }

@@ -34,6 +34,9 @@ class Family(NamedTuple):
     # calls framefusion.prepare(...) - e.g. ("prepare_inputs_labels_for_multimodal", fn) for
     # LLaVA-Video (interface.py:69-70)
     prepare_hook: Optional[tuple] = None
+    # attach(model): alternative to prepare_hook for packers that cannot be re-bound as one method
+    # (e.g. a forward pre-hook that derives the layout from input_ids and calls framefusion.prepare)
+    attach: Optional[Callable] = None
 
 
 _FAMILIES: List[Family] = []
@@ -60,6 +63,8 @@ def _bind_prepare(model, fam: Family) -> None:
     if fam.prepare_hook is not None:
         attr, fn = fam.prepare_hook
         setattr(model, attr, MethodType(fn, model))
+    if fam.attach is not None:
+        fam.attach(model)
 
 
 def apply_framefusion(model, cost, similarity_lower_bound, ratio_lower_bound):

@@ -5,8 +5,12 @@ Same protocol as the reference's ``framefusion/models/qwen2/modeling_qwen2_vl.py
 loop :16-140): M-RoPE position embeddings are a mutable ``[cos, sin]`` list of ``[3, 1, L, dh]``
 tensors, gathered along the token axis by FrameFusion (main.py:145-147,165-167).
 
-The vision tower / packer that builds ``patch_type`` (``framefusion/models/qwenvl/modeling_qwen2_vl.py:117-138``)
-stays outside: callers invoke ``model.framefusion.prepare(...)`` before the prefill.
+The packer block that builds ``patch_type`` (``framefusion/models/qwenvl/modeling_qwen2_vl.py:117-138``) sits in
+the reference inside a re-written ``Qwen2VLForConditionalGeneration.forward``; here it is a forward
+pre-hook on transformers' ``Qwen2VLModel`` (the module that owns the vision tower and receives
+``input_ids`` + ``video_grid_thw``): on a prefill with a video it derives the layout with
+``framefusion_amd.layout.qwen2_vl_layout`` and calls ``framefusion.prepare``.  Bare text-decoder
+wrappers have no such inputs: their callers invoke ``model.framefusion.prepare(...)`` themselves.
 """
 from __future__ import annotations
 
@@ -101,6 +105,28 @@ def qwen2vl_text_model_forward(self, input_ids=None, attention_mask=None, positi
     return BaseModelOutputWithPast(last_hidden_state=hidden_states, past_key_values=past_key_values)
 
 
+def attach_qwen2vl_prepare(model) -> None:
+    """Forward pre-hook on `model.model` (Qwen2VLModel): qwenvl/modeling_qwen2_vl.py:117-138."""
+    from ..layout import qwen2_vl_layout
+    inner = model.model
+    old = getattr(inner, "_framefusion_prepare_handle", None)
+    if old is not None:
+        old.remove()
+
+    def prepare_from_inputs(module, args, kwargs):
+        input_ids = kwargs.get("input_ids", args[0] if args else None)
+        grid = kwargs.get("video_grid_thw")
+        if input_ids is None or grid is None or input_ids.shape[1] == 1:     # :118 (prefill only)
+            return None
+        assert input_ids.shape[0] == 1, "FrameFusion handles one sample per prefill (main.py:203)"
+        cfg = module.config
+        merge = cfg.vision_config.spatial_merge_size
+        qwen2_vl_layout(input_ids, cfg.video_token_id, grid, merge).prepare(model.framefusion)
+        return None
+
+    inner._framefusion_prepare_handle = inner.register_forward_pre_hook(prepare_from_inputs, with_kwargs=True)
+
+
 def register_hf_qwen2_vl() -> None:
     """Make apply_framefusion() accept transformers' Qwen2VLForConditionalGeneration (text decoder at
     ``model.language_model``) and bare wrappers exposing a Qwen2VLTextModel as ``.model``."""
@@ -119,6 +145,7 @@ def register_hf_qwen2_vl() -> None:
         return isinstance(getattr(model, "model", None), Qwen2VLTextModel)
 
     register_family(Family("hf_qwen2_vl", is_full, qwen2vl_text_model_forward, qwen2vl_decoder_forward,
-                           qwen2vl_attention_forward, "model.language_model", "layers", "self_attn"))
+                           qwen2vl_attention_forward, "model.language_model", "layers", "self_attn",
+                           attach=attach_qwen2vl_prepare))
     register_family(Family("hf_qwen2_vl_text", is_text_wrapper, qwen2vl_text_model_forward, qwen2vl_decoder_forward,
                            qwen2vl_attention_forward, "model", "layers", "self_attn"))

@@ -168,6 +168,38 @@ int ff_last_query_attention(const void* q_last, const void* k, int dtype, int64_
                             void* weights, void* importance, void* ws, size_t ws_bytes,
                             ff_stream_t stream);
 
+/* ---- token layout (the patch_type builders of the reference's multimodal packers) -------------
+ * The packers find the visual span in the prompt ids with torch.where and build patch_type as a
+ * Python list of L ints that is then uploaded (llava_video/modeling_llava_video.py:332-336,
+ * qwenvl/modeling_qwen2_vl.py:123-127, internvl/modeling_internvl_chat.py:59-74,
+ * minicpmv/modeling_minicpmv.py:92-98, nvila/llava_arch.py:51,86-88).  Here the row is written on
+ * the device from a handful of segment descriptors.
+ *
+ * ff_token_span: span[0] = first index with ids[i] == token (-1 if none), span[1] = last such
+ * index (-1), span[2] = number of matches.  `span` may be device memory or device-visible pinned
+ * host memory. */
+int ff_token_span(const int64_t* ids, int64_t n, int64_t token, int64_t* span, ff_stream_t stream);
+
+/* Positions begin .. begin+count-1 get type (first + offset) % period; everything else
+ * TEXT_TOKEN (-1).  Segments must not overlap. */
+typedef struct {
+    int32_t begin, count, first, period;
+} ff_segment_t;
+
+/* patch_type [L] int64 (the reference's dtype); segments_host is HOST memory (copied into the
+ * launch arguments, any number of segments). */
+int ff_fill_patch_type(int64_t* patch_type, int64_t L, const ff_segment_t* segments_host,
+                       int64_t n_segments, ff_stream_t stream);
+
+/* internvl marks the image-context tokens with a boolean mask (`selected`, :29) in which every
+ * frame is one run of `patch_num` matches separated by text.  Writes patch_type directly: a
+ * position inside a run gets its offset from the start of the run, every other position -1.
+ * span[0..2] as ff_token_span (first, last, count of nonzero bytes), span[3] = number of runs,
+ * span[4] = number of runs whose length differs from patch_num (the caller rejects the layout if
+ * nonzero: the reference's list arithmetic has no meaning for it).  n < 2^31. */
+int ff_patch_type_from_mask(const uint8_t* mask, int64_t n, int64_t patch_num, int64_t* patch_type,
+                            int64_t* span, ff_stream_t stream);
+
 /* ---- fused step -----------------------------------------------------------------------------
  * One FrameFusion.forward merge call (main.py:104-138): K0 (skipped when order_valid != 0) ->
  * K1 -> K2+K3 -> K4, all enqueued by one host call.  `stats_host_mapped` (may be NULL) is a

@@ -153,3 +153,65 @@ def test_hf_qwen2_vl_text_prefill():
     assert [r["kind"] for r in shadow.log].count("prune") == 1
     for r in shadow.log:
         assert r["flags"] and r["sym"] <= 2, r
+
+
+def test_hf_qwen2_vl_full_model_builds_its_own_layout():
+    """transformers' Qwen2VLForConditionalGeneration with a (tiny, random) vision tower: the packer
+    hook derives patch_type from input_ids + video_grid_thw (qwenvl/modeling_qwen2_vl.py:117-138)
+    and calls prepare; nobody prepares FrameFusion by hand."""
+    from transformers import Qwen2VLConfig, Qwen2VLForConditionalGeneration
+    from transformers.cache_utils import DynamicCache
+    from framefusion_amd.models.qwen2_vl import register_hf_qwen2_vl
+    from oracle import layout_oracle as lay
+    torch.manual_seed(0)
+    VID = 151
+    cfg = Qwen2VLConfig(
+        text_config=dict(vocab_size=160, hidden_size=256, intermediate_size=512, num_hidden_layers=4,
+                         num_attention_heads=8, num_key_value_heads=2, max_position_embeddings=4096,
+                         bos_token_id=None, eos_token_id=None,
+                         rope_parameters={"rope_type": "default", "rope_theta": 1e6, "mrope_section": [4, 6, 6]}),
+        vision_config=dict(depth=1, embed_dim=32, hidden_size=256, num_heads=2, mlp_ratio=2, in_channels=3,
+                           patch_size=14, spatial_merge_size=2, temporal_patch_size=2),
+        image_token_id=150, video_token_id=VID, vision_start_token_id=152, vision_end_token_id=153)
+    cfg._attn_implementation = "sdpa"
+    m = Qwen2VLForConditionalGeneration(cfg).to(DEV).to(torch.bfloat16).eval()
+    register_hf_qwen2_vl()
+    ffa.apply_framefusion(m, cost=0.3, similarity_lower_bound=0.5, ratio_lower_bound=0.1)
+    ff = m.framefusion
+    assert m.model.language_model.framefusion is ff
+    shadow = Shadow(ff)
+    ff.forward = shadow
+    T, H, W = 12, 8, 12                                    # 12 temporal grids of 8x12 patches -> P = 24
+    n = T * H * W // 4
+    ids = [1, 2, 3, 4, 152] + [VID] * n + [153, 5, 6, 7, 8, 9, 10]
+    frame = torch.randn(H * W, 3 * 2 * 14 * 14)
+    frames = [frame]
+    for t in range(1, T):                                   # slowly drifting frames, two scene cuts
+        frames.append(torch.randn_like(frame) if t in (5, 9) else frames[-1] + 0.05 * torch.randn_like(frame))
+    pixels = torch.cat(frames).to(DEV).to(torch.bfloat16)
+    input_ids = torch.tensor([ids], device=DEV)
+    with torch.no_grad():
+        out = m.model(input_ids=input_ids, pixel_values_videos=pixels, video_grid_thw=torch.tensor([[T, H, W]], device=DEV),
+                      mm_token_type_ids=(input_ids == VID).int() * 2,
+                      past_key_values=DynamicCache(config=cfg.text_config), use_cache=True)
+    want = lay.qwen2_vl(ids, VID, H, W, 2, n, len(ids))
+    assert (ff.patch_num, int(ff.image_token_start_index), int(ff.image_token_end_index), int(ff.image_token_length),
+            ff.original_length) == tuple(want[1:])
+    assert ff.patch_num == 24 and ff.original_length == len(ids)
+    lengths = m.model.language_model.framefusion_lengths
+    assert out.last_hidden_state.shape[1] == lengths[-1] < len(ids)
+    assert lengths == sorted(lengths, reverse=True) and ff.finish_merging and ff.finish_pruning
+    kinds = [r["kind"] for r in shadow.log]
+    assert "merge" in kinds and kinds.count("prune") <= 1          # the top-k branch ends both phases at once
+    for r in shadow.log:
+        assert r["flags"] and r["sym"] <= 2, r
+    # a second prefill re-derives the layout (state reset by prepare, main.py:27-38) ...
+    with torch.no_grad():
+        m.model(input_ids=input_ids, pixel_values_videos=pixels, video_grid_thw=torch.tensor([[T, H, W]], device=DEV),
+                mm_token_type_ids=(input_ids == VID).int() * 2,
+                past_key_values=DynamicCache(config=cfg.text_config), use_cache=True)
+    assert m.model.language_model.framefusion_lengths == lengths
+    # ... and the first one left the full-length row behind for inspection
+    first_row = lay.qwen2_vl(ids, VID, H, W, 2, n, len(ids))[0]
+    from framefusion_amd.layout import qwen2_vl_layout
+    assert qwen2_vl_layout(input_ids, VID, (T, H, W), 2).patch_type[0].tolist() == first_row
