@@ -23,6 +23,7 @@ DTYPE_CODE = {torch.float32: FF_F32, torch.bfloat16: FF_BF16, torch.float16: FF_
 (STAT_NV, STAT_FTN, STAT_COUNT, STAT_BRANCH, STAT_K, STAT_MERGED, STAT_LOUT, STAT_BELOW_LB,
  STAT_KTH_KEY, STAT_TIES_TAKEN, STAT_SEQ) = range(11)
 STAT_T_ORDER, STAT_T_PLAN = 16, 24
+FOLD_DROP, FOLD_SEQUENTIAL, FOLD_MEAN = 0, 1, 2
 STAT_WORDS = 32
 MAX_AUX = 4
 ABI_VERSION = 1
@@ -63,6 +64,9 @@ PROTOTYPES = {
                                _i64, C.POINTER(FFAux), _i32, _vp, _vp, _sz, _vp]),
     "ff_prune_step": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp,
                              _vp, C.POINTER(FFAux), _i32, _vp, _sz, _vp]),
+    "ff_plan_topk": (_i32, [_vp, _i32, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ff_merge_finish_topk": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                    _i64, C.POINTER(FFAux), _i32, _vp, _vp, _sz, _vp]),
     "ff_token_span": (_i32, [_vp, _i64, _i64, _vp, _vp]),
     "ff_fill_patch_type": (_i32, [_vp, _i64, C.POINTER(FFSegment), _i64, _vp]),
     "ff_patch_type_from_mask": (_i32, [_vp, _i64, _i64, _vp, _vp, _vp]),

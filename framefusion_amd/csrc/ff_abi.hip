@@ -7,7 +7,7 @@ namespace ff {
 int launch_plan_merge(const void* sim, int dtype, const int32_t* order, int64_t L, double thr, double sub,
                       double ratio_lb, uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
                       void* ws, const int* l0_copies, int* zero_next, int64_t* host_mapped, int64_t seq,
-                      hipStream_t st);
+                      hipStream_t st, long long force_k);
 size_t plan_ws_bytes(int64_t L);
 int* ws_l0_copies(void* ws, int64_t seq);
 int launch_merge_compact(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
@@ -58,26 +58,48 @@ extern "C" int ff_merge_begin(const void* hidden, int dtype, int64_t L, int64_t 
                                      threshold, (hipStream_t)stream);
 }
 
+// second half of a merge call: select (policy or forced k) + run merge (fold 1: main.py's sequential
+// rounding, 2: the baseline's fp32 mean) + compaction
+static int merge_finish(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
+                        double threshold, double sub, double ratio_lb, long long force_k, int fold,
+                        const int32_t* order, const void* sim, uint8_t* member, int32_t* dst, uint8_t* keep,
+                        int64_t* stats, int64_t* stats_host_mapped, int64_t seq, const ff_aux_t* aux_host, int n_aux,
+                        int32_t* order_next, void* ws, size_t ws_bytes, ff_stream_t stream) {
+    if (!hidden || !hidden_out || !order || !sim || !member || !dst || !keep || !stats || !ws) return FF_ERR_ARG;
+    if (ws_bytes < ff_workspace_bytes(L, 1)) return FF_ERR_WORKSPACE;
+    if (L_cap < L) return FF_ERR_ARG;
+    if (dtype != FF_F32 && dtype != FF_BF16 && dtype != FF_F16) return FF_ERR_ARG;
+    if (n_aux < 0 || n_aux > FF_MAX_AUX || (n_aux > 0 && !aux_host)) return FF_ERR_ARG;
+    const int64_t esz = dtype == FF_F32 ? 4 : 2;
+    if (((uintptr_t)hidden & 15) || ((uintptr_t)hidden_out & 15) || ((d * esz) & 15)) return FF_ERR_ALIGN;
+    if (order_next && ((uintptr_t)member & 15)) return FF_ERR_ALIGN;
+    if (L == 0) return FF_OK;
+    int rc = ff::launch_plan_merge(sim, dtype, order, L, threshold, sub, ratio_lb, member, dst, keep, stats, ws,
+                                   ff::ws_l0_copies(ws, seq), ff::ws_l0_copies(ws, seq + 1), stats_host_mapped, seq,
+                                   (hipStream_t)stream, force_k);
+    if (rc) return rc;
+    return ff::launch_merge_compact(hidden, hidden_out, dtype, L, d, L_cap, order, member, fold, dst, keep, aux_host,
+                                    n_aux, order_next, stats, (hipStream_t)stream);
+}
+
 extern "C" int ff_merge_finish(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
                                double threshold, double sub, double ratio_lb, const int32_t* order, const void* sim,
                                uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
                                int64_t* stats_host_mapped, int64_t seq, const ff_aux_t* aux_host, int n_aux,
                                int32_t* order_next, void* ws, size_t ws_bytes, ff_stream_t stream) {
-    if (!hidden || !hidden_out || !order || !sim || !member || !dst || !keep || !stats || !ws) return FF_ERR_ARG;
-    if (ws_bytes < ff_workspace_bytes(L, 1)) return FF_ERR_WORKSPACE;
-    if (L_cap < L) return FF_ERR_ARG;
-    if (dtype != FF_F32 && dtype != FF_BF16 && dtype != FF_F16) return FF_ERR_ARG;
-    if (L == 0) return FF_OK;
-    int rc = ff::launch_plan_merge(sim, dtype, order, L, threshold, sub, ratio_lb, member, dst, keep, stats, ws,
-                                   ff::ws_l0_copies(ws, seq), ff::ws_l0_copies(ws, seq + 1), stats_host_mapped, seq,
-                                   (hipStream_t)stream);
-    if (rc) return rc;
-    if (n_aux < 0 || n_aux > FF_MAX_AUX || (n_aux > 0 && !aux_host)) return FF_ERR_ARG;
-    const int64_t esz = dtype == FF_F32 ? 4 : 2;
-    if (((uintptr_t)hidden & 15) || ((uintptr_t)hidden_out & 15) || ((d * esz) & 15)) return FF_ERR_ALIGN;
-    if (order_next && ((uintptr_t)member & 15)) return FF_ERR_ALIGN;
-    return ff::launch_merge_compact(hidden, hidden_out, dtype, L, d, L_cap, order, member, 1, dst, keep, aux_host,
-                                    n_aux, order_next, stats, (hipStream_t)stream);
+    return merge_finish(hidden, hidden_out, dtype, L, d, L_cap, threshold, sub, ratio_lb, -1, FF_FOLD_SEQUENTIAL, order, sim,
+                        member, dst, keep, stats, stats_host_mapped, seq, aux_host, n_aux, order_next, ws, ws_bytes,
+                        stream);
+}
+
+extern "C" int ff_merge_finish_topk(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d,
+                                    int64_t L_cap, int64_t k, int fold, const int32_t* order, const void* sim,
+                                    uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
+                                    int64_t* stats_host_mapped, int64_t seq, const ff_aux_t* aux_host, int n_aux,
+                                    int32_t* order_next, void* ws, size_t ws_bytes, ff_stream_t stream) {
+    if (k < 0 || (fold != FF_FOLD_SEQUENTIAL && fold != FF_FOLD_MEAN)) return FF_ERR_ARG;
+    return merge_finish(hidden, hidden_out, dtype, L, d, L_cap, 0.0, 0.0, 0.0, k, fold, order, sim, member, dst, keep,
+                        stats, stats_host_mapped, seq, aux_host, n_aux, order_next, ws, ws_bytes, stream);
 }
 
 extern "C" int ff_merge_step(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,

@@ -183,7 +183,12 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
     int open_r = -1, open_n = 0;                            // the output row being accumulated
     auto flush = [&]() {
         float o[E];
-        if (open_n > 0) {
+        if (open_n > 0 && fold == FF_FOLD_MEAN) {
+            // torch .mean(dim=1): fp32 sum (which starts from +0, so an all -0 column gives +0) / N, one rounding
+            const float div = (float)(open_n + 1);
+#pragma unroll
+            for (int e = 0; e < E; ++e) o[e] = A::rnd((acc[e] + 0.0f) / div);
+        } else if (open_n > 0) {
             const float div = A::rnd((float)(open_n + 1));
 #pragma unroll
             for (int e = 0; e < E; ++e) o[e] = A::rnd(acc[e] / div);
@@ -203,6 +208,12 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
                     open_r = __builtin_amdgcn_readlane(dv, b.pos + u - t0);
                     open_n = 0;
                     A::unpack(b.buf[u], acc);
+                } else if (fold == FF_FOLD_MEAN) {
+                    float x[E];
+                    A::unpack(b.buf[u], x);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) acc[e] = acc[e] + x[e];
+                    ++open_n;
                 } else if (fold) {
                     float x[E];
                     A::unpack(b.buf[u], x);

@@ -115,7 +115,7 @@ constexpr int kL0Copies = 16;
 struct PlanParams {
     int mode;            // 0: merge (threshold / top-k decided from the count), 1: prune (top-k given)
     int lo, hi;          // value range the selection runs over (merge: hi < 0 -> [0, Nv))
-    long long k_given;   // prune: k
+    long long k_given;   // prune: k; merge: >= 0 forces top-k with this k, -1 = threshold/budget policy
     double sub, ratio_lb;
     uint32_t thr_key;
     int l0_rows;         // rows of the level-0 table (64 copies or G slices)
@@ -211,7 +211,11 @@ __device__ inline Resolved resolve(const PlanParams& pp, int l0col, int l0cnt, c
     s.tot[tid] = l0col;
     const int c = block_sum_i<kSliceThreads / kWave>(l0cnt, s.scratch);
     r.count = c;
-    if (pp.mode == 0) {
+    if (pp.mode == 0 && pp.k_given >= 0) {
+        // fixed-sparsity policy: the caller fixed k (modeling_qwen2_baseline.py:920,1001)
+        r.topk = true;
+        r.k = pp.k_given > nv ? (long long)nv : pp.k_given;
+    } else if (pp.mode == 0) {
         // main.py:114-116 in double, as python: ratio = count / ftn ; ratio < sub ?
         const double ratio = ftn > 0 ? (double)r.count / (double)ftn : 0.0;
         r.topk = !(ratio < pp.sub);
@@ -666,9 +670,9 @@ static int launch_select_flags(const void* values, PlanParams pp, const int* l0,
 int launch_plan_merge(const void* sim, int dtype, const int32_t* order, int64_t L, double thr, double sub,
                       double ratio_lb, uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
                       void* ws, const int* l0_copies, int* zero_next, int64_t* host_mapped, int64_t seq,
-                      hipStream_t st) {
+                      hipStream_t st, long long force_k) {
     PlanParams pp;
-    pp.mode = 0; pp.lo = 0; pp.hi = -1; pp.k_given = 0; pp.sub = sub; pp.ratio_lb = ratio_lb;
+    pp.mode = 0; pp.lo = 0; pp.hi = -1; pp.k_given = force_k; pp.sub = sub; pp.ratio_lb = ratio_lb;
     pp.l0_rows = kL0Copies; pp.n_slices = 0;
     int rc;
     static int use_fused = -1;
@@ -743,7 +747,20 @@ extern "C" int ff_plan_merge(const void* sim, int dtype, const int32_t* order, i
     if (!aligned16(sim) || !aligned16(dst) || !aligned16(keep) || !aligned16(ws)) return FF_ERR_ALIGN;
     if (L == 0) return FF_OK;
     return ff::launch_plan_merge(sim, dtype, order, L, threshold, sub, ratio_lb, member, dst, keep, stats, ws,
-                                 nullptr, nullptr, nullptr, 0, (hipStream_t)stream);
+                                 nullptr, nullptr, nullptr, 0, (hipStream_t)stream, -1);
+}
+
+extern "C" int ff_plan_topk(const void* sim, int dtype, const int32_t* order, int64_t L, int64_t k, uint8_t* member,
+                            int32_t* dst, uint8_t* keep, int64_t* stats, void* ws, size_t ws_bytes,
+                            ff_stream_t stream) {
+    int rc = check_plan_args(sim, member, dst, keep, stats, L, ws, ws_bytes);
+    if (rc) return rc;
+    if (!order || k < 0) return FF_ERR_ARG;
+    if (dtype != FF_F32 && dtype != FF_BF16 && dtype != FF_F16) return FF_ERR_ARG;
+    if (!aligned16(sim) || !aligned16(dst) || !aligned16(keep) || !aligned16(ws)) return FF_ERR_ALIGN;
+    if (L == 0) return FF_OK;
+    return ff::launch_plan_merge(sim, dtype, order, L, 0.0, 0.0, 0.0, member, dst, keep, stats, ws, nullptr, nullptr,
+                                 nullptr, 0, (hipStream_t)stream, k);
 }
 
 extern "C" int ff_plan_from_index(const int64_t* merge_index, int64_t n_merge, const int32_t* order, int64_t L,

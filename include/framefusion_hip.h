@@ -109,6 +109,14 @@ int ff_plan_merge(const void* sim, int dtype, const int32_t* order, int64_t L,
                   uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
                   void* ws, size_t ws_bytes, ff_stream_t stream);
 
+/* Same outputs for the FIXED-SPARSITY policy of the reference's merging baseline
+ * (framefusion/models/qwen2/modeling_qwen2_baseline.py:918-1012): the k largest by-patch
+ * similarities (k = floor(sparsity * ftn), computed by the caller), ties at the k-th value taken
+ * in ascending j.  stats as ff_plan_merge with BRANCH = 1. */
+int ff_plan_topk(const void* sim, int dtype, const int32_t* order, int64_t L, int64_t k,
+                 uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
+                 void* ws, size_t ws_bytes, ff_stream_t stream);
+
 /* Same outputs for an EXPLICIT merge set (the static merge_tokens_and_get_mask entry point,
  * main.py:243-319): merge_index[0..n_merge) ascending by-patch positions. */
 int ff_plan_from_index(const int64_t* merge_index, int64_t n_merge, const int32_t* order, int64_t L,
@@ -128,12 +136,19 @@ int ff_plan_prune(const void* importance, int dtype, int64_t S, int64_t start, i
  * Replaces index_add_ + divide (main.py:304-317) and the keep-mask gathers of hidden /
  * position embeddings / patch_type (main.py:132-138, 161-178) in one pass.
  * For every slot t with member[t] == 0, i = order[t] (order == NULL: i = t), n = number of
- * consecutive member slots after t (fold != 0; with fold == 0 members are simply dropped):
- *   out[dst[i]] = T( (..(T(h[i] + h[order[t+1]]) + ..) + h[order[t+n]]) / T(n+1) )   (n > 0)
+ * consecutive member slots after t (fold = FF_FOLD_*; with FF_FOLD_DROP members are simply dropped):
+ *   out[dst[i]] = T( (..(T(h[i] + h[order[t+1]]) + ..) + h[order[t+n]]) / T(n+1) )   (n > 0, SEQUENTIAL)
+ *   out[dst[i]] = T( (h[i] + h[order[t+1]] + .. + h[order[t+n]])_fp32 / (n+1) )       (n > 0, MEAN)
  *   out[dst[i]] = h[i]                                                               (n == 0)
  * and each aux tensor (viewed as [outer, L, row_bytes] bytes) is gathered the same way into
  * [outer, L_cap, row_bytes] (every kept position i goes to row dst[i]; `keep` is the plan's keep
  * mask, only read when n_aux > 0). `hidden_out` holds L_cap rows (L_cap >= L_out; L is enough). */
+enum {
+    FF_FOLD_DROP = 0,        /* members are dropped (prune)                                         */
+    FF_FOLD_SEQUENTIAL = 1,  /* main.py:304-317: T-rounded add per member, one T-rounded divide     */
+    FF_FOLD_MEAN = 2         /* modeling_qwen2_baseline.py:1034-1048: T(fp32 sum / (n+1)), .mean()  */
+};
+
 typedef struct {
     const void* src;     /* [outer, L, row_bytes]                         */
     void* dst;           /* [outer, L_cap, row_bytes]                     */
@@ -232,6 +247,16 @@ int ff_merge_finish(const void* hidden, void* hidden_out, int dtype, int64_t L, 
                     int64_t* stats, int64_t* stats_host_mapped, int64_t seq,
                     const ff_aux_t* aux_host, int n_aux, int32_t* order_next,
                     void* ws, size_t ws_bytes, ff_stream_t stream);
+
+/* ff_merge_finish for the fixed-sparsity baseline: top-k with the caller's k instead of the
+ * threshold/budget policy, and `fold` = FF_FOLD_SEQUENTIAL or FF_FOLD_MEAN (the baseline averages
+ * each run with .mean(dim=1), modeling_qwen2_baseline.py:1034-1048).  Same workspace protocol. */
+int ff_merge_finish_topk(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
+                         int64_t k, int fold,
+                         const int32_t* order, const void* sim, uint8_t* member, int32_t* dst, uint8_t* keep,
+                         int64_t* stats, int64_t* stats_host_mapped, int64_t seq,
+                         const ff_aux_t* aux_host, int n_aux, int32_t* order_next,
+                         void* ws, size_t ws_bytes, ff_stream_t stream);
 
 /* One FrameFusion.forward prune call (main.py:61-101) from a single host call: head mean of the
  * attention weights (skipped when H*num == 1: the weights are then already the importance),

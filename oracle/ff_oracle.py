@@ -278,3 +278,71 @@ def last_query_attention(query, key, num=1, is_causal=False, scale=None, enable_
     w = q @ key.transpose(-2, -1) * factor
     w += bias
     return torch.softmax(w, dim=-1)
+
+
+# --------------------------------------------------------------------------------------
+# §8(f) rank 4: the fixed-sparsity merging baseline
+# (framefusion/models/qwen2/modeling_qwen2_baseline.py:26-43, 905-1053, 1081-1085, 1180-1185)
+# --------------------------------------------------------------------------------------
+def density_overhead(sparsity_list: Sequence[float]) -> Tuple[float, float]:
+    """compute_density_overhead (:26-43): (mean cumulative density, final density)."""
+    cost = 0.0
+    remaining = 1.0
+    for s in sparsity_list:
+        remaining *= 1 - s
+        cost += remaining
+    return cost / len(sparsity_list), remaining
+
+
+def mean_merge_rows(hidden: torch.Tensor, order: torch.Tensor, merge_idx: torch.Tensor):
+    """Every run's anchor row becomes ``rows[anchor .. anchor+n].mean(dim=0)`` in the activation
+    dtype (:1034-1048: gather [R, n+1, d], ``.mean(dim=1)`` = fp32 sum / (n+1), one rounding),
+    processed per distinct run length in ascending order like the reference (:1021-1048; runs are
+    disjoint, so the order does not matter).  Returns (hidden_after [1, L, d], keep [1, L])."""
+    L = hidden.shape[1]
+    keep = torch.ones(1, L, dtype=torch.bool)
+    out = hidden.clone()
+    order = order.reshape(-1)
+    flags = torch.zeros(order.shape[0], dtype=torch.long)
+    flags[merge_idx] = 1
+    keep[0, order[merge_idx]] = False                                   # :1011-1012
+    lens = run_lengths(flags[None, :].to(hidden.dtype))[0].to(torch.long)   # :1014 (act dtype storage)
+    rows = out[0]
+    for n in torch.unique(lens).tolist():                               # :1016-1018
+        if n <= 0:
+            continue
+        ends = torch.nonzero(lens == n).reshape(-1)
+        span = (ends - n)[:, None] + torch.arange(n + 1)[None, :]       # :1024-1032
+        rows[order[ends - n]] = rows[order[span]].mean(dim=1)           # :1034-1048
+    return out, keep
+
+
+def fixed_sparsity_merge(hidden: torch.Tensor, patch_type: torch.Tensor, patch_num: int, sparsity: float,
+                         position_embeddings=None, residual: Optional[torch.Tensor] = None):
+    """One layer of the merging baseline (:916-1052 inside the attention forward, + the residual
+    and rotary gathers of :1180-1185 and :1081-1085).  hidden [1, L, d] (the normed activations),
+    patch_type [1, L].  Returns dict(hidden, patch_type, token_mask or None, position_embeddings,
+    residual, prune_num, sim, order)."""
+    out = dict(hidden=hidden, patch_type=patch_type, token_mask=None, position_embeddings=position_embeddings,
+               residual=residual, prune_num=0, sim=None, order=None)
+    if hidden.shape[1] <= 1:                                            # :916 (prefill only)
+        return out
+    ftn = int((patch_type != TEXT_TOKEN).sum())                         # :919
+    prune_num = math.floor(sparsity * ftn)                              # :920
+    out["prune_num"] = prune_num
+    if prune_num <= 0:                                                  # :922
+        return out
+    pt = patch_type.reshape(-1)
+    for p in range(patch_num):                                          # :982-983
+        if not bool((pt == p).any()):
+            raise ValueError("No token in this patch")
+    sim, order = pair_similarity(hidden, patch_type, patch_num)        # :941-991 (same cosine, same order)
+    merge_idx = topk_lowest_index(sim[0], prune_num)                    # :1001 (tie rule: module docstring)
+    merged, keep = mean_merge_rows(hidden, order, merge_idx)
+    out.update(hidden=merged[:, keep[0]], patch_type=patch_type.reshape(1, -1)[:, keep[0]], token_mask=keep,
+               sim=sim, order=order)
+    if position_embeddings is not None:                                 # :1081-1085 (3-D cos/sin lists)
+        out["position_embeddings"] = [t[:, keep[0], :] for t in position_embeddings]
+    if residual is not None:                                            # :1180-1185
+        out["residual"] = residual[:, keep[0], :]
+    return out
