@@ -11,6 +11,10 @@ container only), runs both on the same seeded inputs, asserts bit-equality of ev
 writes the fixtures under ``tests/golden/``.  ``tests/test_oracle_golden.py`` re-checks this file
 against those fixtures wherever the repo travels.
 
+Every function builds its temporaries on the device of its inputs, so the same restatement also
+runs as "PyTorch eager on the GPU" (tools/kbench_eager.py times it there as a second baseline); the
+parity tests always run it on CPU.
+
 The arithmetic is deliberately expressed with the same torch primitives the reference uses
 (activation-dtype ``mul``/``sum``/``norm``/``div``) because the result is defined by their staged
 rounding; the *structure* (ordering, run detection, merging, selection)
@@ -81,7 +85,7 @@ def pair_similarity(hidden: torch.Tensor, patch_type: torch.Tensor, patch_num: i
     rows = hidden[0]
     sim = staged_cosine(rows[order[:-1]], rows[order[1:]])
     sim[ptype_sorted[:-1] != ptype_sorted[1:]] = IGNORE_TOKEN
-    head = torch.full((1,), IGNORE_TOKEN, dtype=hidden.dtype)
+    head = torch.full((1,), IGNORE_TOKEN, dtype=hidden.dtype, device=hidden.device)
     sim = torch.cat((head, sim))
     assert sim.shape[0] == order.shape[0]                               # main.py:240
     return sim[None, :], order[None, :]
@@ -97,7 +101,7 @@ def run_lengths(flags: torch.Tensor) -> torch.Tensor:
     for b in range(flags.shape[0]):
         row = flags[b]
         ones = (row == 1)
-        pad = torch.zeros(1, dtype=torch.bool)
+        pad = torch.zeros(1, dtype=torch.bool, device=flags.device)
         rises = torch.nonzero(ones & ~torch.cat((pad, ones[:-1]))).reshape(-1)
         falls = torch.nonzero(ones & ~torch.cat((ones[1:], pad))).reshape(-1)
         out[b, falls] = (falls - rises + 1).to(flags.dtype)
@@ -111,7 +115,7 @@ def topk_lowest_index(values: torch.Tensor, k: int) -> torch.Tensor:
     """Indices (ascending) of the k largest entries of a 1-D tensor; NaN ranks highest (as in
     torch.topk); ties at the cut go to the lowest index."""
     if k <= 0:
-        return torch.empty(0, dtype=torch.long)
+        return torch.empty(0, dtype=torch.long, device=values.device)
     ranked = torch.sort(values, descending=True, stable=True).indices[:k]
     return torch.sort(ranked).values
 
@@ -126,13 +130,13 @@ def merge_rows(hidden: torch.Tensor, order: torch.Tensor, merge_idx: torch.Tenso
     and after the divide - the order index_add_ applies on CPU (main.py:304-317).
     Returns (hidden_after [1, L, d], keep [1, L] bool)."""
     L = hidden.shape[1]
-    keep = torch.ones(1, L, dtype=torch.bool)
+    keep = torch.ones(1, L, dtype=torch.bool, device=hidden.device)
     out = hidden.clone()
     if merge_idx.numel() == 0:                                          # main.py:264-266
         return out, keep
     order = order.reshape(-1)
     nv = order.shape[0]
-    flags = torch.zeros(nv, dtype=torch.long)
+    flags = torch.zeros(nv, dtype=torch.long, device=hidden.device)
     flags[merge_idx] = 1
     keep[0, order[merge_idx]] = False                                   # main.py:278-279
     # run lengths are stored in the activation dtype by the reference (main.py:269-276): exact
@@ -210,7 +214,8 @@ class OracleFrameFusion:
         ratio = budget(self.sparsity_list, self.cost)
         k = round(n_img * (1 - ratio))
         top = topk_lowest_index(importance[start:start + n_img], k) + start
-        keep = torch.cat((torch.arange(start), top, torch.arange(start + n_img, q_len)))
+        dev = hidden.device
+        keep = torch.cat((torch.arange(start, device=dev), top, torch.arange(start + n_img, q_len, device=dev)))
         hidden = hidden[:, keep, :]
         position_embeddings = gather_position_embeddings(position_embeddings, keep)
         if attention_mask is not None:
@@ -300,10 +305,10 @@ def mean_merge_rows(hidden: torch.Tensor, order: torch.Tensor, merge_idx: torch.
     processed per distinct run length in ascending order like the reference (:1021-1048; runs are
     disjoint, so the order does not matter).  Returns (hidden_after [1, L, d], keep [1, L])."""
     L = hidden.shape[1]
-    keep = torch.ones(1, L, dtype=torch.bool)
+    keep = torch.ones(1, L, dtype=torch.bool, device=hidden.device)
     out = hidden.clone()
     order = order.reshape(-1)
-    flags = torch.zeros(order.shape[0], dtype=torch.long)
+    flags = torch.zeros(order.shape[0], dtype=torch.long, device=hidden.device)
     flags[merge_idx] = 1
     keep[0, order[merge_idx]] = False                                   # :1011-1012
     lens = run_lengths(flags[None, :].to(hidden.dtype))[0].to(torch.long)   # :1014 (act dtype storage)
@@ -312,7 +317,7 @@ def mean_merge_rows(hidden: torch.Tensor, order: torch.Tensor, merge_idx: torch.
         if n <= 0:
             continue
         ends = torch.nonzero(lens == n).reshape(-1)
-        span = (ends - n)[:, None] + torch.arange(n + 1)[None, :]       # :1024-1032
+        span = (ends - n)[:, None] + torch.arange(n + 1, device=ends.device)[None, :]       # :1024-1032
         rows[order[ends - n]] = rows[order[span]].mean(dim=1)           # :1034-1048
     return out, keep
 
