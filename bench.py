@@ -183,7 +183,27 @@ def main():
                      for q, name in enumerate(names)}
         alg = algorithmic_bytes(L, L_out, nv, d, elt, HEAD_DIM)
         dominant = max(("similarity", "merge_compact"), key=lambda k: kernel_us[k])
-        achieved = alg[dominant] / (kernel_us[dominant] * 1e-6) / 1e9
+        # An event pair around ONE launch also times two command-processor round trips (~7 us here;
+        # the rocprofv3 kernel trace does not see them).  For the roofline figure the dominant
+        # kernel is therefore timed differentially, still in pipeline order and with the same cache
+        # state: second pass with no event between it and its predecessor,
+        #   t(kernel) = t(predecessor + kernel, one event pair) - t(predecessor, one event pair),
+        # so the event overhead cancels and what remains is the launch duration plus the ~0.2 us
+        # dependency gap between the two kernels.
+        q_dom = names.index(dominant)
+        pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for r in range(reps):
+            rep_no[0] = r
+            for q, name in enumerate(names):
+                if q == q_dom - 1:
+                    pairs[r][0].record()
+                _lib.check(stages[name](), name)
+                if q == q_dom:
+                    pairs[r][1].record()
+        torch.cuda.synchronize()
+        both_us = sum(a.elapsed_time(b) for a, b in pairs) / reps * 1e3
+        dense_us = both_us - kernel_us[names[q_dom - 1]]
+        achieved = alg[dominant] / (dense_us * 1e-6) / 1e9
         ms_per_step = t_max / args.steps * 1e3
         result = {
             "metric": BASELINE_METRIC,
@@ -207,7 +227,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": profiled_traffic(dominant) if (F, P, d) == (FRAMES, PATCHES, DIM) else None,
-                         "algorithmic_bytes": alg[dominant], "kernel_us": kernel_us[dominant]},
+                         "algorithmic_bytes": alg[dominant], "kernel_us": dense_us,
+                         "kernel_us_own_event_pair": kernel_us[dominant]},
             "kernels_us": kernel_us,
             "step_roofline": {"algorithmic_bytes": alg["step"], "achieved": alg["step"] / (ms_per_step * 1e-3) / 1e9,
                               "frac": alg["step"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
