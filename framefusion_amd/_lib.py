@@ -24,9 +24,11 @@ DTYPE_CODE = {torch.float32: FF_F32, torch.bfloat16: FF_BF16, torch.float16: FF_
  STAT_KTH_KEY, STAT_TIES_TAKEN, STAT_SEQ) = range(11)
 STAT_T_ORDER, STAT_T_PLAN = 16, 24
 FOLD_DROP, FOLD_SEQUENTIAL, FOLD_MEAN = 0, 1, 2
+STAT_ERROR = 11
+ERR_BIT_BARRIER, ERR_BIT_LAYOUT = 1, 2
 STAT_WORDS = 32
 MAX_AUX = 4
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class FFAux(C.Structure):
@@ -59,7 +61,8 @@ PROTOTYPES = {
     "ff_head_mean": (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _vp]),
     "ff_last_query_attention": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _i64, _i64, _f64, _i32, _vp, _vp, _vp,
                                        _sz, _vp]),
-    "ff_merge_begin": (_i32, [_vp, _i32, _i64, _i64, _vp, _i64, _i32, _f64, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
+    "ff_merge_begin": (_i32, [_vp, _i32, _i64, _i64, _vp, _i64, _i32, _f64, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _sz,
+                              _vp]),
     "ff_merge_finish": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                _i64, C.POINTER(FFAux), _i32, _vp, _vp, _sz, _vp]),
     "ff_prune_step": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp,

@@ -109,12 +109,13 @@ class FixedSparsityMerging:
         order_valid = 1 if sc.order_valid_for == order_key else 0
         if sc.dirty:
             sc.ws.zero_()
+            sc.stats.zero_()
             sc.dirty = False
         sc.seq += 1
         seq = sc.seq
         sc.dirty = True
         _lib.check(lib.ff_merge_begin(hidden.data_ptr(), code, L, d, ptype.data_ptr(), int(self.patch_num), order_valid,
-                                      0.0, sc.order.data_ptr(), sc.sim32.data_ptr(), sc.stats.data_ptr(), seq,
+                                      0.0, sc.order.data_ptr(), sc.sim32.data_ptr(), sc.stats.data_ptr(), seq, 0, 0,
                                       sc.ws.data_ptr(), sc.ws_bytes, stream), "ff_merge_begin")
 
         out = torch.empty(1, L, d, dtype=dtype, device=device)

@@ -15,8 +15,8 @@ int launch_merge_compact(const void* hidden, void* hidden_out, int dtype, int64_
                          const uint8_t* keep, const ff_aux_t* aux_host, int n_aux, int32_t* order_next,
                          int64_t* stats, hipStream_t st);
 int launch_similarity_any(const void* hidden, int dtype, int64_t L, int64_t d, const int64_t* ptype,
-                          const int32_t* order, const int64_t* stats, void* sim, int* l0, double thr,
-                          hipStream_t st);
+                          int32_t* order, int64_t* stats, void* sim, int* l0, double thr,
+                          int64_t hint_pre, int64_t hint_patches, int64_t hint_frames, hipStream_t st);
 }  // namespace ff
 
 extern "C" int ff_abi_version(void) { return FF_ABI_VERSION; }
@@ -41,21 +41,25 @@ extern "C" size_t ff_workspace_bytes(int64_t L, int64_t patch_num) {
 
 extern "C" int ff_merge_begin(const void* hidden, int dtype, int64_t L, int64_t d, const int64_t* patch_type,
                               int64_t patch_num, int order_valid, double threshold, int32_t* order, void* sim,
-                              int64_t* stats, int64_t seq, void* ws, size_t ws_bytes, ff_stream_t stream) {
+                              int64_t* stats, int64_t seq, int64_t hint_pre, int64_t hint_frames, void* ws,
+                              size_t ws_bytes, ff_stream_t stream) {
     if (!hidden || !patch_type || !order || !sim || !stats || !ws) return FF_ERR_ARG;
     if (ws_bytes < ff_workspace_bytes(L, patch_num)) return FF_ERR_WORKSPACE;
     if (dtype != FF_F32 && dtype != FF_BF16 && dtype != FF_F16) return FF_ERR_ARG;
     const int64_t esz = dtype == FF_F32 ? 4 : 2;
     if (((uintptr_t)hidden & 15) || ((d * esz) & 15) || ((uintptr_t)ws & 15)) return FF_ERR_ALIGN;
     if (L >= (1ll << 31) || d * esz >= (1ll << 31)) return FF_ERR_UNSUPPORTED;
-    if (!order_valid) {
+    // frame-major hint: the similarity kernel derives (and verifies) the order itself, K0 is skipped
+    const bool hinted = !order_valid && hint_frames > 0 && hint_pre >= 0 && patch_num >= 1 &&
+                        hint_pre + hint_frames * patch_num <= L;
+    if (!order_valid && !hinted) {
         int rc = ff_build_order(patch_type, L, patch_num, order, stats, ws, ws_bytes, stream);
         if (rc) return rc;
     }
     if (L == 0) return FF_OK;
     // the similarity kernel also accumulates the level-0 select statistics of this call
     return ff::launch_similarity_any(hidden, dtype, L, d, patch_type, order, stats, sim, ff::ws_l0_copies(ws, seq),
-                                     threshold, (hipStream_t)stream);
+                                     threshold, hint_pre, patch_num, hinted ? hint_frames : 0, (hipStream_t)stream);
 }
 
 // second half of a merge call: select (policy or forced k) + run merge (fold 1: main.py's sequential
@@ -109,7 +113,7 @@ extern "C" int ff_merge_step(const void* hidden, void* hidden_out, int dtype, in
                              int64_t seq, const ff_aux_t* aux_host, int n_aux, void* ws, size_t ws_bytes,
                              ff_stream_t stream) {
     int rc = ff_merge_begin(hidden, dtype, L, d, patch_type, patch_num, order_valid, threshold, order, sim, stats,
-                            seq, ws, ws_bytes, stream);
+                            seq, 0, 0, ws, ws_bytes, stream);
     if (rc) return rc;
     return ff_merge_finish(hidden, hidden_out, dtype, L, d, L_cap, threshold, sub, ratio_lb, order, sim, member, dst,
                            keep, stats, stats_host_mapped, seq, aux_host, n_aux, nullptr, ws, ws_bytes, stream);

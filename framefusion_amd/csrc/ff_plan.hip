@@ -457,10 +457,11 @@ constexpr int kScanSpan = kScanThreads * kEpt;     // 4096 positions per workgro
 
 // Copy of the result block into device-visible pinned host memory: one lane per word (a single
 // store instruction crosses PCIe once), a system fence, then the sequence word the host polls.
-__device__ inline void publish(const int64_t* __restrict__ stats, int64_t* host_mapped, int64_t seq) {
+__device__ inline void publish(int64_t* __restrict__ stats, int64_t* host_mapped, int64_t seq) {
     const int lane = threadIdx.x;          // called by wave 0
     if (lane < FF_STAT_WORDS && lane != FF_STAT_SEQ)
         __hip_atomic_store(&host_mapped[lane], stats[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (lane == FF_STAT_ERROR) stats[lane] = 0;     // reported; the next call starts clean
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     if (lane == 0) __hip_atomic_store(&host_mapped[FF_STAT_SEQ], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }

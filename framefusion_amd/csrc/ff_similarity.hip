@@ -19,26 +19,83 @@
 
 namespace ff {
 
-template <int DT, int kPairs, int kSimThreads>
+// Frame-major layout the host expects from FrameFusion.prepare()'s scalars: `frames` frames of
+// `patches` visual tokens behind `pre` other tokens, every frame typed 0..patches-1, everything else
+// TEXT.  With a hint the similarity kernel computes the by-patch order in closed form
+// (order[p*F + f] = pre + f*P + p) instead of waiting for the order kernels, WRITES `order` and the
+// stats words K0 would have written, and verifies the hint on the way: every position is compared
+// with its expected type by exactly one lane.  A mismatch sets bit FF_ERR_BIT_LAYOUT of
+// stats[FF_STAT_ERROR]; the host then repeats the call through K0.
+struct LayoutHint {
+    int pre, patches, frames, L;
+};
+
+template <int DT, int kPairs, int kSimThreads, bool kHint>
 __global__ __launch_bounds__(kSimThreads) void k_pair_similarity(
     const char* __restrict__ hidden, uint32_t row_bytes, const int64_t* __restrict__ ptype,
     const int32_t* __restrict__ order, const int64_t* __restrict__ stats, void* __restrict__ sim,
-    int* __restrict__ l0, float thr) {
+    int* __restrict__ l0, float thr, const LayoutHint hint, int32_t* __restrict__ order_out,
+    int64_t* __restrict__ stats_out) {
     using A = Act<DT>;
     constexpr int E = A::kPer16;
     constexpr int R = kPairs + 1;
     constexpr int kSimWaves = kSimThreads / kWave;
-    const int nv = (int)stats[FF_STAT_NV];
     const int lane = lane_id();
+    int nv;
+    if constexpr (kHint) {
+        nv = hint.patches * hint.frames;
+        // the non-visual tail of `order` (positions in sequence order) + their type check
+        const int n_tail = hint.L - nv;
+        const int gtid = blockIdx.x * kSimThreads + threadIdx.x;
+        for (int q = gtid; q < n_tail; q += (int)gridDim.x * kSimThreads) {
+            const int i = q < hint.pre ? q : q + nv;
+            if (ptype[i] != -1) atomicOr((unsigned long long*)(stats_out + FF_STAT_ERROR), (unsigned long long)FF_ERR_BIT_LAYOUT);
+            order_out[nv + q] = i;
+        }
+        if (gtid == 0) {
+            stats_out[FF_STAT_NV] = nv;
+            stats_out[FF_STAT_FTN] = nv;
+        }
+    } else {
+        nv = (int)stats[FF_STAT_NV];
+    }
     const int j0 = uniform((blockIdx.x * kSimWaves + wave_id()) * kPairs);
     if (j0 >= nv) return;
 
     __amdgpu_buffer_rsrc_t row[R];
+    int slot_i[kPairs], slot_p[kPairs], slot_f[kPairs];       // kHint: position / type / frame of slot j0+r
+    int64_t my_type = 0;
+    if constexpr (kHint) {
+        const int F = hint.frames, P = hint.patches;
+        const int p0 = uniform(j0 / F), f0 = j0 - p0 * F;
+        {   // row 0 = slot j0-1 (slot 0 again when j0 == 0)
+            int pm = p0, fm = f0 - 1;
+            if (fm < 0) { fm = F - 1; pm = p0 - 1; }
+            if (j0 == 0) { pm = 0; fm = 0; }
+            row[0] = make_rsrc(hidden + (int64_t)(hint.pre + fm * P + pm) * row_bytes, row_bytes);
+        }
+        int p = p0, f = f0, last_i = hint.pre + f0 * P + p0;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        int j = j0 - 1 + r;
-        j = j < 0 ? 0 : (j >= nv ? nv - 1 : j);
-        row[r] = make_rsrc(hidden + (int64_t)uniform(order[j]) * row_bytes, row_bytes);
+        for (int r = 0; r < kPairs; ++r) {
+            const bool in = j0 + r < nv;
+            const int i = in ? hint.pre + f * P + p : last_i;
+            slot_i[r] = i; slot_p[r] = p; slot_f[r] = f;
+            last_i = i;
+            row[r + 1] = make_rsrc(hidden + (int64_t)i * row_bytes, row_bytes);
+            if (++f == F) { f = 0; ++p; }
+        }
+        // type of my slot, requested now so that the check at the end finds it in a register
+        int my_i = slot_i[0];
+#pragma unroll
+        for (int r = 1; r < kPairs; ++r) my_i = lane == r ? slot_i[r] : my_i;
+        if (lane < kPairs) my_type = ptype[my_i];
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            int j = j0 - 1 + r;
+            j = j < 0 ? 0 : (j >= nv ? nv - 1 : j);
+            row[r] = make_rsrc(hidden + (int64_t)uniform(order[j]) * row_bytes, row_bytes);
+        }
     }
 
     float nrm[R], dot[kPairs];
@@ -89,7 +146,16 @@ __global__ __launch_bounds__(kSimThreads) void k_pair_similarity(
             const int j = j0 + r;
             if (j < nv) {
                 float s = -2.0f;   // IGNORE_TOKEN (main.py:225-238)
-                if (j > 0 && ptype[order[j - 1]] == ptype[order[j]]) {
+                bool same_type;
+                if constexpr (kHint) {
+                    if (my_type != (int64_t)slot_p[r])
+                        atomicOr((unsigned long long*)(stats_out + FF_STAT_ERROR), (unsigned long long)FF_ERR_BIT_LAYOUT);
+                    order_out[j] = slot_i[r];
+                    same_type = slot_f[r] != 0;            // the previous slot is the same patch one frame earlier
+                } else {
+                    same_type = j > 0 && ptype[order[j - 1]] == ptype[order[j]];
+                }
+                if (same_type) {
                     const float d = A::rnd(dot[r]);
                     const float na = A::rnd(sqrtf(nrm[r]));
                     const float nb = A::rnd(sqrtf(nrm[r + 1]));
@@ -129,27 +195,43 @@ __global__ __launch_bounds__(kSimThreads) void k_pair_similarity(
     }
 }
 
+struct SimArgs {
+    const void* hidden;
+    int64_t L, d;
+    const int64_t* ptype;
+    const int32_t* order;
+    const int64_t* stats;
+    void* sim;
+    int* l0;
+    float thr;
+    LayoutHint hint;          // frames == 0: no hint
+    int32_t* order_out;
+    int64_t* stats_out;
+};
+
 template <int DT, int kPairs, int kSimThreads>
-static int launch_similarity_pt(const void* hidden, int64_t L, int64_t d, const int64_t* ptype,
-                                const int32_t* order, const int64_t* stats, void* sim, int* l0, float thr,
-                                hipStream_t st) {
-    const int64_t row_bytes = d * Act<DT>::kBytes;
+static int launch_similarity_pt(const SimArgs& a, hipStream_t st) {
+    const int64_t row_bytes = a.d * Act<DT>::kBytes;
     const int64_t per_block = (int64_t)(kSimThreads / kWave) * kPairs;
-    const int64_t blocks = (L + per_block - 1) / per_block;
-    hipLaunchKernelGGL((k_pair_similarity<DT, kPairs, kSimThreads>), dim3((unsigned)blocks), dim3(kSimThreads), 0, st,
-                       (const char*)hidden, (uint32_t)row_bytes, ptype, order, stats, sim, l0, thr);
+    const int64_t blocks = (a.L + per_block - 1) / per_block;
+    if (a.hint.frames > 0)
+        hipLaunchKernelGGL((k_pair_similarity<DT, kPairs, kSimThreads, true>), dim3((unsigned)blocks), dim3(kSimThreads), 0,
+                           st, (const char*)a.hidden, (uint32_t)row_bytes, a.ptype, a.order, a.stats, a.sim, a.l0, a.thr,
+                           a.hint, a.order_out, a.stats_out);
+    else
+        hipLaunchKernelGGL((k_pair_similarity<DT, kPairs, kSimThreads, false>), dim3((unsigned)blocks), dim3(kSimThreads), 0,
+                           st, (const char*)a.hidden, (uint32_t)row_bytes, a.ptype, a.order, a.stats, a.sim, a.l0, a.thr,
+                           a.hint, (int32_t*)nullptr, (int64_t*)nullptr);
     return (int)hipGetLastError();
 }
 
 template <int DT, int kPairs>
-static int launch_similarity_p(const void* hidden, int64_t L, int64_t d, const int64_t* ptype,
-                               const int32_t* order, const int64_t* stats, void* sim, int* l0, float thr,
-                               hipStream_t st) {
+static int launch_similarity_p(const SimArgs& a, hipStream_t st) {
     static int waves = 0;
     if (!waves) { const char* e = getenv("FF_SIM_WAVES"); waves = e ? atoi(e) : 4; }
-    if (waves == 8) return launch_similarity_pt<DT, kPairs, 512>(hidden, L, d, ptype, order, stats, sim, l0, thr, st);
-    if (waves == 2) return launch_similarity_pt<DT, kPairs, 128>(hidden, L, d, ptype, order, stats, sim, l0, thr, st);
-    return launch_similarity_pt<DT, kPairs, 256>(hidden, L, d, ptype, order, stats, sim, l0, thr, st);
+    if (waves == 8) return launch_similarity_pt<DT, kPairs, 512>(a, st);
+    if (waves == 2) return launch_similarity_pt<DT, kPairs, 128>(a, st);
+    return launch_similarity_pt<DT, kPairs, 256>(a, st);
 }
 
 static int tune_pairs() {
@@ -162,23 +244,24 @@ static int tune_pairs() {
 }
 
 template <int DT>
-static int launch_similarity(const void* hidden, int64_t L, int64_t d, const int64_t* ptype,
-                             const int32_t* order, const int64_t* stats, void* sim, int* l0, float thr,
-                             hipStream_t st) {
+static int launch_similarity(const SimArgs& a, hipStream_t st) {
     switch (tune_pairs()) {
-        case 2: return launch_similarity_p<DT, 2>(hidden, L, d, ptype, order, stats, sim, l0, thr, st);
-        case 8: return launch_similarity_p<DT, 8>(hidden, L, d, ptype, order, stats, sim, l0, thr, st);
-        default: return launch_similarity_p<DT, 4>(hidden, L, d, ptype, order, stats, sim, l0, thr, st);
+        case 2: return launch_similarity_p<DT, 2>(a, st);
+        case 8: return launch_similarity_p<DT, 8>(a, st);
+        default: return launch_similarity_p<DT, 4>(a, st);
     }
 }
 
+// hint_frames > 0: frame-major closed form (see LayoutHint); `order` and `stats` are then outputs.
 int launch_similarity_any(const void* hidden, int dtype, int64_t L, int64_t d, const int64_t* ptype,
-                          const int32_t* order, const int64_t* stats, void* sim, int* l0, double thr,
-                          hipStream_t st) {
+                          int32_t* order, int64_t* stats, void* sim, int* l0, double thr,
+                          int64_t hint_pre, int64_t hint_patches, int64_t hint_frames, hipStream_t st) {
+    SimArgs a{hidden, L, d, ptype, order, stats, sim, l0, (float)thr,
+              LayoutHint{(int)hint_pre, (int)hint_patches, (int)hint_frames, (int)L}, order, stats};
     switch (dtype) {
-        case FF_F32: return launch_similarity<FF_F32>(hidden, L, d, ptype, order, stats, sim, l0, (float)thr, st);
-        case FF_BF16: return launch_similarity<FF_BF16>(hidden, L, d, ptype, order, stats, sim, l0, (float)thr, st);
-        default: return launch_similarity<FF_F16>(hidden, L, d, ptype, order, stats, sim, l0, (float)thr, st);
+        case FF_F32: return launch_similarity<FF_F32>(a, st);
+        case FF_BF16: return launch_similarity<FF_BF16>(a, st);
+        default: return launch_similarity<FF_F16>(a, st);
     }
 }
 
@@ -193,6 +276,6 @@ extern "C" int ff_pair_similarity(const void* hidden, int dtype, int64_t L, int6
     if (((uintptr_t)hidden & 15) || ((d * esz) & 15)) return FF_ERR_ALIGN;
     if (L >= (1ll << 31) || d * esz >= (1ll << 31)) return FF_ERR_UNSUPPORTED;
     if (L == 0) return FF_OK;
-    return ff::launch_similarity_any(hidden, dtype, L, d, patch_type, order, stats, sim, nullptr, 0.0,
-                                     (hipStream_t)stream);
+    return ff::launch_similarity_any(hidden, dtype, L, d, patch_type, const_cast<int32_t*>(order),
+                                     const_cast<int64_t*>(stats), sim, nullptr, 0.0, 0, 0, 0, (hipStream_t)stream);
 }

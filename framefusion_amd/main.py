@@ -115,6 +115,26 @@ class FrameFusion(nn.Module):
         self.sparsity_list = [] if sparsity_list is None else sparsity_list
         for s in self._scratch.values():
             s.order_valid_for = None
+        self._layout_hint = self._frame_major_hint(patch_num, image_token_start_index, image_token_length)
+
+    @staticmethod
+    def _frame_major_hint(patch_num, start, length):
+        """(pre, frames) if the scalars describe whole frames of `patch_num` tokens starting at `start`
+        (the layout every packer of the reference builds), else None.  Only host values are looked at
+        (no device read-back); the similarity kernel verifies the hint against patch_type."""
+        def host_int(x):
+            if isinstance(x, torch.Tensor):
+                if x.is_cuda or x.numel() != 1:
+                    return None
+                x = x.reshape(-1)[0].item()
+            try:
+                return int(x) if float(x) == int(x) else None
+            except (TypeError, ValueError):
+                return None
+        P, pre, n = host_int(patch_num), host_int(start), host_int(length)
+        if P is None or pre is None or n is None or P < 1 or pre < 0 or n < P or n % P:
+            return None
+        return pre, n // P
 
     # ---- reference main.py:40-140 ------------------------------------------------------------
     def forward(self, hidden_states, position_embeddings, attention_mask, self_attn_weights=None):
@@ -207,7 +227,7 @@ class FrameFusion(nn.Module):
     def _merge(self, hidden_states, position_embeddings, attention_mask):
         return self._merge_complete(self._merge_launch(hidden_states, position_embeddings, attention_mask))
 
-    def _merge_launch(self, hidden_states, position_embeddings, attention_mask):
+    def _merge_launch(self, hidden_states, position_embeddings, attention_mask, use_hint=True):
         """Enqueue the whole merge call on the current stream and return without waiting: the
         state machine is advanced by _merge_complete.  (batch.forward_many launches several
         samples on their own streams before completing any of them.)"""
@@ -239,13 +259,20 @@ class FrameFusion(nn.Module):
         thr = self._threshold_for(dtype)
         if sc.dirty:                 # restore the workspace protocol (zeroed tables, fresh parity)
             sc.ws.zero_()
+            sc.stats.zero_()
             sc.dirty = False
         sc.seq += 1
         seq = sc.seq
         sc.dirty = True              # cleared once ff_merge_finish has been enqueued
+        # first call of a prefill: hand the frame-major layout the prepare() scalars describe to the
+        # similarity kernel, which derives and verifies the by-patch order itself (no K0 launch)
+        hint = getattr(self, "_layout_hint", None) if (use_hint and not order_valid) else None
+        if hint is not None and hint[0] + hint[1] * int(self.patch_num) > L:
+            hint = None
+        hint_pre, hint_frames = hint if hint is not None else (0, 0)
         rc = lib.ff_merge_begin(hidden.data_ptr(), code, L, d, ptype.data_ptr(), int(self.patch_num), order_valid,
-                                thr, sc.order.data_ptr(), sim_ptr, sc.stats.data_ptr(), seq, sc.ws.data_ptr(),
-                                sc.ws_bytes, stream)
+                                thr, sc.order.data_ptr(), sim_ptr, sc.stats.data_ptr(), seq, hint_pre, hint_frames,
+                                sc.ws.data_ptr(), sc.ws_bytes, stream)
         _lib.check(rc, "ff_merge_begin")
 
         L_cap = L
@@ -267,7 +294,8 @@ class FrameFusion(nn.Module):
             mask_out = self._gather_mask(attention_mask, L, L_cap, sc.dst, stream)
 
         return dict(sc=sc, seq=seq, L=L, dtype=dtype, out=out, ptype_out=ptype_out, rebuild=rebuild,
-                    mask_out=mask_out)
+                    mask_out=mask_out, hinted=hint is not None,
+                    inputs=(hidden_states, position_embeddings, attention_mask))
 
     def _merge_complete(self, pending):
         sc, seq, L, dtype = pending["sc"], pending["seq"], pending["L"], pending["dtype"]
@@ -277,6 +305,15 @@ class FrameFusion(nn.Module):
         # pinned host memory (sequence word last) BEFORE the merge kernel runs, so the host learns
         # L_out while the second streaming pass is still in flight and returns without waiting for it.
         st = sc.wait_stats(seq)
+        if int(st[_lib.STAT_ERROR]) & _lib.ERR_BIT_LAYOUT:
+            # patch_type is not the frame-major layout the prepare() scalars suggested (e.g. text
+            # between the frames): everything this call enqueued is void.  Repeat it through K0 and
+            # stop hinting for this prefill.
+            assert pending["hinted"]
+            self._layout_hint = None
+            sc.dirty = True
+            sc.order_valid_for = None
+            return self._merge_complete(self._merge_launch(*pending["inputs"], use_hint=False))
         nv, ftn, count = int(st[_lib.STAT_NV]), int(st[_lib.STAT_FTN]), int(st[_lib.STAT_COUNT])
         L_out = int(st[_lib.STAT_LOUT])
         branch = int(st[_lib.STAT_BRANCH])

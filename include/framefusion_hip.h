@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FF_ABI_VERSION 1
+#define FF_ABI_VERSION 2
 
 enum { FF_F32 = 0, FF_BF16 = 1, FF_F16 = 2 };
 
@@ -55,10 +55,16 @@ enum {
     FF_STAT_KTH_KEY = 8,   /* debug: order-preserving key of the k-th largest similarity          */
     FF_STAT_TIES_TAKEN = 9,/* debug: entries equal to the k-th value that were selected           */
     FF_STAT_SEQ = 10,      /* sequence number, copied from the call (host polling)                */
-    FF_STAT_ERROR = 11,    /* nonzero: a device-side consistency check failed (grid barrier timeout) */
+    FF_STAT_ERROR = 11,    /* bit mask of device-side checks that failed, FF_ERR_BIT_*; cleared once published */
     FF_STAT_T_ORDER = 16,  /* 2 words: shader-clock cycles of K0's second launch (diagnostics)    */
     FF_STAT_T_PLAN = 24,   /* reserved for plan-kernel diagnostics                                */
     FF_STAT_WORDS = 32
+};
+
+enum {
+    FF_ERR_BIT_BARRIER = 1,  /* a grid barrier of the fused plan kernel timed out                    */
+    FF_ERR_BIT_LAYOUT = 2    /* the frame-major layout hint of ff_merge_begin does not describe
+                                patch_type: the call's outputs are meaningless, repeat it unhinted  */
 };
 
 typedef void* ff_stream_t; /* hipStream_t */
@@ -234,12 +240,21 @@ int ff_merge_step(const void* hidden, void* hidden_out, int dtype, int64_t L, in
  * SAME zero-initialised workspace for every call of a sequence and `seq` must increase by one per
  * call: the similarity kernel accumulates the select's level-0 statistics into the table of parity
  * (seq & 1) and the scan kernel of the call clears the other table for the next call.
+ * Layout hint (hint_frames > 0, only looked at when order_valid == 0): the caller expects the
+ * frame-major layout the reference's packers produce - hint_frames frames of patch_num visual
+ * tokens typed 0..patch_num-1 behind hint_pre other tokens, TEXT (-1) everywhere else
+ * (llava_video/modeling_llava_video.py:335).  The similarity kernel then computes the by-patch
+ * order in closed form, writes `order` / stats[NV] / stats[FTN] itself and K0 is not launched;
+ * every position's type is verified on the way and a mismatch sets FF_ERR_BIT_LAYOUT in
+ * stats[FF_STAT_ERROR] (published with the stats block): the caller discards the call's outputs,
+ * zeroes the workspace and repeats the call with hint_frames = 0.
  * order_next (optional, [L] int32): receives the by-patch order of the COMPACTED sequence and
  * stats[NV]/stats[FTN] are advanced to it, so the next merge call on the reduced sequence can pass
  * it as `order` with order_valid = 1 and skip K0 (surviving tokens keep their relative order). */
 int ff_merge_begin(const void* hidden, int dtype, int64_t L, int64_t d,
                    const int64_t* patch_type, int64_t patch_num, int order_valid, double threshold,
-                   int32_t* order, void* sim, int64_t* stats, int64_t seq, void* ws, size_t ws_bytes,
+                   int32_t* order, void* sim, int64_t* stats, int64_t seq,
+                   int64_t hint_pre, int64_t hint_frames, void* ws, size_t ws_bytes,
                    ff_stream_t stream);
 int ff_merge_finish(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
                     double threshold, double sub, double ratio_lb,

@@ -411,3 +411,95 @@ def test_determinism():
         outs.append((o.cpu(), p.cpu()))
     for o, p in outs[1:]:
         assert same_bits(o, outs[0][0]) and torch.equal(p, outs[0][1])
+
+
+# ---------------------------------------------------------------------------------------------
+# layout hint: closed-form by-patch order inside the similarity kernel, verified on the device
+# ---------------------------------------------------------------------------------------------
+def one_call(pt, P, start, length, h, cost=0.3, thr=0.6, lb=0.1):
+    L = h.shape[1]
+    f = ffa.FrameFusion(cost, thr, lb)
+    f.prepare(dev(pt), P, start, start + length - 1, length, L)
+    o = orc.OracleFrameFusion(cost, thr, lb)
+    o.prepare(pt.clone(), P, start, start + length - 1, length, L)
+    hg, pg, _ = f(dev(h), dev(torch.arange(L)[None]), None)
+    ho, po, _ = o.forward(h, torch.arange(L)[None], None)
+    return f, o, (hg, pg), (ho, po)
+
+
+@pytest.mark.parametrize("F,P,pre,post", [(9, 16, 3, 5), (5, 33, 0, 0), (64, 7, 11, 0), (3, 300, 0, 2), (1, 8, 2, 2)])
+def test_layout_hint_gives_the_order_k0_builds(F, P, pre, post):
+    h, pt = video_tokens(F, P, 64, p_change=0.4, sigma=0.3, seed=21, pre=pre, post=post, grid=0.125)
+    f, o, (hg, pg), (ho, po) = one_call(pt, P, pre, F * P, h)
+    assert f._layout_hint == (pre, F)
+    assert torch.equal(pg.cpu(), po) and same_bits(hg.cpu(), ho)
+    assert (f.finish_merging, f.finish_pruning, f.sparsity_list) == (o.finish_merging, o.finish_pruning, o.sparsity_list)
+    L = h.shape[1]
+    fresh, stats = hip_order(pt, P)                       # what K0 computes for the same row
+    sc = f.last_call["scratch"]
+    assert torch.equal(f.last_call["order"][:L].cpu().long(), fresh)
+    assert f.last_call["nv"] == F * P == int(stats[_lib.STAT_NV]) and f.last_call["ftn"] == int(stats[_lib.STAT_FTN])
+    assert torch.equal(f.last_plan()["sim"].cpu().float(), o.last_sim[0].float())
+    assert int(sc.stats[_lib.STAT_ERROR]) == 0
+
+
+def test_layout_hint_mismatch_falls_back_to_k0():
+    """prepare() scalars that suggest whole frames while patch_type says otherwise: the device flags
+    the mismatch, the call is repeated through K0 and the result is the reference's."""
+    F, P, d = 6, 10, 64
+    h, pt = video_tokens(F, P, d, p_change=0.4, sigma=0.3, seed=8, pre=4, post=6, grid=0.125)
+    L = h.shape[1]
+    variants = {}
+    a = pt.clone(); a[0, 4 + 2 * P + 3] = -1                      # a text token inside a frame
+    variants["hole"] = a
+    b = pt.clone(); b[0, 1] = 5                                   # a visual token in front of the hinted range
+    variants["stray_before"] = b
+    c = pt.clone(); c[0, L - 2] = 0                               # ... and behind it
+    variants["stray_after"] = c
+    e = pt.clone(); e[0, 4:4 + P] = torch.arange(P).flip(0)       # first frame typed backwards
+    variants["permuted_frame"] = e
+    g = pt.clone(); g[0, 4 + P] = P + 3                           # an out-of-range type (non-text, non-visual)
+    variants["foreign_type"] = g
+    for name, row in variants.items():
+        f, o, (hg, pg), (ho, po) = one_call(row, P, 4, F * P, h)
+        assert f._layout_hint is None, name                        # stopped hinting for this prefill
+        assert torch.equal(pg.cpu(), po) and same_bits(hg.cpu(), ho), name
+        assert torch.equal(f.patch_type.cpu(), o.patch_type), name
+        fresh, stats = hip_order(row, P)
+        assert f.last_call["nv"] == int(stats[_lib.STAT_NV]) and f.last_call["ftn"] == int(stats[_lib.STAT_FTN]), name
+        sc = f.last_call["scratch"]
+        assert int(sc.stats[_lib.STAT_ERROR]) == 0, name           # published and cleared
+        # the instance keeps working: a second prefill with a correct row is hinted again
+        f.prepare(dev(pt), P, 4, 4 + F * P - 1, F * P, L)
+        assert f._layout_hint == (4, F)
+        hg2, pg2, _ = f(dev(h), dev(torch.arange(L)[None]), None)
+        o2 = orc.OracleFrameFusion(0.3, 0.6, 0.1)
+        o2.prepare(pt.clone(), P, 4, 4 + F * P - 1, F * P, L)
+        ho2, po2, _ = o2.forward(h, torch.arange(L)[None], None)
+        assert torch.equal(pg2.cpu(), po2) and same_bits(hg2.cpu(), ho2), name
+
+
+def test_layout_hint_is_only_taken_from_host_scalars():
+    F, P = 5, 12
+    h, pt = video_tokens(F, P, 64, p_change=0.4, sigma=0.3, seed=2, pre=3, post=3, grid=0.125)
+    L = h.shape[1]
+    f = ffa.FrameFusion(0.3, 0.6, 0.1)
+    f.prepare(dev(pt), P, torch.tensor([3], device=DEV), torch.tensor([3 + F * P - 1], device=DEV), F * P, L)
+    assert f._layout_hint is None                                  # no device read-back just for a hint
+    f.prepare(dev(pt), P, torch.tensor([3]), torch.tensor(3 + F * P - 1), torch.tensor(F * P), L)
+    assert f._layout_hint == (3, F)                                # 0-d / 1-element CPU tensors are fine
+    f.prepare(dev(pt), float(P), 3, 3 + F * P - 1, F * P, L)
+    assert f._layout_hint == (3, F)                                # nvila hands patch_num over as a float
+    f.prepare(dev(pt), P, 3, 0, F * P + 1, L)
+    assert f._layout_hint is None                                  # not whole frames
+    f.prepare(dev(pt), P, 3, 0, F * P, L)
+    hg, pg, _ = f(dev(h), dev(torch.arange(L)[None]), None)
+    o = orc.OracleFrameFusion(0.3, 0.6, 0.1)
+    o.prepare(pt.clone(), P, 3, 0, F * P, L)
+    ho, po, _ = o.forward(h, torch.arange(L)[None], None)
+    assert torch.equal(pg.cpu(), po) and same_bits(hg.cpu(), ho)
+    # a hint that does not fit the sequence is dropped on the host
+    f.prepare(dev(pt), P, 3, 0, (F + 2) * P, L)
+    assert f._layout_hint == (3, F + 2)
+    hg, pg, _ = f(dev(h), dev(torch.arange(L)[None]), None)
+    assert torch.equal(pg.cpu(), po) and same_bits(hg.cpu(), ho)
