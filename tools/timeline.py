@@ -11,18 +11,23 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 def short(n):
     n = n.replace("void ", "")
     return n.split("<")[0].split("(")[0].replace("ff::", "")
+# a call = a maximal run of kernels ending with k_merge_compact; the product's merge call is either
+# K0 (two launches) + similarity + hist + flags + scan + merge, or - with a layout hint - starts at
+# the similarity kernel
 calls = []
 cur = []
 for r in rows:
     k = short(r["Kernel_Name"])
-    if k == "k_order_stats" and cur:
+    cur.append((k, int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+    if k == "k_merge_compact":
         calls.append(cur)
         cur = []
-    cur.append((k, int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
-if cur:
-    calls.append(cur)
-want = ["k_order_stats", "k_build_order", "k_pair_similarity", "k_hist_level", "k_flags", "k_scan", "k_merge_compact"]
-calls = [c for c in calls if [k for k, _, _ in c] == want][5:]
+tail = ["k_pair_similarity", "k_hist_level", "k_flags", "k_scan", "k_merge_compact"]
+shapes = [["k_order_stats", "k_build_order"] + tail, tail]
+calls = [c for c in calls if [k for k, _, _ in c] in shapes]
+if calls:
+    common = max(shapes, key=lambda sh: sum([k for k, _, _ in c] == sh for c in calls))
+    calls = [c for c in calls if [k for k, _, _ in c] == common][5:]
 dur = defaultdict(list)
 gap = defaultdict(list)
 span = []
