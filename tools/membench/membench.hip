@@ -76,6 +76,42 @@ __global__ void k_read_rows(const char* __restrict__ base, int n_rows, int row_b
     if (acc.x == 0x12345678u && acc.y == 0x9abcdef0u) sink[0] = acc;
 }
 
+
+// pattern 2: a wave owns NR consecutive by-patch rows and streams them ONE AFTER THE OTHER (a single
+// sequential stream per wave, DEPTH tiles in flight) - the shape of a similarity kernel that keeps
+// the previous row in registers instead of reading R rows side by side
+template <int NR, int DEPTH>
+__global__ void k_read_seq(const char* __restrict__ base, int n_rows, int row_bytes, int row_stride, int overlap,
+                           uint4* __restrict__ sink) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int g0 = wave * (NR - overlap);
+    if (g0 >= n_rows) return;
+    const int F = row_stride, P = n_rows / row_stride;
+    const int tiles = row_bytes >> 10;
+    const int total = NR * tiles;
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    uint4 buf[DEPTH];
+    auto addr = [&](int it) {
+        int r = it / tiles, t = it - r * tiles;
+        int j = g0 + r; if (j >= n_rows) j = n_rows - 1;
+        const int pp = j / F, f = j - pp * F;
+        return base + (size_t)(f * P + pp) * row_bytes + t * 1024 + lane * 16;
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) buf[d] = *(const uint4*)addr(d < total ? d : total - 1);
+    for (int it = 0; it < total; it += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const uint4 v = buf[d];
+            const int nx = it + d + DEPTH;
+            buf[d] = *(const uint4*)addr(nx < total ? nx : total - 1);
+            acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
+        }
+    }
+    if (acc.x == 0x12345678u && acc.y == 0x9abcdef0u) sink[0] = acc;
+}
+
 template <class F>
 static float time_us(F f, int reps) {
     hipEvent_t a, b;
@@ -113,5 +149,11 @@ int main(int argc, char** argv) {
         printf("rows  R=%d pf=%d tpb=%4d blocks=%6d : %7.1f us  %7.1f GB/s\n", R, PF, TPB, blocks, us, (double)n_rows * row_bytes / us / 1e3); }
     ROWSP(5, 256, 0) ROWSP(4, 256, 0) ROWSP(3, 256, 0) ROWSP(2, 256, 0) ROWSP(1, 256, 0) ROWSP(5, 512, 0) ROWSP(5, 128, 0) ROWSP(3, 256, 1) ROWSP(9, 256, 0) ROWSP(9, 256, 1)
     ROWS(1, 256) ROWS(2, 256) ROWS(4, 256) ROWS(5, 256) ROWS(8, 256) ROWS(4, 128) ROWS(4, 512) ROWS(2, 512)
+#define SEQ(NR, DEPTH, TPB, OV) { \
+        const int waves = (n_rows + (NR - OV) - 1) / (NR - OV), blocks = (waves * 64 + TPB - 1) / TPB; \
+        float us = time_us([&] { flip ^= 1; hipLaunchKernelGGL((k_read_seq<NR, DEPTH>), dim3(blocks), dim3(TPB), 0, 0, (const char*)(flip ? a : b), n_rows, row_bytes, F, OV, sink); }, 10); \
+        printf("seq   NR=%2d depth=%d tpb=%4d ov=%d blocks=%6d : %7.1f us  %7.1f GB/s (unique bytes)\n", NR, DEPTH, TPB, OV, blocks, us, (double)n_rows * row_bytes / us / 1e3); }
+    SEQ(4, 2, 256, 0) SEQ(8, 2, 256, 0) SEQ(16, 2, 256, 0) SEQ(8, 4, 256, 0) SEQ(16, 4, 256, 0) SEQ(8, 2, 64, 0) SEQ(16, 4, 64, 0) SEQ(16, 8, 64, 0)
+    SEQ(5, 2, 256, 1) SEQ(9, 2, 256, 1) SEQ(17, 2, 256, 1) SEQ(9, 4, 256, 1) SEQ(17, 4, 256, 1) SEQ(9, 4, 64, 1) SEQ(17, 4, 64, 1) SEQ(17, 8, 64, 1) SEQ(33, 4, 64, 1) SEQ(33, 8, 64, 1)
     return 0;
 }
