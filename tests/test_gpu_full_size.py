@@ -192,3 +192,31 @@ def test_other_dtypes_cascade_exact(dt, p_change):
         assert (a["length"], a["finish_merging"], a["finish_pruning"], a["sparsity"]) == \
                (b["length"], b["finish_merging"], b["finish_pruning"], b["sparsity"]), a["tag"]
         assert same_bits(a["hidden"].cpu(), b["hidden"]), a["tag"]
+
+
+@pytest.mark.parametrize("p_change,pre", [(0.3, 9), (0.6, 0)])
+def test_very_long_sequence_exact(p_change, pre):
+    """~300 k tokens (512 frames x 576 patches, narrow rows): 72 slices of the select / flags / scan
+    kernels, by-patch runs up to hundreds of frames long, two merge calls (the second on the maintained
+    order).  Bit-exact against the oracle on the dyadic grid."""
+    F, P, d = 512, 576, 64
+    h, pt = video_tokens(F, P, d, p_change=p_change, sigma=0.3, seed=5, pre=pre, post=13, dtype=torch.bfloat16, grid=0.125)
+    L = h.shape[1]
+    o = orc.OracleFrameFusion(0.3, 0.6, 0.02)
+    o.prepare(pt.clone(), P, pre, pre + F * P - 1, F * P, L)
+    f = ffa.FrameFusion(0.3, 0.6, 0.02)
+    f.prepare(pt.to(DEV), P, pre, pre + F * P - 1, F * P, L)
+    ho, po = h, torch.arange(L)[None]
+    hg, pg = h.to(DEV), torch.arange(L, device=DEV)[None]
+    calls = 0
+    for layer in range(3):
+        if o.finish_merging:
+            break
+        ho, po, _ = o.forward(ho, po, None)
+        hg, pg, _ = f(hg, pg, None)
+        calls += 1
+        assert torch.equal(pg.cpu(), po), layer
+        assert same_bits(hg.cpu(), ho), layer
+        assert (f.finish_merging, f.finish_pruning, f.sparsity_list) == (o.finish_merging, o.finish_pruning, o.sparsity_list)
+        ho, hg = harness.layer_stub(ho, layer), harness.layer_stub(hg, layer)
+    assert calls >= 1 and ho.shape[1] < L
