@@ -13,7 +13,7 @@ int* ws_l0_copies(void* ws, int64_t seq);
 int launch_merge_compact(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
                          const int32_t* order, const uint8_t* member, int fold, const int32_t* dst,
                          const uint8_t* keep, const ff_aux_t* aux_host, int n_aux, int32_t* order_next,
-                         int64_t* stats, hipStream_t st);
+                         int64_t* stats, hipStream_t st, bool skip_identity);
 int launch_similarity_any(const void* hidden, int dtype, int64_t L, int64_t d, const int64_t* ptype,
                           int32_t* order, int64_t* stats, void* sim, int* l0, double thr,
                           int64_t hint_pre, int64_t hint_patches, int64_t hint_frames, hipStream_t st);
@@ -82,8 +82,9 @@ static int merge_finish(const void* hidden, void* hidden_out, int dtype, int64_t
                                    ff::ws_l0_copies(ws, seq), ff::ws_l0_copies(ws, seq + 1), stats_host_mapped, seq,
                                    (hipStream_t)stream, force_k);
     if (rc) return rc;
+    // when the select folds nothing the merge kernel exits at once: see ff_merge_finish in the header
     return ff::launch_merge_compact(hidden, hidden_out, dtype, L, d, L_cap, order, member, fold, dst, keep, aux_host,
-                                    n_aux, order_next, stats, (hipStream_t)stream);
+                                    n_aux, order_next, stats, (hipStream_t)stream, true);
 }
 
 extern "C" int ff_merge_finish(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,

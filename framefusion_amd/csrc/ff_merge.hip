@@ -76,10 +76,14 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
     const char* __restrict__ hidden, char* __restrict__ out, uint32_t row_bytes, int L, int64_t L_cap,
     const int32_t* __restrict__ order, const uint8_t* __restrict__ member, int fold,
     const int32_t* __restrict__ dst, const uint8_t* __restrict__ keep, AuxPack aux, int kSlots, int n_main,
-    int reverse, int n_aux_blocks, int32_t* __restrict__ order_next, int64_t* __restrict__ stats) {
+    int reverse, int n_aux_blocks, int32_t* __restrict__ order_next, int64_t* __restrict__ stats,
+    const int64_t* __restrict__ identity_stats) {
     using A = Act<DT>;
     constexpr int E = A::kPer16;
     const int lane = lane_id();
+    // nothing folded (a merge call whose threshold set is empty, main.py:264-266): the reduced
+    // sequence IS the input, the caller keeps using its own tensors and this launch writes nothing
+    if (identity_stats && identity_stats[FF_STAT_MERGED] == 0) return;
     if ((int)blockIdx.x >= n_main + n_aux_blocks) {
         // ---- by-patch order of the COMPACTED sequence, for the next merge call (order maintenance):
         // the surviving slots keep their relative by-patch order and dst[] is monotonic in the
@@ -275,12 +279,13 @@ template <int DT>
 static void launch_mc(dim3 grid, hipStream_t st, int depth, const char* h, char* o, uint32_t row_bytes, int L,
                       int64_t L_cap, const int32_t* order, const uint8_t* member, int fold, const int32_t* dst,
                       const uint8_t* keep, const AuxPack& pack, int slots, int n_main, int reverse,
-                      int n_aux_blocks, int32_t* order_next, int64_t* stats) {
+                      int n_aux_blocks, int32_t* order_next, int64_t* stats, const int64_t* identity_stats) {
     static int nt = -1;
     if (nt < 0) { const char* e = getenv("FF_MERGE_NT"); nt = e ? atoi(e) : 3; }
 #define FF_MC_LAUNCH(DEPTH, NT)                                                                                    \
     hipLaunchKernelGGL((k_merge_compact<DT, DEPTH, NT>), grid, dim3(kMergeThreads), 0, st, h, o, row_bytes, L, L_cap, \
-                       order, member, fold, dst, keep, pack, slots, n_main, reverse, n_aux_blocks, order_next, stats)
+                       order, member, fold, dst, keep, pack, slots, n_main, reverse, n_aux_blocks, order_next, stats, \
+                       identity_stats)
     if (depth == 8) { FF_MC_LAUNCH(8, 0); return; }
     switch (nt) {
         case 1: FF_MC_LAUNCH(4, 1); break;
@@ -294,7 +299,7 @@ static void launch_mc(dim3 grid, hipStream_t st, int depth, const char* h, char*
 int launch_merge_compact(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
                          const int32_t* order, const uint8_t* member, int fold, const int32_t* dst,
                          const uint8_t* keep, const ff_aux_t* aux_host, int n_aux, int32_t* order_next,
-                         int64_t* stats, hipStream_t st) {
+                         int64_t* stats, hipStream_t st, bool skip_identity) {
     AuxPack pack;
     pack.n = keep ? n_aux : 0;
     for (int x = 0; x < pack.n; ++x) pack.a[x] = aux_host[x];
@@ -318,10 +323,11 @@ int launch_merge_compact(const void* hidden, void* hidden_out, int dtype, int64_
     const dim3 grid((unsigned)(n_main + n_aux_blocks + n_next_blocks), (unsigned)((nblk + kMergeWaves - 1) / kMergeWaves));
     const char* h = (const char*)hidden;
     char* o = (char*)hidden_out;
+    const int64_t* ident = (skip_identity && stats) ? stats : nullptr;
     switch (dtype) {
-        case FF_F32: launch_mc<FF_F32>(grid, st, depth, h, o, (uint32_t)row_bytes, (int)L, L_cap, order, member, fold, dst, keep, pack, slots, n_main, reverse, n_aux_blocks, order_next, stats); break;
-        case FF_BF16: launch_mc<FF_BF16>(grid, st, depth, h, o, (uint32_t)row_bytes, (int)L, L_cap, order, member, fold, dst, keep, pack, slots, n_main, reverse, n_aux_blocks, order_next, stats); break;
-        default: launch_mc<FF_F16>(grid, st, depth, h, o, (uint32_t)row_bytes, (int)L, L_cap, order, member, fold, dst, keep, pack, slots, n_main, reverse, n_aux_blocks, order_next, stats);
+        case FF_F32: launch_mc<FF_F32>(grid, st, depth, h, o, (uint32_t)row_bytes, (int)L, L_cap, order, member, fold, dst, keep, pack, slots, n_main, reverse, n_aux_blocks, order_next, stats, ident); break;
+        case FF_BF16: launch_mc<FF_BF16>(grid, st, depth, h, o, (uint32_t)row_bytes, (int)L, L_cap, order, member, fold, dst, keep, pack, slots, n_main, reverse, n_aux_blocks, order_next, stats, ident); break;
+        default: launch_mc<FF_F16>(grid, st, depth, h, o, (uint32_t)row_bytes, (int)L, L_cap, order, member, fold, dst, keep, pack, slots, n_main, reverse, n_aux_blocks, order_next, stats, ident);
     }
     return (int)hipGetLastError();
 }
@@ -346,7 +352,7 @@ extern "C" int ff_merge_compact(const void* hidden, void* hidden_out, int dtype,
     if (L == 0) return FF_OK;
     return ff::launch_merge_compact(hidden, hidden_out, dtype, L, d, L_cap, order, member, fold, dst, keep, aux_host, n_aux,
                                     nullptr, nullptr,
-                                    (hipStream_t)stream);
+                                    (hipStream_t)stream, false);
 }
 
 extern "C" int ff_gather_mask(const void* mask, void* out, int64_t elem_bytes, int64_t L, int64_t L_cap,

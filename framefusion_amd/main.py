@@ -328,6 +328,15 @@ class FrameFusion(nn.Module):
             self.finish_merging = True
             self.finish_pruning = True
 
+        if L_out == L:
+            # nothing was folded (empty threshold set, main.py:264-266): the merge kernel saw that on
+            # the device and wrote nothing - the reduced sequence is the input itself, and the order
+            # in the scratch still describes the (unchanged) patch_type
+            self.last_call = dict(kind="merge", L_in=L, L_out=L, nv=nv, ftn=ftn, count=count, branch=branch,
+                                  k=int(st[_lib.STAT_K]), scratch=sc, dtype=dtype, order=sc.order)
+            sc.order_valid_for = (self.patch_type.data_ptr(), L)
+            return pending["inputs"]
+
         self.patch_type = ptype_out[:, :L_out]                                      # main.py:132
         # order maintenance: the merge kernel also wrote the by-patch order of the compacted
         # sequence, so the next merge call of this prefill skips K0

@@ -248,6 +248,10 @@ int ff_merge_step(const void* hidden, void* hidden_out, int dtype, int64_t L, in
  * every position's type is verified on the way and a mismatch sets FF_ERR_BIT_LAYOUT in
  * stats[FF_STAT_ERROR] (published with the stats block): the caller discards the call's outputs,
  * zeroes the workspace and repeats the call with hint_frames = 0.
+ * Identity calls: when the select folds nothing (stats[FF_STAT_MERGED] == 0, e.g. an empty
+ * threshold set, main.py:264-266) the reduced sequence IS the input: the merge kernel exits without
+ * writing hidden_out, the aux outputs or order_next, and stats[NV]/[FTN] stay as they are - the
+ * caller keeps using its input tensors and its current `order`.
  * order_next (optional, [L] int32): receives the by-patch order of the COMPACTED sequence and
  * stats[NV]/stats[FTN] are advanced to it, so the next merge call on the reduced sequence can pass
  * it as `order` with order_valid = 1 and skip K0 (surviving tokens keep their relative order). */
