@@ -5,8 +5,9 @@ synthetic [1, 64 frames x 576 tokens, 4096] bf16 activations (BASELINE.json conf
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = prepare() + one FrameFusion.forward call (K0 order, K1 similarity, K2/K3 plan, K4
-merge+compaction, one 128-byte readback) on one video sample resident in HBM.  With N ranks each
+A step = prepare() + one FrameFusion.forward call (by-patch order - derived inside the similarity
+kernel from prepare()'s layout scalars and verified there -, K1 similarity, K2/K3 plan, K4
+merge+compaction, one 256-byte result block) on one video sample resident in HBM.  With N ranks each
 rank reduces its own independent sample (seed + rank): weak scaling, no data-path collective.
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (live hipEvent timing on the
 launch stream, algorithmic bytes from DESIGN.md); `cpu_baseline` times the CPU oracle
@@ -233,7 +234,7 @@ def main():
             "step_roofline": {"algorithmic_bytes": alg["step"], "achieved": alg["step"] / (ms_per_step * 1e-3) / 1e9,
                               "frac": alg["step"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:         # reported at N = 1 only (other ranks would wait)
             result["cpu_baseline"] = cpu_baseline(hidden, ptype, cos, sin, P, L, args.cpu_calls)
     if dist is not None:
         dist.barrier()
