@@ -12,7 +12,7 @@ writes the fixtures under ``tests/golden/``.  ``tests/test_oracle_golden.py`` re
 against those fixtures wherever the repo travels.
 
 Every function builds its temporaries on the device of its inputs, so the same restatement also
-runs as "PyTorch eager on the GPU" (tools/kbench_eager.py times it there as a second baseline); the
+runs as "PyTorch eager on the GPU" (tests/bench_eager_gpu.py times it there as a second baseline); the
 parity tests always run it on CPU.
 
 The arithmetic is deliberately expressed with the same torch primitives the reference uses

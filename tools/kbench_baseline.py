@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Fixed-sparsity merging baseline at full size: per-layer GPU time of the [0.1] * 28 schedule on
 64 x 576 x 4096 bf16 (normed activations merged, residual + cos/sin + patch_type compacted).
-    python tools/kbench_baseline.py [--layers 28] [--sparsity 0.1] [--cpu]
+    python tools/kbench_baseline.py [--layers 28] [--sparsity 0.1]
+(the CPU oracle of the same layer is timed by tests/bench_eager_gpu.py --baseline-cpu)
 """
 import argparse
 import os
@@ -26,7 +27,6 @@ def main():
     ap.add_argument("--sparsity", type=float, default=0.1)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--no-residual", action="store_true")
-    ap.add_argument("--cpu", action="store_true", help="also time one layer of the CPU oracle")
     a = ap.parse_args()
     hidden, ptype = video_tokens(a.frames, a.patches, a.dim, p_change=0.3, sigma=0.3, seed=1234, dtype=torch.bfloat16)
     L = hidden.shape[1]
@@ -61,12 +61,6 @@ def main():
     byt = [(rows[i] + rows[i + 1]) * a.dim * esz * (1 if a.no_residual else 2) for i in range(a.layers)]
     print("algorithmic GB/s per layer:", " ".join(f"{b / (t * 1e-6) / 1e9:.0f}" for b, t in zip(byt, per_layer)))
     print(f"whole schedule: {sum(per_layer) / 1e3:.2f} ms GPU, {wall:.2f} ms wall (last rep)")
-    if a.cpu:
-        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        from oracle import ff_oracle as orc
-        t0 = time.perf_counter()
-        orc.fixed_sparsity_merge(hidden, ptype, a.patches, a.sparsity, [cos, sin], hidden)
-        print(f"CPU oracle, layer 0: {(time.perf_counter() - t0) * 1e3:.0f} ms on {torch.get_num_threads()} threads")
 
 
 if __name__ == "__main__":
