@@ -234,6 +234,8 @@ def main():
             "step_roofline": {"algorithmic_bytes": alg["step"], "achieved": alg["step"] / (ms_per_step * 1e-3) / 1e9,
                               "frac": alg["step"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
+        if world == 1 and (F, P, d) == (FRAMES, PATCHES, DIM):
+            result["cascade"] = prefill_cascade(dev)
         if not args.no_cpu_baseline and world == 1:         # reported at N = 1 only (other ranks would wait)
             result["cpu_baseline"] = cpu_baseline(hidden, ptype, cos, sin, P, L, args.cpu_calls)
     if dist is not None:
@@ -262,6 +264,43 @@ def profiled_traffic(kernel):
             return None
         total += scale * val * 1024.0
     return total
+
+
+def prefill_cascade(dev, reps=8):
+    """Extra (SURVEY.md §8d "the full cascade per sample"): every FrameFusion.forward call of ONE
+    prefill in the threshold regime (p_change 0.5, 14 + 20 text tokens): call A merges, call B of
+    layer 0 finds nothing left (identity), call B of layer 1 prunes with last-query importance.
+    Host wall per call after a device synchronise, mean over `reps` prefills."""
+    import framefusion_amd as ffa
+    from framefusion_amd.synth import video_tokens, rotary_tables
+    h0, pt = video_tokens(FRAMES, PATCHES, DIM, p_change=0.5, sigma=SIGMA, sigma_hi=1.6, seed=1234, pre=14, post=20,
+                          dtype=torch.bfloat16, device=str(dev))
+    L = h0.shape[1]
+    cos, sin = rotary_tables(L, HEAD_DIM, torch.bfloat16, device=str(dev))
+    ff = ffa.FrameFusion(COST, THRESHOLD, RATIO_LB)
+    gen = torch.Generator(device=dev).manual_seed(7)
+    acc = []
+    for rep in range(reps + 2):
+        ff.prepare(pt, PATCHES, 14, 14 + FRAMES * PATCHES - 1, FRAMES * PATCHES, L)
+        h, pe, calls = h0, [cos, sin], []
+        while not (ff.finish_merging and ff.finish_pruning) and len(calls) < 30:
+            w = None
+            if ff.finish_merging and not ff.finish_pruning:            # what the attention hook hands over
+                w = torch.rand(1, 1, 1, h.shape[1], generator=gen, device=dev).to(torch.bfloat16)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n_in = h.shape[1]
+            h, pe, _ = ff(h, pe, None, w)
+            torch.cuda.synchronize()
+            calls.append((ff.last_call["kind"], n_in, h.shape[1], (time.perf_counter() - t0) * 1e6))
+        if rep >= 2:
+            acc.append(calls)
+    n_calls = len(acc[0])
+    per_call = [{"kind": acc[0][i][0], "tokens_in": acc[0][i][1], "tokens_out": acc[0][i][2],
+                 "us": sum(c[i][3] for c in acc) / len(acc)} for i in range(n_calls)]
+    total = sum(c["us"] for c in per_call)
+    return {"workload": f"one prefill, [1, {L}, {DIM}] bf16, p_change=0.5 (threshold branch), importance = random [1,1,1,S]",
+            "calls": per_call, "total_us": total, "tokens_reduced_per_s": (L - per_call[-1]["tokens_out"]) / (total * 1e-6)}
 
 
 def cpu_baseline(hidden, ptype, cos, sin, P, L, calls):
