@@ -40,11 +40,17 @@ class TokenLayout:
     image_token_end_index: int
     image_token_length: int
     original_length: int
+    # False when the builder knows the visual tokens are NOT `frames x patch_num` contiguous tokens
+    # (text between InternVL's frames, MiniCPM-V's slice markers): FrameFusion then skips the
+    # frame-major shortcut of its first merge call instead of finding out on the device
+    frame_major: bool = True
 
     def prepare(self, framefusion, **flags):
         """What the reference's packers do last (e.g. modeling_llava_video.py:338)."""
         framefusion.prepare(self.patch_type, self.patch_num, self.image_token_start_index,
                             self.image_token_end_index, self.image_token_length, self.original_length, **flags)
+        if not self.frame_major and hasattr(framefusion, "_layout_hint"):
+            framefusion._layout_hint = None
         return self
 
 
@@ -143,7 +149,10 @@ def minicpmv_layout(image_bound, num_frames: int, seq_len: int, device) -> Token
         raise ValueError(f"image_bound {lo}..{lo + count} does not fit a sequence of {seq_len} tokens")
     row = fill_patch_type(seq_len, [(lo, count, 0, token_per_frame)], device)
     start, end = lo, lo + count - 1                                           # :101-102 (argmax of type >= 0)
-    return TokenLayout(row, token_per_frame, start, end, end - start + 1, seq_len)   # :100, :103-104
+    # the modulo typing makes every token of the span visual, but the span is two tokens longer than
+    # whole frames (:98), so it is frame-major only by accident
+    return TokenLayout(row, token_per_frame, start, end, end - start + 1, seq_len,
+                       frame_major=(count % token_per_frame == 0))                # :100, :103-104
 
 
 def internvl_layout(selected: torch.Tensor, n_frames: int, patch_num: int) -> TokenLayout:
@@ -170,7 +179,8 @@ def internvl_layout(selected: torch.Tensor, n_frames: int, patch_num: int) -> To
     if n_frames > 1 and (first == 0 or last == N - 1):
         raise IndexError("the reference's gap list (count_consecutive_false(selected)[1:-1]) needs text before "
                          "and after the frames")                              # :67-71
-    return TokenLayout(row, int(patch_num), first, last, last - first + 1, N)
+    return TokenLayout(row, int(patch_num), first, last, last - first + 1, N,
+                       frame_major=(last - first + 1 == n_frames * int(patch_num)))   # no text between the frames
 
 
 def nvila_layout(chunk_lengths: Sequence[int], n_media_features: int, media_frames: int, pool_sizes: int,

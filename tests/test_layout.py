@@ -180,3 +180,44 @@ def test_hip_layout_rejects_what_the_reference_cannot_build():
         L.minicpmv_layout([(2, 6), (8, 12)], 2, 12, DEV)    # bound + 2 runs past the sequence
     with pytest.raises(RuntimeError):
         L.nvila_layout([3, 10, 2], 12, 4, 1, DEV)           # 12 types into a 10-token slice
+
+
+@pytest.mark.gpu
+def test_layouts_drive_a_merge_call():
+    """A layout built on the device feeds FrameFusion.prepare and the first merge call: frame-major
+    layouts take the closed-form order inside the similarity kernel, InternVL's frames with text in
+    between are announced as such (no wasted hinted attempt) - both must give the oracle's result."""
+    import framefusion_amd as ffa
+    from framefusion_amd import layout as L
+    from framefusion_amd.synth import video_tokens
+    from oracle import ff_oracle as orc
+    from tests.conftest import same_bits
+    F, P, d, gap = 6, 16, 64, 5
+    # InternVL-like: text, then F frames of P tokens separated by `gap` text tokens, then text
+    sel = [False] * 3
+    for f in range(F):
+        sel += [True] * P + ([False] * gap if f + 1 < F else [])
+    sel += [False] * 4
+    N = len(sel)
+    lay_i = L.internvl_layout(torch.tensor(sel, device=DEV), F, P)
+    assert not lay_i.frame_major
+    vis, _ = video_tokens(F, P, d, p_change=0.4, sigma=0.3, seed=3, grid=0.125)
+    hidden = torch.zeros(1, N, d, dtype=vis.dtype)
+    text, _ = video_tokens(1, N, d, p_change=1.0, sigma=0.3, seed=4, grid=0.125)
+    hidden[0] = text[0]
+    hidden[0, torch.tensor(sel)] = vis[0]
+    for lay_x, hint in ((lay_i, None),
+                        (L.qwen2_vl_layout(torch.tensor([7] * 3 + [VIDEO_TOKEN_ID] * (F * P) + [9] * 4, device=DEV),
+                                           VIDEO_TOKEN_ID, (F, 8, 8), 2), (3, F))):
+        f = ffa.FrameFusion(0.3, 0.6, 0.1)
+        lay_x.prepare(f)
+        assert f._layout_hint == hint
+        n = lay_x.original_length
+        h = hidden[:, :n].contiguous()
+        o = orc.OracleFrameFusion(0.3, 0.6, 0.1)
+        o.prepare(lay_x.patch_type.cpu(), lay_x.patch_num, lay_x.image_token_start_index, lay_x.image_token_end_index,
+                  lay_x.image_token_length, lay_x.original_length)
+        hg, pg, _ = f(h.to(DEV), torch.arange(n, device=DEV)[None], None)
+        ho, po, _ = o.forward(h, torch.arange(n)[None], None)
+        assert torch.equal(pg.cpu(), po) and same_bits(hg.cpu(), ho)
+        assert int(f.last_call["scratch"].stats[11]) == 0          # no layout mismatch was raised on the device
