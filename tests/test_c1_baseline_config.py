@@ -1,0 +1,68 @@
+"""BASELINE.json configs[0] ("C1"): synthetic hidden_states [1, 14 + 8x576 + 20, 1024] fp32 through the
+reference's merge call.  tests/golden/c1.npz was produced by the REAL reference on torch-cpu
+(oracle/make_golden_c1.py).  CPU: the oracle must reproduce it bit for bit.  GPU: the HIP path must
+give the same kept-token indices; activations and similarities are fp32 sums in another order, so they
+are compared at 1e-5 relative (north-star bar for hidden_states: 1e-3)."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from framefusion_amd.synth import video_tokens
+from oracle import ff_oracle as orc
+from tests.conftest import Golden
+
+DEV = "cuda:0"
+CASES = ["topk", "thr", "low"]
+
+
+def inputs(g, name):
+    F, P, D, pre, post, seed, unique = (int(v) for v in g[f"{name}/cfg"])
+    p_change, sigma_hi = (float(v) for v in g[f"{name}/fcfg"])
+    h, pt = video_tokens(F, P, D, p_change=p_change, sigma=0.3, sigma_hi=None if sigma_hi < 0 else sigma_hi, seed=seed,
+                         pre=pre, post=post, dtype=torch.float32)
+    return h, pt, F, P, pre, bool(unique)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_reproduces_the_reference_on_c1(name):
+    g = Golden("c1")
+    h, pt, F, P, pre, _ = inputs(g, name)
+    L = h.shape[1]
+    o = orc.OracleFrameFusion(0.3, 0.6, 0.1)
+    o.prepare(pt.clone(), P, pre, pre + F * P - 1, F * P, L)
+    ho, po, _ = o.forward(h.clone(), torch.arange(L)[None], None)
+    assert np.array_equal(po[0].numpy().astype(np.int32), g[f"{name}/kept"])
+    assert np.array_equal(o.last_sim[0].numpy(), g[f"{name}/sim"])
+    assert [int(o.finish_merging), int(o.finish_pruning)] == g[f"{name}/flags"].tolist()
+    assert o.sparsity_list == g[f"{name}/sparsity"].tolist()
+    assert np.array_equal(ho[0, torch.from_numpy(g[f"{name}/rows_idx"])].numpy(), g[f"{name}/rows"])
+    assert hashlib.sha256(ho.numpy().tobytes()).digest() == g[f"{name}/sha256"].tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_hip_matches_the_reference_on_c1(name):
+    import framefusion_amd as ffa
+    g = Golden("c1")
+    h, pt, F, P, pre, unique = inputs(g, name)
+    L = h.shape[1]
+    f = ffa.FrameFusion(0.3, 0.6, 0.1)
+    f.prepare(pt.to(DEV), P, pre, pre + F * P - 1, F * P, L)
+    hg, pg, _ = f(h.to(DEV), torch.arange(L, device=DEV)[None], None)
+    kept = pg[0].cpu().numpy().astype(np.int32)
+    want = g[f"{name}/kept"]
+    sim = f.last_plan()["sim"].cpu().numpy()
+    np.testing.assert_allclose(sim, g[f"{name}/sim"], rtol=2e-6, atol=2e-7)
+    assert [int(f.finish_merging), int(f.finish_pruning)] == g[f"{name}/flags"].tolist()
+    if name == "topk":
+        assert f.sparsity_list == []
+    else:
+        # the ratio is a count over ftn: identical unless a similarity sits within an ulp of the threshold
+        assert f.sparsity_list == pytest.approx(g[f"{name}/sparsity"].tolist(), abs=2.0 / (F * P))
+    assert unique
+    assert np.setxor1d(kept, want).size <= 2          # an fp32 ulp at the cut may swap one pair; normally 0
+    if np.array_equal(kept, want):
+        rows = hg[0, torch.from_numpy(g[f"{name}/rows_idx"]).to(DEV)].cpu().numpy()
+        np.testing.assert_allclose(rows, g[f"{name}/rows"], rtol=1e-5, atol=1e-6)
