@@ -126,7 +126,14 @@ def check(rc: int, what: str):
         raise FrameFusionHipError(f"{what} failed: [{rc}] {msg.decode() if msg else '?'}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr() -> int:
+    """hipStream_t of PyTorch's current stream on the current device (the raw getter is ~10x cheaper
+    than building a torch.cuda.Stream object; same value)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -99,6 +99,18 @@ class FrameFusion(nn.Module):
         self._scratch = {}
         self.last_call = None     # diagnostics of the most recent reduction (tests / bench)
 
+    _PLAIN = (bool, int, float, str, list, tuple, dict, type(None), torch.Tensor)
+
+    def __setattr__(self, name, value):
+        # The module has no parameters, buffers or submodules; its attributes are per-prefill state
+        # (flags, scalars, the patch_type tensor) rewritten on every call.  nn.Module.__setattr__
+        # spends ~2 us per assignment on parameter/buffer/submodule bookkeeping before it ends up in
+        # __dict__ as well, so plain values go there directly.
+        if type(value) in FrameFusion._PLAIN:
+            object.__setattr__(self, name, value)
+        else:
+            super().__setattr__(name, value)
+
     # ---- reference main.py:15-38 -----------------------------------------------------------
     def prepare(self, patch_type: torch.Tensor, patch_num: int, image_token_start_index,
                 image_token_end_index, image_token_length, original_length: int,
@@ -138,6 +150,12 @@ class FrameFusion(nn.Module):
 
     # ---- reference main.py:40-140 ------------------------------------------------------------
     def forward(self, hidden_states, position_embeddings, attention_mask, self_attn_weights=None):
+        dev = hidden_states.device
+        if dev.type == "cuda" and dev.index != torch.cuda.current_device():
+            # the kernels are launched through ctypes on the CURRENT device's stream: follow the
+            # tensors (several replicas on several GPUs in one process, as in the reference's demo)
+            with torch.cuda.device(dev):
+                return self.forward(hidden_states, position_embeddings, attention_mask, self_attn_weights)
         bsz, q_len, hidden_size = hidden_states.size()
         prune_now = q_len > 1 and self.finish_merging == True and self.finish_pruning == False
         merge_now = q_len > 1 and (not self.finish_merging)
@@ -163,11 +181,13 @@ class FrameFusion(nn.Module):
             s = self._scratch[key] = _Scratch(device)
         # the scratch is reused call after call: if the caller switched streams, order the new
         # stream behind the one that last touched it
-        cur = torch.cuda.current_stream(device)
-        last = getattr(s, "last_stream", None)
-        if last is not None and last != cur:
-            cur.wait_stream(last)
-        s.last_stream = cur
+        ptr = _lib.stream_ptr()
+        if getattr(s, "last_stream_ptr", None) != ptr:
+            cur = torch.cuda.current_stream(device)
+            last = getattr(s, "last_stream", None)
+            if last is not None and last != cur:
+                cur.wait_stream(last)
+            s.last_stream, s.last_stream_ptr = cur, ptr
         return s.ensure(L, dtype)
 
     @staticmethod
