@@ -5,7 +5,7 @@ Same class, method and attribute surface as the reference's ``framefusion/main.p
 ``IGNORE_TOKEN`` :5-6) so the reference's patched decoder/attention forwards can call it
 unchanged; every tensor-sized operation behind it is a hand-written gfx950 kernel reached through
 the C ABI of ``include/framefusion_hip.h``.  The host keeps only the state machine and the python
-float budget arithmetic, and reads ONE 128-byte result block back per merge call (the reference
+float budget arithmetic, and reads ONE 256-byte result block back per merge call (the reference
 performs 17 host syncs per call).  The prune call needs no readback at all.
 
 There is no eager/CPU fallback: CPU tensors raise ``FrameFusionHipError``.
@@ -13,6 +13,7 @@ There is no eager/CPU fallback: CPU tensors raise ``FrameFusionHipError``.
 from __future__ import annotations
 
 import ctypes as C
+import time
 from typing import List, Optional
 
 import torch
@@ -82,6 +83,8 @@ class _Scratch:
         n = 0
         while view[word] != seq:
             n += 1
+            if (n & 1023) == 0:
+                time.sleep(0)                    # let other Python threads (other replicas) run
             if n > spins:
                 torch.cuda.current_stream().synchronize()
                 if view[word] != seq:
