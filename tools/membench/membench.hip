@@ -112,6 +112,76 @@ __global__ void k_read_seq(const char* __restrict__ base, int n_rows, int row_by
     if (acc.x == 0x12345678u && acc.y == 0x9abcdef0u) sink[0] = acc;
 }
 
+// pattern 3: copy - every word is read, a fraction `keep_256`/256 of the rows is written (row = 8 KiB),
+// stores optionally non-temporal: the traffic mix of the merge+compaction pass
+template <int NT>
+__global__ void k_copy_rows(const uint4* __restrict__ src, uint4* __restrict__ dst, int n_rows, int keep_256) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int waves = (gridDim.x * blockDim.x) >> 6;
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    int out_row = 0;
+    for (int r = wave; r < n_rows; r += waves) {
+        const bool keep = ((r * 37) & 255) < keep_256;
+        const uint4* p = src + (size_t)r * 512 + lane;
+        uint4 v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            if (NT) { const v4u q = __builtin_nontemporal_load((const v4u*)(p + t * 64)); v[t] = make_uint4(q.x, q.y, q.z, q.w); }
+            else v[t] = p[t * 64];
+        }
+        out_row = (int)(((long long)r * keep_256) >> 8);
+        uint4* q = dst + (size_t)out_row * 512 + lane;
+        if (keep) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (NT) { v4u w = {v[t].x, v[t].y, v[t].z, v[t].w}; __builtin_nontemporal_store(w, (v4u*)(q + t * 64)); }
+                else q[t * 64] = v[t];
+            }
+        } else {                                       // dropped row: still read in full (the merge pass folds it)
+            uint4 x = v[0];
+#pragma unroll
+            for (int t = 1; t < 8; ++t) { x.x ^= v[t].x; x.y ^= v[t].y; x.z ^= v[t].z; x.w ^= v[t].w; }
+            if (x.x == 0x12345678u && x.w == 0x9abcdef0u) q[0] = x;
+        }
+    }
+}
+
+// pattern 4: the same copy with the merge kernel's decomposition: a wave owns ONE 1 KiB column tile of
+// SLOTS consecutive by-patch rows (rows 4.7 MB apart), DEPTH pieces in flight
+template <int SLOTS, int DEPTH, int NT>
+__global__ void k_copy_coltile(const char* __restrict__ src, char* __restrict__ dst, int n_rows, int row_stride, int keep_256) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6);      // 0..7
+    const int g0 = blockIdx.x * SLOTS;
+    const int F = row_stride, P = n_rows / row_stride;
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    for (int s0 = 0; s0 < SLOTS; s0 += DEPTH) {
+        uint4 v[DEPTH];
+        int rr[DEPTH];
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) {
+            int j = g0 + s0 + u; if (j >= n_rows) j = n_rows - 1;
+            const int pp = j / F, f = j - pp * F;
+            rr[u] = f * P + pp;
+            const char* p = src + (size_t)rr[u] * 8192 + tile * 1024 + lane * 16;
+            if (NT) { const v4u q = __builtin_nontemporal_load((const v4u*)p); v[u] = make_uint4(q.x, q.y, q.z, q.w); }
+            else v[u] = *(const uint4*)p;
+        }
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) {
+            const int r = rr[u];
+            if (((r * 37) & 255) < keep_256) {
+                char* q = dst + (size_t)(((long long)r * keep_256) >> 8) * 8192 + tile * 1024 + lane * 16;
+                if (NT) { v4u w = {v[u].x, v[u].y, v[u].z, v[u].w}; __builtin_nontemporal_store(w, (v4u*)q); }
+                else *(uint4*)q = v[u];
+            } else { acc.x ^= v[u].x; acc.y ^= v[u].y; acc.z ^= v[u].z; acc.w ^= v[u].w; }
+        }
+    }
+    if (acc.x == 0x12345678u && acc.w == 0x9abcdef0u) *(uint4*)dst = acc;
+}
+
 template <class F>
 static float time_us(F f, int reps) {
     hipEvent_t a, b;
@@ -155,5 +225,17 @@ int main(int argc, char** argv) {
         printf("seq   NR=%2d depth=%d tpb=%4d ov=%d blocks=%6d : %7.1f us  %7.1f GB/s (unique bytes)\n", NR, DEPTH, TPB, OV, blocks, us, (double)n_rows * row_bytes / us / 1e3); }
     SEQ(4, 2, 256, 0) SEQ(8, 2, 256, 0) SEQ(16, 2, 256, 0) SEQ(8, 4, 256, 0) SEQ(16, 4, 256, 0) SEQ(8, 2, 64, 0) SEQ(16, 4, 64, 0) SEQ(16, 8, 64, 0)
     SEQ(5, 2, 256, 1) SEQ(9, 2, 256, 1) SEQ(17, 2, 256, 1) SEQ(9, 4, 256, 1) SEQ(17, 4, 256, 1) SEQ(9, 4, 64, 1) SEQ(17, 4, 64, 1) SEQ(17, 8, 64, 1) SEQ(33, 4, 64, 1) SEQ(33, 8, 64, 1)
+    char* c; CK(hipMalloc(&c, bytes));
+#define COPY(NT, KEEP, BLOCKS) { \
+        float us = time_us([&] { flip ^= 1; hipLaunchKernelGGL((k_copy_rows<NT>), dim3(BLOCKS), dim3(256), 0, 0, (const uint4*)(flip ? a : b), (uint4*)c, n_rows, KEEP); }, 10); \
+        const double moved = (double)n_rows * row_bytes * (1.0 + KEEP / 256.0); \
+        printf("copy  nt=%d keep=%3d/256 blocks=%5d : %7.1f us  %7.1f GB/s (read + written bytes)\n", NT, KEEP, BLOCKS, us, moved / us / 1e3); }
+#define COLT(SLOTS, DEPTH, NT, KEEP) { \
+        dim3 grid((n_rows + SLOTS - 1) / SLOTS, 2); \
+        float us = time_us([&] { flip ^= 1; hipLaunchKernelGGL((k_copy_coltile<SLOTS, DEPTH, NT>), grid, dim3(256), 0, 0, (const char*)(flip ? a : b), c, n_rows, F, KEEP); }, 10); \
+        const double moved = (double)n_rows * row_bytes * (1.0 + KEEP / 256.0); \
+        printf("colt  slots=%2d depth=%d nt=%d keep=%3d/256 : %7.1f us  %7.1f GB/s (read + written bytes)\n", SLOTS, DEPTH, NT, KEEP, us, moved / us / 1e3); }
+    COLT(32, 4, 1, 77) COLT(32, 4, 0, 77) COLT(32, 8, 1, 77) COLT(16, 4, 1, 77) COLT(64, 4, 1, 77) COLT(32, 2, 1, 77)
+    COPY(0, 256, 2048) COPY(1, 256, 2048) COPY(0, 77, 2048) COPY(1, 77, 2048) COPY(1, 77, 4096) COPY(1, 77, 1024) COPY(1, 128, 2048)
     return 0;
 }
