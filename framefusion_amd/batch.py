@@ -49,7 +49,8 @@ def forward_many(instances: Sequence, hidden_states: Sequence[torch.Tensor], pos
                 results[i] = ff.forward(h, position_embeddings[i], masks[i], weights[i])
     for i, ff in enumerate(instances):
         if pending[i] is not None:
-            results[i] = ff._merge_complete(pending[i])
+            with torch.cuda.stream(streams[i]):  # a rejected layout hint repeats the call: same stream
+                results[i] = ff._merge_complete(pending[i])
     for s in streams:
         main.wait_stream(s)                      # consumers on the caller's stream see finished outputs
     return results
