@@ -74,7 +74,7 @@ PROTOTYPES = {
     "ff_fill_patch_type": (_i32, [_vp, _i64, C.POINTER(FFSegment), _i64, _vp]),
     "ff_patch_type_from_mask": (_i32, [_vp, _i64, _i64, _vp, _vp, _vp]),
     "ff_merge_step": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _i64, _i32, _f64, _f64, _f64, _vp, _vp, _vp,
-                             _vp, _vp, _vp, _vp, _i64, C.POINTER(FFAux), _i32, _vp, _sz, _vp]),
+                             _vp, _vp, _vp, _vp, _i64, C.POINTER(FFAux), _i32, _i64, _i64, _vp, _vp, _sz, _vp]),
 }
 
 _lib = None

@@ -111,13 +111,14 @@ extern "C" int ff_merge_step(const void* hidden, void* hidden_out, int dtype, in
                              const int64_t* patch_type, int64_t patch_num, int order_valid, double threshold,
                              double sub, double ratio_lb, int32_t* order, void* sim, uint8_t* member,
                              int32_t* dst, uint8_t* keep, int64_t* stats, int64_t* stats_host_mapped,
-                             int64_t seq, const ff_aux_t* aux_host, int n_aux, void* ws, size_t ws_bytes,
+                             int64_t seq, const ff_aux_t* aux_host, int n_aux, int64_t hint_pre,
+                             int64_t hint_frames, int32_t* order_next, void* ws, size_t ws_bytes,
                              ff_stream_t stream) {
     int rc = ff_merge_begin(hidden, dtype, L, d, patch_type, patch_num, order_valid, threshold, order, sim, stats,
-                            seq, 0, 0, ws, ws_bytes, stream);
+                            seq, hint_pre, hint_frames, ws, ws_bytes, stream);
     if (rc) return rc;
     return ff_merge_finish(hidden, hidden_out, dtype, L, d, L_cap, threshold, sub, ratio_lb, order, sim, member, dst,
-                           keep, stats, stats_host_mapped, seq, aux_host, n_aux, nullptr, ws, ws_bytes, stream);
+                           keep, stats, stats_host_mapped, seq, aux_host, n_aux, order_next, ws, ws_bytes, stream);
 }
 
 extern "C" int ff_prune_step(const void* hidden, void* hidden_out, int dtype, int64_t S, int64_t d, int64_t L_cap,

@@ -226,13 +226,16 @@ int ff_patch_type_from_mask(const uint8_t* mask, int64_t n, int64_t patch_num, i
  * K1 -> K2+K3 -> K4, all enqueued by one host call.  `stats_host_mapped` (may be NULL) is a
  * device-visible pinned host pointer that receives a copy of the stats block, its FF_STAT_SEQ
  * word written last with `seq`, so the host can poll instead of synchronising the stream.
- * Workspace protocol as for ff_merge_begin / ff_merge_finish below. */
+ * Workspace protocol, layout hint, identity calls and order_next as for ff_merge_begin /
+ * ff_merge_finish below.  One host call = five launches issued back to back: the form to use when
+ * the sequence is short enough that the host, not the similarity pass, would set the pace. */
 int ff_merge_step(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
                   const int64_t* patch_type, int64_t patch_num, int order_valid,
                   double threshold, double sub, double ratio_lb,
                   int32_t* order, void* sim, uint8_t* member, int32_t* dst, uint8_t* keep,
                   int64_t* stats, int64_t* stats_host_mapped, int64_t seq,
                   const ff_aux_t* aux_host, int n_aux,
+                  int64_t hint_pre, int64_t hint_frames, int32_t* order_next,
                   void* ws, size_t ws_bytes, ff_stream_t stream);
 
 /* The same step in two halves, so the host can allocate the output tensors while the first

@@ -62,7 +62,7 @@ int main(int argc, char** argv) {
     const double thr = 0.6015625;                                        // bf16(0.6), main.py:113
     FF(ff_merge_step(dh, dout, FF_BF16, L, d, L, (const int64_t*)dpt, P, /*order_valid=*/0, thr, /*sub=*/0.7, /*ratio_lb=*/0.1,
                      (int32_t*)dorder, dsim, (uint8_t*)dmember, (int32_t*)ddst, (uint8_t*)dkeep, (int64_t*)dstats, nullptr,
-                     /*seq=*/1, aux, 1, dws, wsb, st));
+                     /*seq=*/1, aux, 1, /*hint_pre=*/0, /*hint_frames=*/0, /*order_next=*/nullptr, dws, wsb, st));
     CK(hipStreamSynchronize(st));
     std::vector<int64_t> stats(FF_STAT_WORDS);
     std::vector<uint8_t> keep(L);
