@@ -1,0 +1,223 @@
+#!/usr/bin/env python
+"""Full-size golden vectors from the REAL reference on gaussian (un-quantised) inputs - the
+configurations BASELINE.json quotes, at their stated sizes (SURVEY.md §8d C2 / C3 / C5 and the real
+LLaVA-Video-7B shape).  Runs ONLY in the build container (imports /root/reference/framefusion/main.py,
+compiles utils.scaled_dot_product_attention from the reference file's AST; nothing of the reference is
+written to disk).  Inputs are regenerated from seeds on the test side; the fixture keeps the
+reference's OUTPUTS, compactly:
+
+  merge cases  (one FrameFusion.forward merge call, main.py:104-138)
+      sim          [Nv] activation-dtype bits (by-patch order)
+      merged       bit mask over by-patch slots  (the reference's merge_index_by_patch)
+      kept         bit mask over sequence positions (from a [1, L] position tensor, main.py:171-175)
+      stats        L, L_out, Nv, ftn, count(sim >= thr), branch, k, finish_merging, finish_pruning
+      tie          top-k branch: bits of the k-th value, size of its tie class, members the reference took,
+                   and whether the reference's choice IS the lowest-index choice
+      rows         8 sampled anchors: sequence position, run length, output row bits
+      sha256       of the reference's output activations
+  prune cases  (attention importance -> one FrameFusion.forward prune call, utils.py:27-57 + main.py:61-101)
+      importance   [S] bits = torch.mean(weights, dim=(1, 2))[0]
+      w_rows       the weights of two (head, query) rows, bits
+      kept         bit mask over sequence positions
+      stats        S, L_out, start, n_img, k + the tie class at the cut as above
+
+    python oracle/make_golden_full.py        # ~2 min, peak ~6 GB
+"""
+from __future__ import annotations
+
+import ast
+import hashlib
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+import framefusion.main as ref                       # noqa: E402  (the reference)
+from oracle import ff_oracle as orc                  # noqa: E402
+from framefusion_amd.synth import video_tokens       # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden", "full.npz")
+N_ROWS = 8
+
+# name: (F, P, D, pre, post, seed, p_change, sigma_hi, (cost, thr, lb))
+MERGE_CASES = {
+    "c2_topk":   (64, 576, 4096, 0, 0, 1234, 0.2, None, (0.3, 0.6, 0.1)),     # bench.py's workload, to the seed
+    "c2_thr":    (64, 576, 4096, 14, 20, 1234, 0.5, 1.6, (0.3, 0.6, 0.1)),
+    "c2_low":    (64, 576, 4096, 14, 20, 1234, 0.95, None, (0.3, 0.6, 0.1)),
+    "c3_p195":   (64, 195, 3584, 15, 12, 77, 0.5, 1.8, (0.3, 0.5, 0.1)),      # Qwen2-VL-7B, 128 frames = 64 grids
+    "c3_p180":   (64, 180, 3584, 15, 12, 78, 0.3, 1.8, (0.3, 0.7, 0.1)),
+    "c5_topk":   (64, 576, 8192, 14, 20, 5, 0.2, None, (0.3, 0.6, 0.1)),      # LLaVA-Video-72B, 64 frames
+    "c5_low":    (64, 576, 8192, 14, 20, 5, 0.95, None, (0.3, 0.6, 0.1)),
+    "llava7b":   (64, 210, 3584, 14, 20, 9, 0.2, None, (0.3, 0.6, 0.1)),      # the real 7B token layout (14 x 15)
+}
+# name: (H, H_kv, dh, num, S, start, n_img, d, seed, sparsity_list)
+PRUNE_CASES = {
+    "c5_prune":  (64, 8, 128, 1, 35053, 14, 35019, 8192, 21, [0.05]),         # after c5_low-like merge (5 % folded)
+    "c3_prune":  (28, 4, 128, 4, 9011, 15, 8984, 3584, 22, [0.28]),           # Qwen2-VL: num = 4
+    "c2_prune":  (28, 4, 128, 1, 18732, 14, 18698, 3584, 23, [0.493]),        # LLaVA-Video-7B heads
+}
+
+
+def bits(t: torch.Tensor) -> np.ndarray:
+    t = t.detach().contiguous()
+    if t.dtype in (torch.bfloat16, torch.float16):
+        return t.view(torch.int16).numpy().copy()
+    return t.numpy().copy()
+
+
+def load_reference_sdpa():
+    src = open(os.path.join(REF, "framefusion", "utils.py")).read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "scaled_dot_product_attention"][0]
+    ns = {"torch": torch, "math": math}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "<reference utils.py>", "exec"), ns)
+    return ns["scaled_dot_product_attention"]
+
+
+def tie_record(values: torch.Tensor, taken_mask: torch.Tensor, k: int):
+    """values 1-D (activation dtype), taken_mask bool over the same index space, k entries taken.
+    -> (kth bits as int64, tie size, taken in tie, reference == lowest-index rule)"""
+    if k <= 0 or k >= values.numel():
+        return np.asarray([0, 0, 0, 1], dtype=np.int64)
+    v = values.float()
+    key = torch.where(torch.isnan(v), torch.full_like(v, float("inf")), v)
+    kth = torch.sort(key, descending=True).values[k - 1]
+    tie = key == kth
+    want = torch.zeros_like(taken_mask)
+    want[orc.topk_lowest_index(values, k)] = True
+    kth_t = kth.to(values.dtype)
+    kb = int(kth_t.view(torch.int16)) & 0xffff if values.dtype != torch.float32 else int(kth_t.view(torch.int32))
+    return np.asarray([kb, int(tie.sum()), int((tie & taken_mask).sum()), int(torch.equal(want, taken_mask))], dtype=np.int64)
+
+
+def gen_merge(name, spec, store):
+    F, P, D, pre, post, seed, p_change, sigma_hi, (cost, thr, lb) = spec
+    t0 = time.time()
+    h, pt = video_tokens(F, P, D, p_change=p_change, sigma=0.3, sigma_hi=sigma_hi, seed=seed, pre=pre, post=post,
+                         dtype=torch.bfloat16)
+    L = h.shape[1]
+    r = ref.FrameFusion(cost, thr, lb)
+    r.prepare(pt.clone(), P, pre, pre + F * P - 1, F * P, L)
+    sim_r, order_r = ref.FrameFusion.compute_similarity_and_token_index_by_patch(h, pt, P)
+    hr, pos_r, _ = r.forward(h.clone(), torch.arange(L)[None], None)          # the call under test (clone: main.py:304 mutates)
+    kept = torch.zeros(L, dtype=torch.bool)
+    kept[pos_r[0]] = True
+    nv = sim_r.shape[1]
+    ftn = int((pt != -1).sum())
+    # the merge set, recovered from the kept mask: slot j was merged iff its position was dropped
+    merged = ~kept[order_r[0]]
+    count = int((sim_r[0] >= thr).sum())
+    branch = int(r.finish_pruning)
+    k = int(merged.sum()) if branch else 0
+    # cross-check with the oracle (shares everything but the tie choice)
+    o = orc.OracleFrameFusion(cost, thr, lb)
+    o.prepare(pt.clone(), P, pre, pre + F * P - 1, F * P, L)
+    ho, pos_o, _ = o.forward(h.clone(), torch.arange(L)[None], None)
+    assert torch.equal(o.last_sim, sim_r) and torch.equal(o.last_order, order_r), name
+    assert (o.finish_merging, o.finish_pruning) == (r.finish_merging, r.finish_pruning), name
+    assert ho.shape == hr.shape, name
+    tie = tie_record(sim_r[0], merged, k) if branch else np.asarray([0, 0, 0, 1], dtype=np.int64)
+    if not branch:
+        assert torch.equal(pos_o, pos_r) and torch.equal(ho.view(torch.int16), hr.view(torch.int16)), name
+        assert o.sparsity_list == r.sparsity_list
+    else:
+        # outside the tie class the oracle and the reference agree
+        kth = torch.tensor(int(tie[0]), dtype=torch.int32).to(torch.int16).view(torch.bfloat16)
+        in_tie = sim_r[0] == kth
+        merged_o = torch.zeros(nv, dtype=torch.bool)
+        merged_o[o.last_merge_idx] = True
+        assert torch.equal(merged_o[~in_tie], merged[~in_tie]), name
+        assert int(merged_o.sum()) == k == int(orc.budget([], cost) * ftn), name
+    # sampled anchors (output rows), spread over the output
+    rows_out = torch.linspace(0, hr.shape[1] - 1, N_ROWS).long()
+    rows_pos = pos_r[0][rows_out]
+    inv = torch.empty(L, dtype=torch.long)
+    inv[order_r[0]] = torch.arange(nv)
+    run_len = []
+    for p in rows_pos.tolist():
+        n = 0
+        if pt[0, p] != -1:
+            j = int(inv[p]) + 1
+            while j < nv and bool(merged[j]):
+                n += 1
+                j += 1
+        run_len.append(n)
+    store[f"{name}/cfg"] = np.asarray([F, P, D, pre, post, seed], dtype=np.int64)
+    store[f"{name}/fcfg"] = np.asarray([p_change, -1.0 if sigma_hi is None else sigma_hi, cost, thr, lb], dtype=np.float64)
+    store[f"{name}/sim"] = bits(sim_r[0])
+    store[f"{name}/merged"] = np.packbits(merged.numpy())
+    store[f"{name}/kept"] = np.packbits(kept.numpy())
+    store[f"{name}/stats"] = np.asarray([L, hr.shape[1], nv, ftn, count, branch, k, int(r.finish_merging),
+                                         int(r.finish_pruning)], dtype=np.int64)
+    store[f"{name}/sparsity"] = np.asarray(r.sparsity_list, dtype=np.float64)
+    store[f"{name}/tie"] = tie
+    store[f"{name}/rows_pos"] = rows_pos.numpy().astype(np.int64)
+    store[f"{name}/rows_run"] = np.asarray(run_len, dtype=np.int64)
+    store[f"{name}/rows"] = bits(hr[0, rows_out])
+    store[f"{name}/sha256"] = np.frombuffer(hashlib.sha256(bits(hr).tobytes()).digest(), dtype=np.uint8).copy()
+    print(f"{name}: L={L} -> {hr.shape[1]} branch={'topk' if branch else 'thr'} count={count} k={k} "
+          f"tie(size,taken,lowest)={tie[1:].tolist()} distinct_sim={int(torch.unique(sim_r).numel())} "
+          f"runs={run_len} ({time.time() - t0:.1f}s)", flush=True)
+
+
+def gen_prune(name, spec, store, sdpa):
+    H, Hk, dh, num, S, start, n_img, d, seed, sparsity = spec
+    t0 = time.time()
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(1, H, num, dh, generator=g).to(torch.bfloat16)
+    kk = torch.randn(1, Hk, S, dh, generator=g).to(torch.bfloat16)
+    hid = torch.randn(1, S, d, generator=g).to(torch.bfloat16)
+    w = sdpa(q, kk, torch.zeros_like(kk), num=num, is_causal=True, enable_gqa=True)          # [1, H, num, S]
+    w_o = orc.last_query_attention(q, kk, num=num, is_causal=True, enable_gqa=True)
+    assert torch.equal(w.view(torch.int16), w_o.view(torch.int16)), name
+    imp = torch.mean(w, dim=(1, 2))[0]
+    original_length = S + 1000          # tokens already folded by the merge calls (main.py:66)
+    image_token_length = n_img + 1000
+    r = ref.FrameFusion(0.3, 0.6, 0.1)
+    r.prepare(torch.zeros(1, S, dtype=torch.long), 1, start, start + n_img, image_token_length, original_length,
+              finish_merging=True, finish_pruning=False, sparsity_list=list(sparsity))
+    hr, pos_r, _ = r.forward(hid, torch.arange(S)[None], None, w)
+    assert r.finish_pruning
+    kept = torch.zeros(S, dtype=torch.bool)
+    kept[pos_r[0]] = True
+    k = int(kept[start:start + n_img].sum())
+    assert k == round(n_img * (1 - orc.budget(list(sparsity), 0.3)))
+    assert torch.equal(hr.view(torch.int16), hid[:, pos_r[0]].view(torch.int16))
+    tie = tie_record(imp[start:start + n_img], kept[start:start + n_img], k)
+    store[f"{name}/cfg"] = np.asarray([H, Hk, dh, num, S, start, n_img, d, seed, original_length, image_token_length],
+                                      dtype=np.int64)
+    store[f"{name}/sparsity"] = np.asarray(sparsity, dtype=np.float64)
+    store[f"{name}/importance"] = bits(imp)
+    store[f"{name}/w_rows"] = bits(torch.stack((w[0, 0, 0], w[0, H - 1, num - 1])))
+    store[f"{name}/kept"] = np.packbits(kept.numpy())
+    store[f"{name}/stats"] = np.asarray([S, hr.shape[1], start, n_img, k], dtype=np.int64)
+    store[f"{name}/tie"] = tie
+    print(f"{name}: S={S} -> {hr.shape[1]} k={k} tie(size,taken,lowest)={tie[1:].tolist()} "
+          f"distinct_imp={int(torch.unique(imp[start:start + n_img]).numel())} ({time.time() - t0:.1f}s)", flush=True)
+
+
+def main():
+    only = set(sys.argv[1:])
+    store = {}
+    if os.path.exists(OUT) and only:
+        store.update({k: v for k, v in np.load(OUT).items()})
+    sdpa = load_reference_sdpa()
+    for name, spec in PRUNE_CASES.items():
+        if not only or name in only:
+            gen_prune(name, spec, store, sdpa)
+    for name, spec in MERGE_CASES.items():
+        if not only or name in only:
+            gen_merge(name, spec, store)
+    np.savez_compressed(OUT, **store)
+    print("wrote", OUT, os.path.getsize(OUT), "bytes")
+
+
+if __name__ == "__main__":
+    main()
