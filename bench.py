@@ -43,8 +43,12 @@ def parse():
     ap.add_argument("--patches", type=int, default=PATCHES)
     ap.add_argument("--dim", type=int, default=DIM)
     ap.add_argument("--p-change", type=float, default=P_CHANGE)
-    ap.add_argument("--batch", type=int, default=1,
-                    help="independent samples per GPU per step, overlapped on HIP streams (default 1 = BASELINE configs[1])")
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="collective backend for the scalars exchanged off the timed path (nccl = RCCL over xGMI)")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="allow more ranks than GPUs (rank r -> GPU r %% device_count; gloo only: RCCL refuses two ranks "
+                         "on one device) - exercises the N > 1 path on a 1-GPU box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-calls", type=int, default=5)
     return ap.parse_args()
@@ -64,70 +68,59 @@ def algorithmic_bytes(L_in, L_out, nv, d, elt, head_dim, pe_outer=1):
 def main():
     args = parse()
     from framefusion_amd import dp
+    # `python bench.py --gpus N` starts its own N ranks (one per GPU) unless a launcher already did
+    dp.launch_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:])
     world, rank, local = dp.env_world()
-    if world == 1 and args.gpus > 1:
-        print("bench.py: --gpus > 1 must be launched with torch.distributed.run", file=sys.stderr)
+    if world != max(1, args.gpus):
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks", file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist = dp.init("nccl", dev)
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0:
+        print("bench.py needs an MI355X: framefusion_amd has no CPU path", file=sys.stderr)
+        sys.exit(2)
+    if world > n_dev and not (args.oversubscribe and args.backend == "gloo"):
+        print(f"bench.py: {world} ranks but {n_dev} GPU(s) visible (one rank per GPU; "
+              f"--oversubscribe --backend gloo shares GPUs for a functional check)", file=sys.stderr)
+        sys.exit(2)
+    dev = torch.device("cuda", local % n_dev)
+    torch.cuda.set_device(dev)
+    dist = dp.init(args.backend, dev)
+    # rank 0's workload description is THE workload: broadcast over RCCL before anything is generated
+    cfg = dp.broadcast_config(dist, dict(seed=args.seed, frames=args.frames, patches=args.patches, dim=args.dim,
+                                         p_change=args.p_change, steps=args.steps, warmup=args.warmup), dev)
+    args.seed, args.frames, args.patches, args.dim = cfg["seed"], cfg["frames"], cfg["patches"], cfg["dim"]
+    args.p_change, args.steps, args.warmup = cfg["p_change"], cfg["steps"], cfg["warmup"]
 
     import framefusion_amd as ffa
     from framefusion_amd import _lib
     from framefusion_amd.synth import video_tokens, rotary_tables
 
     F, P, d = args.frames, args.patches, args.dim
-    hidden, ptype = video_tokens(F, P, d, p_change=args.p_change, sigma=SIGMA, seed=dp.sample_seed(1234, rank),
+    hidden, ptype = video_tokens(F, P, d, p_change=args.p_change, sigma=SIGMA, seed=dp.sample_seed(args.seed, rank),
                                  dtype=torch.bfloat16, device=str(dev))
     L = hidden.shape[1]
     cos, sin = rotary_tables(L, HEAD_DIM, torch.bfloat16, device=str(dev))
     ff = ffa.FrameFusion(COST, THRESHOLD, RATIO_LB)
-    B = max(1, args.batch)
-    if B > 1:
-        # B independent samples per GPU (seeds offset by the rank stride), one instance + stream each
-        from framefusion_amd.batch import forward_many
-        samples = [(hidden, ptype)] + [video_tokens(F, P, d, p_change=args.p_change, sigma=SIGMA,
-                                                    seed=dp.sample_seed(1234, rank + world * b), dtype=torch.bfloat16,
-                                                    device=str(dev)) for b in range(1, B)]
-        ffs = [ff] + [ffa.FrameFusion(COST, THRESHOLD, RATIO_LB) for _ in range(1, B)]
-
     # the timed loop alternates between two copies of the sample so that no step finds its input
     # in the 256 MiB Infinity Cache just because the previous step read the very same buffer
     hidden_alt = hidden.clone()
     flip = [0]
 
     def step():
-        if B == 1:
-            flip[0] ^= 1
-            ff.prepare(ptype, P, 0, L, L, L)
-            out, pos, _ = ff(hidden_alt if flip[0] else hidden, [cos, sin], None)
-            return out
-        for f, (h, pt) in zip(ffs, samples):
-            f.prepare(pt, P, 0, L, L, L)
-        res = forward_many(ffs, [h for h, _ in samples], [[cos, sin] for _ in samples])
-        return res
+        flip[0] ^= 1
+        ff.prepare(ptype, P, 0, L, L, L)
+        out, pos, _ = ff(hidden_alt if flip[0] else hidden, [cos, sin], None)
+        return out
 
-    def barrier():
-        dp.barrier(dist)
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if B > 1:
-        reduced = sum(L - r[0].shape[1] for r in out)
-        out = out[0][0]
-    else:
-        reduced = L - out.shape[1]
+    # W untimed steps, then EXACTLY K steps between barrier + synchronize; max over ranks
+    t_max, elapsed, out = dp.timed_steps(dist, step, args.steps, args.warmup, dev)
+    reduced = L - out.shape[1]
     L_out = out.shape[1]
     info = ff.last_call
-
-    # whole-job numbers: max time over ranks, tokens summed over ranks
-    t_max, tok_all = dp.aggregate(dist, elapsed, float(reduced * args.steps), dev)
+    # whole-job numbers: tokens summed over ranks; one record per rank all_gathered for the report
+    _, tok_all = dp.aggregate(dist, elapsed, float(reduced * args.steps), dev)
+    per_rank = dp.gather_records(dist, (rank, dev.index, L, L_out, elapsed / args.steps * 1e3), dev)
+    B = 1
 
     result = None
     if rank == 0:
@@ -211,6 +204,10 @@ def main():
             "value": tok_all / t_max,
             "unit": "tokens/s",
             "n_gpus": world,
+            "rccl_ranks": dist.get_world_size() if dist is not None else 1,
+            "collective_backend": (dist.get_backend() if dist is not None else None),
+            "per_rank": [{"rank": int(r[0]), "gpu": int(r[1]), "tokens_in": int(r[2]), "tokens_out": int(r[3]),
+                          "ms_per_step": r[4]} for r in per_rank],
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,

@@ -252,8 +252,7 @@ class FrameFusion(nn.Module):
 
     def _merge_launch(self, hidden_states, position_embeddings, attention_mask, use_hint=True):
         """Enqueue the whole merge call on the current stream and return without waiting: the
-        state machine is advanced by _merge_complete.  (batch.forward_many launches several
-        samples on their own streams before completing any of them.)"""
+        state machine is advanced by _merge_complete."""
         _lib.require_gpu(hidden_states, "FrameFusion.forward")
         lib = _lib.load()
         bsz, L, d = hidden_states.size()

@@ -1,72 +1,68 @@
-"""CPU, world_size 2 over gloo: the data-parallel plumbing bench.py uses (sharding of independent
-samples, max-time / summed-token aggregation, length gather).  The data path itself has no
-collective, so this is all the N > 1 logic there is."""
+"""CPU, world_size 2 over gloo: the multi-rank skeleton of bench.py, driven through the PRODUCT's code path
+(framefusion_amd/dp.py): `python tests/dp_worker.py --gpus 2` launches its own two ranks exactly as
+`python bench.py --gpus 2` does (dp.launch_ranks -> torch.distributed.run on 127.0.0.1), rank 0's config
+is broadcast, every rank times its own independent sample, records are all_gathered and the whole-job
+numbers are max-time / summed-units.  The data path itself has no collective."""
+import json
 import os
-import socket
+import subprocess
 import sys
 
 import pytest
 import torch
-import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+def run_worker(*argv, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), *argv], capture_output=True,
+                         text=True, timeout=240, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout           # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
 
 
-def _worker(rank, world, port, out):
-    sys.path.insert(0, ROOT)
-    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank),
-                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    from framefusion_amd import dp
-    from oracle import ff_oracle as orc
-    from framefusion_amd.synth import video_tokens
-    dist = dp.init("gloo")
-    assert dist is not None and dist.get_world_size() == world
-    mine = dp.shard(5, world, rank)
-    reduced = 0
-    lens = (0, 0)
-    for idx in mine:     # each rank reduces its own samples with the CPU oracle (no GPU here)
-        h, pt = video_tokens(6, 8, 32, p_change=0.3, seed=dp.sample_seed(100, idx), pre=1, post=1, grid=0.125)
-        f = orc.OracleFrameFusion(0.3, 0.6, 0.1)
-        f.prepare(pt, 8, 1, 49, 48, h.shape[1])
-        o, _, _ = f.forward(h, torch.arange(h.shape[1])[None], None)
-        reduced += h.shape[1] - o.shape[1]
-        lens = (h.shape[1], o.shape[1])
-    dp.barrier(dist)
-    t_max, total = dp.aggregate(dist, 0.5 + rank, float(reduced), torch.device("cpu"))
-    gathered = dp.gather_lengths(dist, lens[0], lens[1], torch.device("cpu"))
-    out.put((rank, mine, reduced, t_max, total, gathered))
-    dist.destroy_process_group()
+@pytest.mark.timeout(300)
+def test_self_launched_two_ranks_over_gloo():
+    out = run_worker("--gpus", "2", "--steps", "3", "--warmup", "1", "--seed", "100")
+    assert out["n_gpus"] == 2 and out["ranks"] == 2
+    recs = out["records"]
+    assert len(recs) == 2
+    # rank 1 started with seed 1100 locally; the broadcast made rank 0's seed the job's seed
+    assert [r[3] for r in recs] == [100.0, 100.0] and out["seed"] == 100
+    # independent samples (seed + rank): both reduce something, and differently
+    assert all(r[0] > r[1] for r in recs) and recs[0][1] != recs[1][1]
+    assert out["units"] == sum((r[0] - r[1]) * out["steps"] for r in recs)
+    assert out["t_max"] == out["t_all"] >= max(r[2] for r in recs) * out["steps"] / 1e3 * 0.5
 
 
-@pytest.mark.timeout(120)
-def test_two_rank_sharding_and_aggregation():
-    world = 2
-    ctx = mp.get_context("spawn")
-    out = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, out)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = sorted(out.get(timeout=100) for _ in range(world))
-    for p in procs:
-        p.join(timeout=30)
-        assert p.exitcode == 0
-    (r0, m0, red0, t0, tot0, g0), (r1, m1, red1, t1, tot1, g1) = res
-    assert m0 == [0, 2, 4] and m1 == [1, 3]                      # round-robin, disjoint, complete
-    assert t0 == t1 == 1.5                                        # slowest rank's time everywhere
-    assert tot0 == tot1 == float(red0 + red1) and red0 > 0 and red1 > 0
-    assert g0 == g1 and len(g0) == 2 and all(a > b for a, b in g0)
+@pytest.mark.timeout(300)
+def test_single_rank_does_not_launch():
+    out = run_worker("--gpus", "1", "--steps", "2", "--warmup", "0")
+    assert out["n_gpus"] == 1 and out["ranks"] == 1 and len(out["records"]) == 1
 
 
 def test_single_process_helpers():
     from framefusion_amd import dp
-    assert dp.shard(5, 1, 0) == [0, 1, 2, 3, 4]
-    assert dp.aggregate(None, 1.25, 7.0, torch.device("cpu")) == (1.25, 7.0)
-    assert dp.gather_lengths(None, 10, 4, torch.device("cpu")) == [(10, 4)]
-    assert dp.init("gloo") is None or True
+    cpu = torch.device("cpu")
+    assert dp.shard(5, 1, 0) == [0, 1, 2, 3, 4] and dp.shard(5, 2, 1) == [1, 3]
+    assert dp.aggregate(None, 1.25, 7.0, cpu) == (1.25, 7.0)
+    assert dp.gather_lengths(None, 10, 4, cpu) == [(10, 4)]
+    assert dp.gather_records(None, (1, 2.5), cpu) == [[1.0, 2.5]]
+    assert dp.broadcast_config(None, dict(seed=3, p=0.5), cpu) == dict(seed=3, p=0.5)
+    assert dp.init("gloo") is None
+    t_max, mine, out = dp.timed_steps(None, lambda: 7, 3, 1, cpu)
+    assert out == 7 and t_max == mine > 0
+    dp.launch_ranks(1, "unused", [])             # one rank: returns
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    """The product has no CPU path: bench.py must fail loudly, not fall back."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=240, cwd=ROOT)
+    assert res.returncode == 2 and "MI355X" in res.stderr

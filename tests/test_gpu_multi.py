@@ -1,0 +1,68 @@
+"""GPU: bench.py as the driver runs it, including N > 1.
+
+* 2 ranks over RCCL (one per GPU) when the box has >= 2 GPUs - `python bench.py --gpus 2` must start its own
+  ranks, broadcast rank 0's config, all_gather the per-rank records and print ONE JSON line;
+* on a 1-GPU box the same N = 2 job runs with both ranks on GPU 0 and gloo carrying the scalars
+  (`--oversubscribe --backend gloo`): every line of the multi-rank path except RCCL itself, with two
+  processes driving the HIP kernels concurrently;
+* the N = 1 line carries the contract's fields (roofline, cpu_baseline, ...)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*argv):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True,
+                         timeout=600, env=env, cwd=ROOT)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    return json.loads(lines[0])
+
+
+def check_multi(out, n):
+    assert out["n_gpus"] == n and out["rccl_ranks"] == n and out["scaling"] == "weak"
+    assert [r["rank"] for r in out["per_rank"]] == list(range(n))
+    assert all(r["tokens_in"] == 64 * 576 and 0 < r["tokens_out"] < r["tokens_in"] for r in out["per_rank"])
+    reduced = sum(r["tokens_in"] - r["tokens_out"] for r in out["per_rank"])
+    assert out["value"] == pytest.approx(reduced * out["steps"] / (out["ms_per_step"] * 1e-3 * out["steps"]), rel=1e-6)
+    assert "cpu_baseline" not in out                     # N = 1 only
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_over_rccl():
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    out = run_bench("--gpus", "2", "--steps", "10", "--warmup", "3")
+    check_multi(out, 2)
+    assert out["collective_backend"] == "nccl"
+    assert sorted(r["gpu"] for r in out["per_rank"]) == [0, 1]
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_sharing_one_gpu_over_gloo():
+    out = run_bench("--gpus", "2", "--steps", "10", "--warmup", "3", "--backend", "gloo", "--oversubscribe")
+    check_multi(out, 2)
+    assert out["collective_backend"] == "gloo"
+
+
+@pytest.mark.timeout(900)
+def test_single_gpu_line_has_the_contract_fields():
+    out = run_bench("--steps", "10", "--warmup", "3", "--cpu-calls", "1")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in out, key
+    assert out["n_gpus"] == 1 and out["dtype"] == "bf16" and out["vs_baseline"] is None
+    rf = out["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0.3 < rf["frac"] < 1.0 and rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"])
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    assert "workload" in out["config"] and "model" not in out["config"]
