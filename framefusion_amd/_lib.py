@@ -28,7 +28,7 @@ STAT_ERROR = 11
 ERR_BIT_BARRIER, ERR_BIT_LAYOUT = 1, 2
 STAT_WORDS = 32
 MAX_AUX = 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class FFAux(C.Structure):
@@ -65,7 +65,7 @@ PROTOTYPES = {
                               _vp]),
     "ff_merge_finish": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                _i64, C.POINTER(FFAux), _i32, _vp, _vp, _sz, _vp]),
-    "ff_prune_step": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp,
+    "ff_prune_step": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _i32, _i64, _i64, _vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp,
                              _vp, C.POINTER(FFAux), _i32, _vp, _sz, _vp]),
     "ff_plan_topk": (_i32, [_vp, _i32, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ff_merge_finish_topk": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,

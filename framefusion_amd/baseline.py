@@ -46,11 +46,22 @@ class FixedSparsityMerging:
 
     def __init__(self, sparsity: Sequence[float] = (0.1,) * 28):
         self.sparsity = list(sparsity)
-        self.patch_type: Optional[torch.Tensor] = None
+        self._ptype_gen = 0
+        self.patch_type = None
         self.patch_num: Optional[int] = None
         self._ftn: Optional[int] = None
         self._scratch = {}
         self.last_call = None
+
+    @property
+    def patch_type(self) -> Optional[torch.Tensor]:
+        return self._patch_type
+
+    @patch_type.setter
+    def patch_type(self, value):
+        # any assignment invalidates the by-patch order cached in the scratch (keyed on the generation)
+        self._patch_type = value
+        self._ptype_gen += 1
 
     def prepare(self, patch_type: torch.Tensor, patch_num: int):
         """New prefill: the full-length patch_type row of the packer."""
@@ -105,8 +116,7 @@ class FixedSparsityMerging:
         hidden = hidden_states if hidden_states.is_contiguous() else hidden_states.contiguous()
         sc = self._scratch_for(device, L, dtype)
         stream = _lib.stream_ptr()
-        order_key = (ptype.data_ptr(), L)
-        order_valid = 1 if sc.order_valid_for == order_key else 0
+        order_valid = 1 if sc.order_valid_for == (self._ptype_gen, L) else 0
         if sc.dirty:
             sc.ws.zero_()
             sc.stats.zero_()
@@ -144,15 +154,27 @@ class FixedSparsityMerging:
         token_mask = sc.keep[:L].bool().view(1, L)          # a copy: the scratch is reused by the next layer
 
         st = sc.wait_stats(seq)
+        if int(st[_lib.STAT_ERROR]):
+            sc.dirty = True
+            sc.order_valid_for = None
+            raise FrameFusionHipError(f"device-side check failed in the merge call (error bits {int(st[_lib.STAT_ERROR]):#x})")
         nv, L_out = int(st[_lib.STAT_NV]), int(st[_lib.STAT_LOUT])
         if nv <= 0:
             raise ValueError("No token in this patch")                               # :982-983
+        if L_out == L:
+            # the forced top-k folded nothing (its only candidate was by-patch slot 0, which has no
+            # predecessor): the merge kernel wrote nothing - the caller's tensors ARE the result and the
+            # by-patch order in the scratch still describes them
+            self.last_call = dict(kind="merge", L_in=L, L_out=L, nv=nv, ftn=ftn, k=int(st[_lib.STAT_K]),
+                                  scratch=sc, dtype=dtype, order=sc.order)
+            sc.order_valid_for = (self._ptype_gen, L)
+            return hidden_states, token_mask, residual
         self._ftn = ftn - (L - L_out)                       # every dropped token was a visual one
         self.patch_type = ptype_out[:, :L_out]                                       # :1051
         self.last_call = dict(kind="merge", L_in=L, L_out=L_out, nv=nv, ftn=ftn, k=int(st[_lib.STAT_K]),
                               scratch=sc, dtype=dtype, order=sc.order)
         sc.order, sc.order_next = sc.order_next, sc.order
-        sc.order_valid_for = (ptype_out.data_ptr(), L_out)
+        sc.order_valid_for = (self._ptype_gen, L_out)
         if rebuild is not None:
             rebuild(L_out)
         return out[:, :L_out], token_mask, (res_out[:, :L_out] if res_out is not None else None)

@@ -6,17 +6,27 @@
 namespace ff {
 int launch_plan_merge(const void* sim, int dtype, const int32_t* order, int64_t L, double thr, double sub,
                       double ratio_lb, uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
-                      void* ws, const int* l0_copies, int* zero_next, int64_t* host_mapped, int64_t seq,
+                      void* ws, size_t ws_bytes, bool have_tables, int64_t* host_mapped, int64_t seq,
                       hipStream_t st, long long force_k);
-size_t plan_ws_bytes(int64_t L);
-int* ws_l0_copies(void* ws, int64_t seq);
+int launch_plan_prune(const void* imp, int dtype, int64_t S, int64_t start, int64_t n_img, int64_t k,
+                      uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats, void* ws, size_t ws_bytes,
+                      bool have_tables, hipStream_t st);
+size_t plan_ws_front_bytes(int64_t L);
+size_t plan_ws_tail_bytes(int64_t L);
+int* ws_l0(void* ws);
+int* ws_t16_end(void* ws, size_t ws_bytes);
+void table_regions(void* ws, size_t ws_bytes, int64_t L, void** a, size_t* a_bytes, void** b, size_t* b_bytes);
+int zero_tables(void* ws, size_t ws_bytes, int64_t L, hipStream_t st);
 int launch_merge_compact(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
                          const int32_t* order, const uint8_t* member, int fold, const int32_t* dst,
                          const uint8_t* keep, const ff_aux_t* aux_host, int n_aux, int32_t* order_next,
-                         int64_t* stats, hipStream_t st, bool skip_identity);
+                         int64_t* stats, hipStream_t st, bool skip_identity, void* zero_a, size_t zero_a_bytes,
+                         void* zero_b, size_t zero_b_bytes);
 int launch_similarity_any(const void* hidden, int dtype, int64_t L, int64_t d, const int64_t* ptype,
-                          int32_t* order, int64_t* stats, void* sim, int* l0, double thr,
+                          int32_t* order, int64_t* stats, void* sim, int* l0, int* t16_end, double thr,
                           int64_t hint_pre, int64_t hint_patches, int64_t hint_frames, hipStream_t st);
+int launch_head_mean(const void* attn_w, int dtype, int64_t H, int64_t num, int64_t S, void* importance,
+                     int64_t lo, int64_t hi, int* l0, int* t16_end, hipStream_t st);
 }  // namespace ff
 
 extern "C" int ff_abi_version(void) { return FF_ABI_VERSION; }
@@ -35,8 +45,9 @@ extern "C" const char* ff_error_string(int code) {
 extern "C" size_t ff_workspace_bytes(int64_t L, int64_t patch_num) {
     (void)patch_num;
     if (L < 0) return 0;
-    // select statistics tables (ff_plan.hip) followed by the per-slice rows of the order kernel
-    return ff::plan_ws_bytes(L) + ((size_t)(L / 4096) + 1) * 64 + 256;
+    // front: level-0 select table + fp32 level rows (ff_plan.hip), the per-slice rows of the order
+    // kernel; tail (down from the end): the per-slice level-1 select tables
+    return ff::plan_ws_front_bytes(L) + ((size_t)(L / 4096) + 1) * 64 + 256 + ff::plan_ws_tail_bytes(L);
 }
 
 extern "C" int ff_merge_begin(const void* hidden, int dtype, int64_t L, int64_t d, const int64_t* patch_type,
@@ -57,9 +68,12 @@ extern "C" int ff_merge_begin(const void* hidden, int dtype, int64_t L, int64_t 
         if (rc) return rc;
     }
     if (L == 0) return FF_OK;
-    // the similarity kernel also accumulates the level-0 select statistics of this call
-    return ff::launch_similarity_any(hidden, dtype, L, d, patch_type, order, stats, sim, ff::ws_l0_copies(ws, seq),
-                                     threshold, hint_pre, patch_num, hinted ? hint_frames : 0, (hipStream_t)stream);
+    // the similarity kernel also accumulates the select tables of this call (zero on entry: cleared by
+    // the previous call's merge kernel)
+    (void)seq;
+    return ff::launch_similarity_any(hidden, dtype, L, d, patch_type, order, stats, sim, ff::ws_l0(ws),
+                                     ff::ws_t16_end(ws, ws_bytes), threshold, hint_pre, patch_num,
+                                     hinted ? hint_frames : 0, (hipStream_t)stream);
 }
 
 // second half of a merge call: select (policy or forced k) + run merge (fold 1: main.py's sequential
@@ -78,13 +92,19 @@ static int merge_finish(const void* hidden, void* hidden_out, int dtype, int64_t
     if (((uintptr_t)hidden & 15) || ((uintptr_t)hidden_out & 15) || ((d * esz) & 15)) return FF_ERR_ALIGN;
     if (order_next && ((uintptr_t)member & 15)) return FF_ERR_ALIGN;
     if (L == 0) return FF_OK;
-    int rc = ff::launch_plan_merge(sim, dtype, order, L, threshold, sub, ratio_lb, member, dst, keep, stats, ws,
-                                   ff::ws_l0_copies(ws, seq), ff::ws_l0_copies(ws, seq + 1), stats_host_mapped, seq,
-                                   (hipStream_t)stream, force_k);
+    if (((uintptr_t)member & 7) || ((uintptr_t)dst & 15) || ((uintptr_t)keep & 15) || ((uintptr_t)order & 15) ||
+        ((uintptr_t)sim & 15) || ((uintptr_t)ws & 15))
+        return FF_ERR_ALIGN;
+    int rc = ff::launch_plan_merge(sim, dtype, order, L, threshold, sub, ratio_lb, member, dst, keep, stats, ws, ws_bytes,
+                                   true, stats_host_mapped, seq, (hipStream_t)stream, force_k);
     if (rc) return rc;
-    // when the select folds nothing the merge kernel exits at once: see ff_merge_finish in the header
+    // when the select folds nothing the merge kernel exits at once: see ff_merge_finish in the header;
+    // its extra workgroups clear the select tables for the next call either way
+    void *za, *zb;
+    size_t zab, zbb;
+    ff::table_regions(ws, ws_bytes, L, &za, &zab, &zb, &zbb);
     return ff::launch_merge_compact(hidden, hidden_out, dtype, L, d, L_cap, order, member, fold, dst, keep, aux_host,
-                                    n_aux, order_next, stats, (hipStream_t)stream, true);
+                                    n_aux, order_next, stats, (hipStream_t)stream, true, za, zab, zb, zbb);
 }
 
 extern "C" int ff_merge_finish(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
@@ -122,18 +142,39 @@ extern "C" int ff_merge_step(const void* hidden, void* hidden_out, int dtype, in
 }
 
 extern "C" int ff_prune_step(const void* hidden, void* hidden_out, int dtype, int64_t S, int64_t d, int64_t L_cap,
-                             const void* attn_w, int64_t H, int64_t num, void* importance, int64_t start,
-                             int64_t n_img, int64_t k, uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
-                             const ff_aux_t* aux_host, int n_aux, void* ws, size_t ws_bytes, ff_stream_t stream) {
-    if (!attn_w || !importance) return FF_ERR_ARG;
+                             const void* attn_w, int w_dtype, int64_t H, int64_t num, void* importance,
+                             int tables_ready,
+                             int64_t start, int64_t n_img, int64_t k, uint8_t* member, int32_t* dst, uint8_t* keep,
+                             int64_t* stats, const ff_aux_t* aux_host, int n_aux, void* ws, size_t ws_bytes,
+                             ff_stream_t stream) {
+    if (!attn_w || !importance || !hidden || !hidden_out || !member || !dst || !keep || !stats || !ws) return FF_ERR_ARG;
+    if (S < 0 || d < 1 || H < 1 || num < 1 || start < 0 || n_img < 0 || start + n_img > S || k < 0) return FF_ERR_ARG;
+    if (dtype != FF_F32 && dtype != FF_BF16 && dtype != FF_F16) return FF_ERR_ARG;
+    if (w_dtype != FF_F32 && w_dtype != FF_BF16 && w_dtype != FF_F16) return FF_ERR_ARG;
+    if (S >= (1ll << 29)) return FF_ERR_UNSUPPORTED;
+    if (ws_bytes < ff_workspace_bytes(S, 1)) return FF_ERR_WORKSPACE;
+    if (((uintptr_t)attn_w & 15) || ((uintptr_t)importance & 15) || ((uintptr_t)member & 7) || ((uintptr_t)dst & 15) ||
+        ((uintptr_t)keep & 15) || ((uintptr_t)ws & 15))
+        return FF_ERR_ALIGN;
+    if (S == 0) return FF_OK;
+    hipStream_t st = (hipStream_t)stream;
     const void* imp = attn_w;
+    bool have_tables = tables_ready != 0;          // a [S] importance whose producer already filled the tables
     if (H * num != 1) {
-        int rc = ff_head_mean(attn_w, dtype, H, num, S, importance, stream);
+        // head mean (main.py:69-70) + the select tables of its output in the same launch
+        int rc = ff::launch_head_mean(attn_w, w_dtype, H, num, S, importance, start, start + n_img, ff::ws_l0(ws),
+                                      ff::ws_t16_end(ws, ws_bytes), st);
         if (rc) return rc;
         imp = importance;
+        have_tables = true;
     }
-    int rc = ff_plan_prune(imp, dtype, S, start, n_img, k, member, dst, keep, stats, ws, ws_bytes, stream);
+    int rc = ff::launch_plan_prune(imp, w_dtype, S, start, n_img, k, member, dst, keep, stats, ws, ws_bytes, have_tables, st);
     if (rc) return rc;
-    return ff_merge_compact(hidden, hidden_out, dtype, S, d, L_cap, nullptr, member, 0, dst, keep, aux_host, n_aux,
-                            stream);
+    void *za = nullptr, *zb = nullptr;
+    size_t zab = 0, zbb = 0;
+    if (have_tables) ff::table_regions(ws, ws_bytes, S, &za, &zab, &zb, &zbb);
+    const int64_t esz = dtype == FF_F32 ? 4 : 2;
+    if (((uintptr_t)hidden & 15) || ((uintptr_t)hidden_out & 15) || ((d * esz) & 15)) return FF_ERR_ALIGN;
+    return ff::launch_merge_compact(hidden, hidden_out, dtype, S, d, L_cap, nullptr, member, FF_FOLD_DROP, dst, keep,
+                                    aux_host, n_aux, nullptr, nullptr, st, false, za, zab, zb, zbb);
 }

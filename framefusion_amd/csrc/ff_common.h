@@ -165,6 +165,45 @@ __device__ inline int block_excl_scan(int v, int* scratch, int& total) {
     return base + incl - v;
 }
 
+// ---- select tables (ff_plan.hip; filled by the similarity / importance kernels) ------------------
+// Level 0: kL0Copies copies of [256 bins of the key's top byte | count(value >= thr)], row stride
+// kL0Stride ints, at the START of the workspace.  Level 1: for every slice of kSelSlice consecutive
+// values, kT16Copies copies of a 65536-bin table indexed by the key's top 16 bits, laid out DOWN from
+// the END of the workspace (slice g ends at ws_end - g * kT16SliceInts): both locations depend on
+// neither L nor the call, so "zero on entry" survives calls of different lengths.
+constexpr int kSelSlice = 4096;
+constexpr int kL0Copies = 16;
+constexpr int kL0Stride = 260;                    // 256 bins + count + pad
+constexpr int kL0Ints = kL0Copies * kL0Stride;
+constexpr int kT16Copies = 2;
+constexpr size_t kT16SliceInts = (size_t)kT16Copies * 65536;
+
+__device__ __host__ inline int* t16_slice(int* t16_end, int g) { return t16_end - (size_t)(g + 1) * kT16SliceInts; }
+// bin of the 16-bit key prefix inside a level-1 table: the two bytes swapped, so that NEIGHBOURING key
+// values (a video's similarities are a dozen adjacent bf16 values) sit 1 KiB apart - on different
+// cache lines and memory channels - instead of sharing one line whose atomics would serialise
+__device__ __host__ inline uint32_t t16_bin(uint32_t key16) { return ((key16 & 0xffu) << 8) | (key16 >> 8); }
+
+// table[idx] += 1 for every lane with `valid`.  Lanes that hold the same idx are folded into ONE
+// non-returning atomic for the first kIters distinct values (video similarities take a dozen distinct
+// bf16 values: unfolded, thousands of atomics pile up on a few memory-side words); whatever is
+// left after kIters rounds adds directly.
+template <int kIters>
+__device__ inline void wave_agg_add(int* table, uint32_t idx, bool valid) {
+    unsigned long long rem = __ballot(valid);
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int it = 0; it < kIters; ++it) {
+        if (rem == 0ull) break;                                   // wave-uniform
+        const int first = __ffsll((long long)rem) - 1;
+        const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)idx, first);
+        const unsigned long long m = __ballot(valid && idx == v) & rem;
+        if (lane == first) atomicAdd(&table[v], (int)__popcll(m));
+        rem &= ~m;
+    }
+    if ((rem >> lane) & 1ull) atomicAdd(&table[idx], 1);
+}
+
 template <int NW>
 __device__ inline int block_sum_i(int v, int* scratch) {
     v = wave_sum_i(v);

@@ -96,6 +96,58 @@ __global__ __launch_bounds__(256) void k_lq_softmax(const float* __restrict__ sc
     }
 }
 
+// Select tables of freshly computed importances (one value per lane, 64 consecutive positions per
+// wave, so the slice is wave-uniform): what the plan kernel of the prune call needs (ff_plan.hip).
+template <int DT>
+__device__ inline void importance_tables(float value, int s, bool in_range, int* l0, int* t16_end) {
+    using A = Act<DT>;
+    uint32_t bits;
+    if constexpr (DT == FF_F32) bits = __float_as_uint(value);
+    else if constexpr (DT == FF_BF16) bits = __float_as_uint(A::rnd(value)) >> 16;
+    else { _Float16 h = (_Float16)value; bits = (uint32_t)__builtin_bit_cast(uint16_t, h); }
+    const uint32_t key = order_key<DT>(bits);
+    wave_agg_add<3>(l0 + (blockIdx.x & (kL0Copies - 1)) * kL0Stride, key >> (A::kKeyBits - 8), in_range);
+    int* t16 = t16_slice(t16_end, uniform(s) / kSelSlice) + (wave_id() & (kT16Copies - 1)) * 65536;
+    wave_agg_add<2>(t16, t16_bin(key >> (A::kKeyBits - 16)), in_range);
+}
+
+// importance[s] = T(mean over H*num of attn_w[h, n, s]) accumulated in fp32 (main.py:70); with l0 the
+// select tables of the values in [lo, hi) are accumulated on the way.
+template <int DT>
+__global__ __launch_bounds__(256) void k_head_mean(const void* __restrict__ w, int rows, int S,
+                                                   void* __restrict__ imp, int lo, int hi, int* __restrict__ l0,
+                                                   int* t16_end) {
+    using A = Act<DT>;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    float v = 0.f;
+    if (s < S) {
+        float acc = 0.f;
+        for (int r = 0; r < rows; ++r) acc += A::load1(w, (int64_t)r * S + s);
+        v = A::rnd(acc / (float)rows);
+        A::store1(imp, s, v);
+    }
+    if (l0) importance_tables<DT>(v, s, s >= lo && s < hi, l0, t16_end);
+}
+
+int launch_head_mean(const void* attn_w, int dtype, int64_t H, int64_t num, int64_t S, void* importance,
+                     int64_t lo, int64_t hi, int* l0, int* t16_end, hipStream_t st) {
+    const unsigned blocks = (unsigned)((S + 255) / 256);
+    switch (dtype) {
+        case FF_F32:
+            hipLaunchKernelGGL(k_head_mean<FF_F32>, dim3(blocks), dim3(256), 0, st, attn_w, (int)(H * num), (int)S, importance, (int)lo, (int)hi, l0, t16_end);
+            break;
+        case FF_BF16:
+            hipLaunchKernelGGL(k_head_mean<FF_BF16>, dim3(blocks), dim3(256), 0, st, attn_w, (int)(H * num), (int)S, importance, (int)lo, (int)hi, l0, t16_end);
+            break;
+        case FF_F16:
+            hipLaunchKernelGGL(k_head_mean<FF_F16>, dim3(blocks), dim3(256), 0, st, attn_w, (int)(H * num), (int)S, importance, (int)lo, (int)hi, l0, t16_end);
+            break;
+        default:
+            return FF_ERR_ARG;
+    }
+    return (int)hipGetLastError();
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void k_lq_mean(const float* __restrict__ probs_f, int rows, int S,
                                                  void* __restrict__ imp) {
@@ -126,6 +178,14 @@ static int launch_lq(const void* q, const void* k, int64_t H, int64_t H_kv, int6
 }
 
 }  // namespace ff
+
+extern "C" int ff_head_mean(const void* attn_w, int dtype, int64_t H, int64_t num, int64_t S, void* importance,
+                            ff_stream_t stream) {
+    if (!attn_w || !importance || H < 1 || num < 1 || S < 0) return FF_ERR_ARG;
+    if (S >= (1ll << 31) || H * num >= (1ll << 31)) return FF_ERR_UNSUPPORTED;
+    if (S == 0) return FF_OK;
+    return ff::launch_head_mean(attn_w, dtype, H, num, S, importance, 0, 0, nullptr, nullptr, (hipStream_t)stream);
+}
 
 extern "C" int ff_last_query_attention(const void* q_last, const void* k, int dtype, int64_t H, int64_t H_kv,
                                        int64_t num, int64_t S, int64_t dh, double scale, int causal,

@@ -15,8 +15,6 @@
 // order with a rounding to the activation dtype T after EVERY add, then one rounded divide by
 // T(n+1) - the order CPU index_add_ applies; fp32-accumulate-then-round differs on ~23 % of
 // elements by more than 1e-3 relative.
-#include <stdlib.h>
-
 #include "ff_common.h"
 
 namespace ff {
@@ -71,16 +69,39 @@ struct Batch {
     bool last;
 };
 
-template <int DT, int kDepth, int kNt>
+// Select tables to clear for the next call (ff_plan.hip): two byte ranges, multiples of 16.
+struct ZeroJob {
+    uint4* a; uint4* b;
+    long long a_n16, b_n16;
+    int n_blocks;
+};
+
+template <int DT>
 __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
     const char* __restrict__ hidden, char* __restrict__ out, uint32_t row_bytes, int L, int64_t L_cap,
     const int32_t* __restrict__ order, const uint8_t* __restrict__ member, int fold,
-    const int32_t* __restrict__ dst, const uint8_t* __restrict__ keep, AuxPack aux, int kSlots, int n_main,
-    int reverse, int n_aux_blocks, int32_t* __restrict__ order_next, int64_t* __restrict__ stats,
-    const int64_t* __restrict__ identity_stats) {
+    const int32_t* __restrict__ dst, const uint8_t* __restrict__ keep, AuxPack aux, int n_main,
+    int n_aux_blocks, int n_next_blocks, int32_t* __restrict__ order_next, int64_t* __restrict__ stats,
+    const int64_t* __restrict__ identity_stats, ZeroJob zero) {
     using A = Act<DT>;
     constexpr int E = A::kPer16;
+    constexpr int kDepth = 4;                     // row pieces requested per batch (two batches in flight)
+    constexpr int kSlots = kSlotsDefault;
     const int lane = lane_id();
+    if ((int)blockIdx.x >= n_main + n_aux_blocks + n_next_blocks) {
+        // ---- the select tables of this call have been consumed by the plan kernel: clear them for the
+        // next call's producer (runs even when nothing is folded)
+        if (blockIdx.y != 0) return;
+        const long long total = zero.a_n16 + zero.b_n16;
+        const long long per = (total + zero.n_blocks - 1) / zero.n_blocks;
+        const long long z0 = ((long long)blockIdx.x - n_main - n_aux_blocks - n_next_blocks) * per;
+        const long long z1 = min(z0 + per, total);
+        for (long long z = z0 + threadIdx.x; z < z1; z += kMergeThreads) {
+            uint4* p = z < zero.a_n16 ? zero.a + z : zero.b + (z - zero.a_n16);
+            *p = make_uint4(0, 0, 0, 0);
+        }
+        return;
+    }
     // nothing folded (a merge call whose threshold set is empty, main.py:264-266): the reduced
     // sequence IS the input, the caller keeps using its own tensors and this launch writes nothing
     if (identity_stats && identity_stats[FF_STAT_MERGED] == 0) return;
@@ -134,7 +155,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
     // slot groups are walked from the END of the by-patch order: the similarity pass read the rows
     // in ascending order, so its most recently fetched rows - the ones the 256 MiB Infinity Cache
     // still holds - are the first ones this pass asks for
-    const int t0 = (reverse ? (n_main - 1 - (int)blockIdx.x) : (int)blockIdx.x) * kSlots;
+    const int t0 = (n_main - 1 - (int)blockIdx.x) * kSlots;
     const int cb = uniform(blockIdx.y * kMergeWaves + wave_id());     // 1 KiB column tile
     const uint32_t col = (uint32_t)cb * 1024u;
     if (col >= row_bytes) return;
@@ -179,7 +200,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
 #pragma unroll
         for (int u = 0; u < kDepth; ++u) {
             const bool is_mem = (mem_bits >> u) & 1u;
-            if (u < take && (fold || !is_mem)) b.buf[u] = buf_load16<(kNt & 2) ? 2 : 0>(piece(b.idx[u]), voff);
+            if (u < take && (fold || !is_mem)) b.buf[u] = buf_load16<2>(piece(b.idx[u]), voff);
         }
     };
 
@@ -200,7 +221,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
 #pragma unroll
             for (int e = 0; e < E; ++e) o[e] = acc[e];
         }
-        buf_store16<(kNt & 1) ? 2 : 0>(make_rsrc(out + (int64_t)open_r * row_bytes + col, blk_bytes), voff, A::pack(o));
+        buf_store16<2>(make_rsrc(out + (int64_t)open_r * row_bytes + col, blk_bytes), voff, A::pack(o));
     };
     auto fold_batch = [&](Batch<kDepth>& b) {
 #pragma unroll
@@ -263,72 +284,39 @@ __global__ __launch_bounds__(256) void k_gather_mask(const char* __restrict__ ma
     }
 }
 
-// importance[s] = T(mean over H*num of attn_w[h, n, s]) accumulated in fp32 (main.py:70).
-template <int DT>
-__global__ __launch_bounds__(256) void k_head_mean(const void* __restrict__ w, int rows, int S,
-                                                   void* __restrict__ imp) {
-    using A = Act<DT>;
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= S) return;
-    float acc = 0.f;
-    for (int r = 0; r < rows; ++r) acc += A::load1(w, (int64_t)r * S + s);
-    A::store1(imp, s, acc / (float)rows);
-}
-
-template <int DT>
-static void launch_mc(dim3 grid, hipStream_t st, int depth, const char* h, char* o, uint32_t row_bytes, int L,
-                      int64_t L_cap, const int32_t* order, const uint8_t* member, int fold, const int32_t* dst,
-                      const uint8_t* keep, const AuxPack& pack, int slots, int n_main, int reverse,
-                      int n_aux_blocks, int32_t* order_next, int64_t* stats, const int64_t* identity_stats) {
-    static int nt = -1;
-    if (nt < 0) { const char* e = getenv("FF_MERGE_NT"); nt = e ? atoi(e) : 3; }
-#define FF_MC_LAUNCH(DEPTH, NT)                                                                                    \
-    hipLaunchKernelGGL((k_merge_compact<DT, DEPTH, NT>), grid, dim3(kMergeThreads), 0, st, h, o, row_bytes, L, L_cap, \
-                       order, member, fold, dst, keep, pack, slots, n_main, reverse, n_aux_blocks, order_next, stats, \
-                       identity_stats)
-    if (depth == 8) { FF_MC_LAUNCH(8, 0); return; }
-    switch (nt) {
-        case 1: FF_MC_LAUNCH(4, 1); break;
-        case 2: FF_MC_LAUNCH(4, 2); break;
-        case 3: FF_MC_LAUNCH(4, 3); break;
-        default: FF_MC_LAUNCH(4, 0);
-    }
-#undef FF_MC_LAUNCH
-}
-
 int launch_merge_compact(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
                          const int32_t* order, const uint8_t* member, int fold, const int32_t* dst,
                          const uint8_t* keep, const ff_aux_t* aux_host, int n_aux, int32_t* order_next,
-                         int64_t* stats, hipStream_t st, bool skip_identity) {
+                         int64_t* stats, hipStream_t st, bool skip_identity, void* zero_a, size_t zero_a_bytes,
+                         void* zero_b, size_t zero_b_bytes) {
     AuxPack pack;
     pack.n = keep ? n_aux : 0;
     for (int x = 0; x < pack.n; ++x) pack.a[x] = aux_host[x];
     for (int x = pack.n; x < FF_MAX_AUX; ++x) pack.a[x] = ff_aux_t{nullptr, nullptr, 0, 0};
     const int64_t row_bytes = d * (dtype == FF_F32 ? 4 : 2);
     const int nblk = (int)((row_bytes + 1023) / 1024);
-    static int slots = 0, depth = 0, reverse = 1;   // development knobs (FF_MERGE_*), defaults are the tuned values
-    if (!slots) {
-        const char* e1 = getenv("FF_MERGE_SLOTS");
-        const char* e2 = getenv("FF_MERGE_DEPTH");
-        slots = e1 ? atoi(e1) : kSlotsDefault;
-        depth = e2 ? atoi(e2) : 4;
-        const char* e4 = getenv("FF_MERGE_REVERSE");
-        reverse = e4 ? atoi(e4) : 1;
-        if (slots < 1 || slots > 56) slots = kSlotsDefault;
-    }
-    const int n_main = (int)((L + slots - 1) / slots);
+    const int n_main = (int)((L + kSlotsDefault - 1) / kSlotsDefault);
     const int n_aux_blocks = pack.n ? (int)((L + kMergeWaves * 4 - 1) / (kMergeWaves * 4)) : 0;
     if (!order || !stats) order_next = nullptr;
     const int n_next_blocks = order_next ? (int)((L + kMergeThreads * 16 - 1) / (kMergeThreads * 16)) : 0;
-    const dim3 grid((unsigned)(n_main + n_aux_blocks + n_next_blocks), (unsigned)((nblk + kMergeWaves - 1) / kMergeWaves));
+    ZeroJob zero{(uint4*)zero_a, (uint4*)zero_b, (long long)(zero_a_bytes / 16), (long long)(zero_b_bytes / 16), 0};
+    const long long z16 = zero.a_n16 + zero.b_n16;
+    if (z16 > 0) zero.n_blocks = (int)min((long long)256, (z16 + kMergeThreads * 16 - 1) / (kMergeThreads * 16));
+    const dim3 grid((unsigned)(n_main + n_aux_blocks + n_next_blocks + zero.n_blocks),
+                    (unsigned)((nblk + kMergeWaves - 1) / kMergeWaves));
     const char* h = (const char*)hidden;
     char* o = (char*)hidden_out;
     const int64_t* ident = (skip_identity && stats) ? stats : nullptr;
+#define FF_MC_LAUNCH(DT)                                                                                               \
+    hipLaunchKernelGGL((k_merge_compact<DT>), grid, dim3(kMergeThreads), 0, st, h, o, (uint32_t)row_bytes, (int)L, L_cap, \
+                       order, member, fold, dst, keep, pack, n_main, n_aux_blocks, n_next_blocks, order_next, stats, ident, \
+                       zero)
     switch (dtype) {
-        case FF_F32: launch_mc<FF_F32>(grid, st, depth, h, o, (uint32_t)row_bytes, (int)L, L_cap, order, member, fold, dst, keep, pack, slots, n_main, reverse, n_aux_blocks, order_next, stats, ident); break;
-        case FF_BF16: launch_mc<FF_BF16>(grid, st, depth, h, o, (uint32_t)row_bytes, (int)L, L_cap, order, member, fold, dst, keep, pack, slots, n_main, reverse, n_aux_blocks, order_next, stats, ident); break;
-        default: launch_mc<FF_F16>(grid, st, depth, h, o, (uint32_t)row_bytes, (int)L, L_cap, order, member, fold, dst, keep, pack, slots, n_main, reverse, n_aux_blocks, order_next, stats, ident);
+        case FF_F32: FF_MC_LAUNCH(FF_F32); break;
+        case FF_BF16: FF_MC_LAUNCH(FF_BF16); break;
+        default: FF_MC_LAUNCH(FF_F16);
     }
+#undef FF_MC_LAUNCH
     return (int)hipGetLastError();
 }
 
@@ -352,7 +340,7 @@ extern "C" int ff_merge_compact(const void* hidden, void* hidden_out, int dtype,
     if (L == 0) return FF_OK;
     return ff::launch_merge_compact(hidden, hidden_out, dtype, L, d, L_cap, order, member, fold, dst, keep, aux_host, n_aux,
                                     nullptr, nullptr,
-                                    (hipStream_t)stream, false);
+                                    (hipStream_t)stream, false, nullptr, 0, nullptr, 0);
 }
 
 extern "C" int ff_gather_mask(const void* mask, void* out, int64_t elem_bytes, int64_t L, int64_t L_cap,
@@ -363,28 +351,5 @@ extern "C" int ff_gather_mask(const void* mask, void* out, int64_t elem_bytes, i
     if (L == 0) return FF_OK;
     hipLaunchKernelGGL(ff::k_gather_mask, dim3((unsigned)L), dim3(256), 0, (hipStream_t)stream, (const char*)mask,
                        (char*)out, (int)elem_bytes, (int)L, L_cap, dst);
-    return (int)hipGetLastError();
-}
-
-extern "C" int ff_head_mean(const void* attn_w, int dtype, int64_t H, int64_t num, int64_t S, void* importance,
-                            ff_stream_t stream) {
-    if (!attn_w || !importance || H < 1 || num < 1 || S < 0) return FF_ERR_ARG;
-    if (S >= (1ll << 31) || H * num >= (1ll << 31)) return FF_ERR_UNSUPPORTED;
-    if (S == 0) return FF_OK;
-    const unsigned blocks = (unsigned)((S + 255) / 256);
-    hipStream_t st = (hipStream_t)stream;
-    switch (dtype) {
-        case FF_F32:
-            hipLaunchKernelGGL(ff::k_head_mean<FF_F32>, dim3(blocks), dim3(256), 0, st, attn_w, (int)(H * num), (int)S, importance);
-            break;
-        case FF_BF16:
-            hipLaunchKernelGGL(ff::k_head_mean<FF_BF16>, dim3(blocks), dim3(256), 0, st, attn_w, (int)(H * num), (int)S, importance);
-            break;
-        case FF_F16:
-            hipLaunchKernelGGL(ff::k_head_mean<FF_F16>, dim3(blocks), dim3(256), 0, st, attn_w, (int)(H * num), (int)S, importance);
-            break;
-        default:
-            return FF_ERR_ARG;
-    }
     return (int)hipGetLastError();
 }

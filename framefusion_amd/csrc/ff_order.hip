@@ -16,7 +16,7 @@
 
 namespace ff {
 
-size_t plan_ws_bytes(int64_t L);      // ff_plan.hip: the select tables occupy the front of the workspace
+size_t plan_ws_front_bytes(int64_t L);      // ff_plan.hip: the select tables occupy the front (and the tail) of the workspace
 
 constexpr int kOrderThreads = 1024;
 constexpr int kOrderWaves = kOrderThreads / kWave;
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(kOrderThreads) void k_build_order(
 extern "C" int ff_build_order(const int64_t* patch_type, int64_t L, int64_t patch_num, int32_t* order,
                               int64_t* stats, void* ws, size_t ws_bytes, ff_stream_t stream) {
     if (!patch_type || !order || !stats || !ws || L < 0 || patch_num < 1) return FF_ERR_ARG;
-    if (ws_bytes < ff::plan_ws_bytes(L) + ((size_t)(L / ff::kStatSpan) + 1) * sizeof(ff::OrderRow)) return FF_ERR_WORKSPACE;
+    if (ws_bytes < ff::plan_ws_front_bytes(L) + ((size_t)(L / ff::kStatSpan) + 1) * sizeof(ff::OrderRow)) return FF_ERR_WORKSPACE;
     if (((uintptr_t)patch_type & 15) || ((uintptr_t)order & 15) || ((uintptr_t)ws & 15)) return FF_ERR_ALIGN;
     if (L >= (1ll << 31) || patch_num > 32768) return FF_ERR_UNSUPPORTED;
     if (L == 0) return FF_OK;
@@ -349,7 +349,7 @@ extern "C" int ff_build_order(const int64_t* patch_type, int64_t L, int64_t patc
         attr_set = true;
     }
     // pass 1 (slice facts) + pass 2 (closed form on every workgroup, or the sort on workgroup 0)
-    ff::OrderRow* rows = (ff::OrderRow*)((char*)ws + ff::plan_ws_bytes(L));
+    ff::OrderRow* rows = (ff::OrderRow*)((char*)ws + ff::plan_ws_front_bytes(L));
     const int n_rows = (int)((L + ff::kStatSpan - 1) / ff::kStatSpan);
     hipLaunchKernelGGL(ff::k_order_stats, dim3(n_rows), dim3(ff::kStatThreads), 0, (hipStream_t)stream, patch_type,
                        (int)L, (int)patch_num, rows);

@@ -1,24 +1,28 @@
-// K2+K3 - the integer "plan" between the two streaming passes: threshold count, budget decision,
-// top-k (radix select with a lowest-index tie rule), member flags, keep mask and the compaction
-// scan.  Everything here works on <= L 2-byte similarities and L-sized index arrays (a few hundred
-// KB, L2-resident); the branch the reference takes on the host after two .item() syncs
+// K2+K3 - the integer "plan" between the two streaming passes, ONE launch: threshold count, budget
+// decision, top-k (radix select with a lowest-index tie rule), member flags, keep mask and the
+// compaction scan.  Everything here works on <= L 2-byte similarities and L-sized index arrays (a few
+// hundred KB, cache-resident); the branch the reference takes on the host after two .item() syncs
 // (framefusion/main.py:112-127) is decided on the device, in double, exactly as python does.
 //
 // Replaces: main.py:112-127 (select), find_contigious_latter_index (main.py:351-380), the
 // unique/where/repeat_interleave index algebra of merge_tokens_and_get_mask (main.py:269-301)
 // and the keep-mask construction (main.py:278-279) - 17 host syncs in the reference.
 //
-// Launches, split by what is inherently global (details at "multi-workgroup select" below):
-//   k_hist_level  per 4096-value slice: one byte of the radix select per launch (level 0 comes for
-//                 free from the similarity kernel in the fused path); nothing runs in the
-//                 threshold branch beyond re-deriving the decision;
-//   k_flags       per slice: member[t] for every by-patch slot and the scatter
-//                 keep[order[t]] = !member[t] - one CU would take a cycle per scattered byte,
-//                 many CUs do not notice it;
-//   k_scan        many workgroups, no communication: workgroup g recounts keep[0, 4096 g) itself
-//                 (<= L bytes, L2-resident) and scans its own 4096 positions into dst[]; the last
-//                 workgroup knows L_out and publishes the result block.
-// Run lengths are not materialised: the merge kernel derives them from 64 member flags at a time.
+// Why one launch is enough.  The select needs two global facts: the k-th largest key and how many
+// entries equal to it belong to the top k.  Both come out of small histograms that the PRODUCER of
+// the values (the similarity kernel, the importance kernels, or k_tables for the stand-alone entry
+// points) accumulates while it runs: the top byte of the order-preserving key (level 0, 16 copies)
+// and, per slice of 4096 values, the top 16 bits (level 1).  For 16-bit activation dtypes that is
+// the whole key.  Every workgroup of k_plan re-derives the same decision from those tables
+// (deterministic, no communication), locates the slot t* of the last tie member that is taken (the
+// per-slice tie counts give the slice, one 4096-value scan gives the slot), and from then on
+// "is slot t folded?" is a pure function of (value[t], t).  The compaction scan needs, for the
+// workgroup that owns positions [4096 g, 4096 g + 4096), the number of kept positions before it:
+// every workgroup walks ALL slots once (coalesced values + order[], 36 slots per thread at
+// 64 x 576), counts the kept ones whose position precedes its range and drops the keep flags of its
+// own range into LDS on the way - so there is no dependency between workgroups at all.
+// fp32 activations need two more radix levels (bits 15..0): k_hist_level, one launch each, before
+// k_plan.  Run lengths are not materialised: the merge kernel derives them from 64 member flags.
 #include <stdlib.h>
 #include <string.h>
 
@@ -26,7 +30,7 @@
 
 namespace ff {
 
-constexpr int kEpt = 16;                          // values per thread: two/four 16-byte loads
+constexpr int kEpt = 16;                          // values per thread in k_hist_level / k_tables
 
 // 16 consecutive T values starting at j0 (j0 % 16 == 0): the raw 16-byte words first (so the loads
 // can be issued before anything they do not depend on), then the order-preserving keys; entries at
@@ -80,45 +84,22 @@ __device__ inline void keys_of(const RawKeys<DT>& r, int j0, int n, uint32_t* ke
     valid_mask = left >= kEpt ? 0xffffu : (left <= 0 ? 0u : ((1u << left) - 1u));
 }
 
-template <int DT>
-__device__ inline void load_keys(const void* __restrict__ v, int j0, int n, uint32_t* key, uint32_t& valid_mask) {
-    const RawKeys<DT> r = load_raw<DT>(v, j0, n);
-    keys_of<DT>(r, j0, n, key, valid_mask);
-}
-
-// key of a T-valued float (the threshold): entries with key >= this and not NaN satisfy sim >= thr
-template <int DT>
-__device__ inline uint32_t key_of_value(float x) {
-    if constexpr (DT == FF_F32) return order_key<DT>(__float_as_uint(x));
-    else if constexpr (DT == FF_BF16) return order_key<DT>(__float_as_uint(x) >> 16);
-    else { _Float16 h = (_Float16)x; return order_key<DT>((uint32_t)__builtin_bit_cast(uint16_t, h)); }
-}
-
 template <int DT> __device__ inline uint32_t nan_key() { return Act<DT>::kKeyBits == 32 ? 0xffffffffu : 0xffffu; }
 
-// ---- multi-workgroup select ---------------------------------------------------------------------
-// The decision data is a handful of small histograms, so instead of one workgroup walking all
-// similarities several times, every workgroup of every stage re-derives the (deterministic)
-// decision from the partial histograms written by the previous stage:
-//   level 0 : top-byte histogram + count(sim >= thr), accumulated by the similarity kernel itself
-//             (64 copies, atomics spread over its whole run) or by k_hist_level(0);
-//   level l : k_hist_level(l) - slice g (4096 values) histograms byte l of the keys that match the
-//             l-byte prefix of the k-th key, one row per slice, no atomics across workgroups;
-//   k_flags : resolves the k-th key from all levels; the last level's per-slice rows also give the
-//             number of entries equal to it in earlier slices (lowest-index tie rule without a
-//             global scan); then member flags + the keep scatter for its slice.
-constexpr int kSliceThreads = 256;
-constexpr int kSlice = kSliceThreads * kEpt;      // 4096 values per workgroup
-constexpr int kRowStride = 260;                   // 256 bins + count + pad
-constexpr int kL0Copies = 16;
+// key of value t of the array (any t < cap)
+template <int DT>
+__device__ inline uint32_t key_at(const void* __restrict__ v, int t) { return order_key<DT>(Act<DT>::bits1(v, t)); }
+
+constexpr int kSliceThreads = 256;                // k_hist_level / k_tables: one slice per workgroup
+constexpr int kPlanThreads = 1024;                // k_plan: one slice per workgroup, 4 values per thread
 
 struct PlanParams {
     int mode;            // 0: merge (threshold / top-k decided from the count), 1: prune (top-k given)
-    int lo, hi;          // value range the selection runs over (merge: hi < 0 -> [0, Nv))
+    int lo, hi;          // value range the selection runs over (merge: [0, Nv))
     long long k_given;   // prune: k; merge: >= 0 forces top-k with this k, -1 = threshold/budget policy
     double sub, ratio_lb;
     uint32_t thr_key;
-    int l0_rows;         // rows of the level-0 table (64 copies or G slices)
+    int p0_guess;        // expected top byte of the k-th key (speculative prefetch of its level-1 rows)
     int n_slices;
 };
 
@@ -126,19 +107,21 @@ struct Resolved {
     bool topk;
     long long k;
     int count;
-    uint32_t prefix;     // leading `levels_done` bytes of the k-th key
+    uint32_t prefix;     // leading `levels` bytes of the k-th key
     int remaining;       // entries still to take inside the prefix
 };
 
-struct SliceLds {
-    int hist[kSliceThreads / kWave][2][256];
+template <int NT>
+struct SelLds {
     int tot[256];
-    int scratch[kSliceThreads / kWave + 1];
-    int bcast[4];
+    int part[NT / 256][256];
+    int scratch[NT / kWave + 1];
+    int bcast[8];
 };
 
 // pick the bin, from the top, in which the running count reaches `remaining` (s.tot filled)
-__device__ inline int pick_from_tot(SliceLds& s, int remaining, int& above) {
+template <int NT>
+__device__ inline int pick_from_tot(SelLds<NT>& s, int remaining, int& above) {
     const int lane = lane_id();
     __syncthreads();
     if (wave_id() == 0) {
@@ -165,52 +148,29 @@ __device__ inline int pick_from_tot(SliceLds& s, int remaining, int& above) {
     return bin;
 }
 
-// Column `tid` of the level-0 table summed over its rows, plus this thread's share of the count
-// column.  Straight-line loads (all 64 in flight) for the table the similarity kernel fills.
-__device__ inline void sum_l0(const PlanParams& pp, const int* __restrict__ l0, int& col, int& cnt_part) {
-    const int tid = threadIdx.x;
-    int t0 = 0;
-    if (pp.l0_rows == kL0Copies) {
-        int v[kL0Copies];
-#pragma unroll
-        for (int q = 0; q < kL0Copies; ++q) v[q] = l0[q * kRowStride + tid];
-#pragma unroll
-        for (int q = 0; q < kL0Copies; ++q) t0 += v[q];
-    } else {
-#pragma unroll 16
-        for (int q = 0; q < pp.l0_rows; ++q) t0 += l0[q * kRowStride + tid];
-    }
-    int c = 0;
-    for (int q = tid; q < pp.l0_rows; q += kSliceThreads) c += l0[q * kRowStride + 256];
-    col = t0;
-    cnt_part = c;
-}
-
-// Column `tid` of every row of level table `l` (1-based) into regs[0..n_slices) is not possible with
-// a runtime count, so levels are summed on the fly; `before` = the rows of slices < my_slice only.
-__device__ inline void sum_level(const int* __restrict__ tab, int n_slices, int my_slice, int& all, int& before) {
-    const int tid = threadIdx.x;
-    int a = 0, b = 0;
-#pragma unroll 16
-    for (int g = 0; g < n_slices; ++g) {
-        const int x = tab[g * 256 + tid];
-        a += x;
-        b += g < my_slice ? x : 0;
-    }
-    all = a;
-    before = b;
-}
-
-// Re-derive the decision and the first `levels` bytes of the k-th key from the partial tables.
-// l0col / l0cnt: this thread's sums from sum_l0; lvcol[l-1]: column sums of level l (sum_level).
-__device__ inline Resolved resolve(const PlanParams& pp, int l0col, int l0cnt, const int* lvcol, int levels,
-                                   long long ftn, int nv, SliceLds& s) {
-    const int tid = threadIdx.x;
+// Re-derive the decision and the first `levels` bytes of the k-th key from the tables:
+// level 0 = l0 (kL0Copies copies), level 1 = the T16 rows of the level-0 bin, levels 2.. = the
+// per-slice rows k_hist_level wrote into lv (fp32 only).  All NT threads call.
+template <int NT>
+__device__ inline Resolved resolve(const PlanParams& pp, const int* __restrict__ l0, int* t16_end,
+                                   const int* __restrict__ lv, int levels, long long ftn, int nv, SelLds<NT>& s) {
+    constexpr int NQ = NT / 256;
+    const int tid = threadIdx.x, c = tid & 255, q = tid >> 8;
     Resolved r;
     r.prefix = 0; r.remaining = 0; r.count = 0;
-    s.tot[tid] = l0col;
-    const int c = block_sum_i<kSliceThreads / kWave>(l0cnt, s.scratch);
-    r.count = c;
+    // level-0 column sums: copy q, q + NQ, ... of column c; the count column rides along
+    int t0 = 0, cnt = 0;
+#pragma unroll
+    for (int x = 0; x < kL0Copies / NQ; ++x) t0 += l0[(q + x * NQ) * kL0Stride + c];
+    if (tid < kL0Copies) cnt = l0[tid * kL0Stride + 256];
+    s.part[q][c] = t0;
+    r.count = block_sum_i<NT / kWave>(cnt, s.scratch);                 // (two barriers inside)
+    if (tid < 256) {
+        int a = 0;
+#pragma unroll
+        for (int x = 0; x < NQ; ++x) a += s.part[x][tid];
+        s.tot[tid] = a;
+    }
     if (pp.mode == 0 && pp.k_given >= 0) {
         // fixed-sparsity policy: the caller fixed k (modeling_qwen2_baseline.py:920,1001)
         r.topk = true;
@@ -230,212 +190,542 @@ __device__ inline Resolved resolve(const PlanParams& pp, int l0col, int l0cnt, c
         r.topk = true;
         r.k = pp.k_given;
     }
-    if (!r.topk || r.k <= 0 || levels <= 0) return r;
+    if (!r.topk || r.k <= 0 || levels <= 0) return r;       // uniform over the whole grid
     r.remaining = (int)r.k;
-    for (int l = 0; l < levels; ++l) {
-        if (l > 0) {
-            __syncthreads();
-            s.tot[tid] = lvcol[l - 1];
+    int above;
+    int bin = pick_from_tot(s, r.remaining, above);
+    r.prefix = (uint32_t)bin;
+    r.remaining -= above;
+    if (levels == 1) return r;
+    {   // level 1: column c of the T16 rows of bin, summed over slices q, q + NQ, ... and the copies
+        int a = 0;
+        for (int g = q; g < pp.n_slices; g += NQ) {
+            const int* row = t16_slice(t16_end, g) + t16_bin((r.prefix << 8) | (uint32_t)c);
+#pragma unroll
+            for (int x = 0; x < kT16Copies; ++x) a += row[x * 65536];
         }
-        int above;
-        const int bin = pick_from_tot(s, r.remaining, above);
+        s.part[q][c] = a;
+        __syncthreads();
+        if (tid < 256) {
+            int b = 0;
+#pragma unroll
+            for (int x = 0; x < NQ; ++x) b += s.part[x][tid];
+            s.tot[tid] = b;
+        }
+        bin = pick_from_tot(s, r.remaining, above);
+        r.prefix = (r.prefix << 8) | (uint32_t)bin;
+        r.remaining -= above;
+    }
+    for (int l = 2; l < levels; ++l) {
+        const int* tab = lv + (size_t)(l - 2) * pp.n_slices * 256;
+        int a = 0;
+        for (int g = q; g < pp.n_slices; g += NQ) a += tab[g * 256 + c];
+        s.part[q][c] = a;
+        __syncthreads();
+        if (tid < 256) {
+            int b = 0;
+#pragma unroll
+            for (int x = 0; x < NQ; ++x) b += s.part[x][tid];
+            s.tot[tid] = b;
+        }
+        bin = pick_from_tot(s, r.remaining, above);
         r.prefix = (r.prefix << 8) | (uint32_t)bin;
         r.remaining -= above;
     }
     return r;
 }
 
-__device__ inline void slice_range(const PlanParams& pp, int nv, int& lo, int& hi) {
-    lo = pp.mode == 0 ? 0 : pp.lo;
-    hi = pp.mode == 0 ? nv : pp.hi;
+// ---- k_tables: the level-0 / level-1 tables of an existing value array ----------------------------
+// (stand-alone plan entry points and importances handed over by the caller; the fused merge step
+// gets the same tables from the similarity kernel's epilogue).  Tables must be zero on entry.
+template <int DT>
+__global__ __launch_bounds__(kSliceThreads) void k_tables(const void* __restrict__ values, int cap, int lo, int hi,
+                                                          const int64_t* __restrict__ stats, uint32_t thr_key,
+                                                          int* __restrict__ l0, int* t16_end) {
+    using A = Act<DT>;
+    const int tid = threadIdx.x;
+    const int j0 = blockIdx.x * kSelSlice + tid * kEpt;
+    const RawKeys<DT> raw = load_raw<DT>(values, j0, cap);
+    if (hi < 0) hi = (int)stats[FF_STAT_NV];
+    uint32_t key[kEpt], valid;
+    keys_of<DT>(raw, j0, hi, key, valid);
+    int* tab = l0 + (blockIdx.x & (kL0Copies - 1)) * kL0Stride;
+    int* t16 = t16_slice(t16_end, blockIdx.x) + (tid & (kT16Copies - 1)) * 65536;
+    int n_ge = 0;
+#pragma unroll
+    for (int e = 0; e < kEpt; ++e) {
+        const bool in = ((valid >> e) & 1u) && (j0 + e >= lo);
+        n_ge += (in && key[e] >= thr_key && key[e] != nan_key<DT>()) ? 1 : 0;
+        wave_agg_add<3>(tab, key[e] >> (A::kKeyBits - 8), in);
+        // neighbouring lanes use different copies, so the fold is per copy
+        if (in) atomicAdd(&t16[t16_bin(key[e] >> (A::kKeyBits - 16))], 1);
+    }
+    n_ge = wave_sum_i(n_ge);
+    if (lane_id() == 0 && n_ge) atomicAdd(&tab[256], n_ge);
 }
 
-// level `level` histogram of slice blockIdx.x (level 0 also counts values >= thr)
+// ---- k_hist_level: radix levels 2 and 3 of fp32 keys ----------------------------------------------
+// Slice g histograms byte `level` of the keys that match the (level)-byte prefix of the k-th key,
+// one row per slice in lv[level - 2], no atomics across workgroups.
+struct HistLds {
+    SelLds<kSliceThreads> sel;
+    int hist[kSliceThreads / kWave][2][256];
+};
+
 template <int DT>
-__device__ inline void hist_level_body(const void* values, int cap, const PlanParams& pp, int level,
-                                       const int64_t* stats, const int* l0, int* lv, int* l0_out, SliceLds& s) {
+__global__ __launch_bounds__(kSliceThreads) void k_hist_level(
+    const void* __restrict__ values, int cap, PlanParams pp, int level, const int64_t* __restrict__ stats,
+    const int* __restrict__ l0, int* t16_end, int* __restrict__ lv) {
     using A = Act<DT>;
+    __shared__ HistLds s;
     const int tid = threadIdx.x, w = wave_id(), cp = lane_id() & 1;
-    // every load this workgroup needs is independent of the others: issue them all first
-    const int j0 = blockIdx.x * kSlice + tid * kEpt;
+    const int j0 = blockIdx.x * kSelSlice + tid * kEpt;
     const RawKeys<DT> raw = load_raw<DT>(values, j0, cap);
     const int nv = (int)stats[FF_STAT_NV];
     const long long ftn = stats[FF_STAT_FTN];
-    int l0col = 0, l0cnt = 0, lvcol[3] = {0, 0, 0}, dummy;
-    if (level > 0) {
-        sum_l0(pp, l0, l0col, l0cnt);
-        for (int l = 1; l < level; ++l) sum_level(lv + (size_t)(l - 1) * pp.n_slices * 256, pp.n_slices, 0, lvcol[l - 1], dummy);
-    }
-    int lo, hi;
-    slice_range(pp, nv, lo, hi);
-    uint32_t prefix = 0;
-    if (level > 0) {
-        const Resolved r = resolve(pp, l0col, l0cnt, lvcol, level, ftn, nv, s);
-        if (!r.topk || r.k <= 0) return;          // uniform over the whole grid
-        prefix = r.prefix;
-        __syncthreads();
-    }
+    const int lo = pp.mode == 0 ? 0 : pp.lo, hi = pp.mode == 0 ? nv : pp.hi;
+    const Resolved r = resolve<kSliceThreads>(pp, l0, t16_end, lv, level, ftn, nv, s.sel);
+    if (!r.topk || r.k <= 0) return;          // uniform over the whole grid
+    __syncthreads();
     for (int x = tid; x < (kSliceThreads / kWave) * 2 * 256; x += kSliceThreads) (&s.hist[0][0][0])[x] = 0;
     __syncthreads();
     uint32_t key[kEpt], valid;
     keys_of<DT>(raw, j0, hi, key, valid);
     const int shift = A::kKeyBits - 8 * (level + 1);
-    int c = 0;
 #pragma unroll
     for (int e = 0; e < kEpt; ++e) {
         const bool in = ((valid >> e) & 1u) && (j0 + e >= lo);
-        if (!in) continue;
-        if (level == 0) {
-            c += (key[e] >= pp.thr_key && key[e] != nan_key<DT>()) ? 1 : 0;
-            atomicAdd(&s.hist[w][cp][key[e] >> shift], 1);
-        } else if ((key[e] >> (shift + 8)) == prefix) {
-            atomicAdd(&s.hist[w][cp][(key[e] >> shift) & 255u], 1);
-        }
+        if (in && (key[e] >> (shift + 8)) == r.prefix) atomicAdd(&s.hist[w][cp][(key[e] >> shift) & 255u], 1);
     }
-    if (level == 0) c = block_sum_i<kSliceThreads / kWave>(c, s.scratch);
     __syncthreads();
     int t = 0;
 #pragma unroll
-    for (int q = 0; q < kSliceThreads / kWave; ++q) t += s.hist[q][0][tid] + s.hist[q][1][tid];
-    if (level == 0) {
-        l0_out[blockIdx.x * kRowStride + tid] = t;
-        if (tid == 0) l0_out[blockIdx.x * kRowStride + 256] = c;
+    for (int qq = 0; qq < kSliceThreads / kWave; ++qq) t += s.hist[qq][0][tid] + s.hist[qq][1][tid];
+    lv[((size_t)(level - 2) * pp.n_slices + blockIdx.x) * 256 + tid] = t;
+}
+
+// Copy of the result block into device-visible pinned host memory: one lane per word (a single
+// store instruction crosses PCIe once), a system fence, then the sequence word the host polls.
+__device__ inline void publish(int64_t* __restrict__ stats, int64_t* host_mapped, int64_t seq) {
+    const int lane = threadIdx.x;          // called by wave 0
+    if (lane < FF_STAT_WORDS && lane != FF_STAT_SEQ)
+        __hip_atomic_store(&host_mapped[lane], stats[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (lane == FF_STAT_ERROR) stats[lane] = 0;     // reported; the next call starts clean
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    if (lane == 0) __hip_atomic_store(&host_mapped[FF_STAT_SEQ], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// ---- k_plan ---------------------------------------------------------------------------------------
+// Workgroup g owns by-patch slots AND sequence positions [4096 g, 4096 g + 4096).
+// mode 0 (merge): slot t of `order` (visual slots [0, nv), then the non-visual tail) is folded iff it is
+//   selected and t > 0 (slot 0 has no predecessor: the reference would wrap to order[-1],
+//   main.py:290; reachable only when top-k exceeds the number of valid pairs);
+// mode 1 (prune): order = identity, position i in [lo, hi) is DROPPED iff it is not selected.
+//
+// Latency structure: the kernel is a chain of dependent steps on a cold chip (its predecessor streamed
+// hundreds of MB), so every load that does not depend on the decision is issued in the FIRST round:
+// the values and order[] of up to kRegChunks x 8192 slots (8 consecutive slots per thread per chunk,
+// kept in registers), the level-0 tables, and - speculatively - the level-1 rows of the top byte the
+// k-th key is expected to have (pp.p0_guess: the threshold's; a wrong guess costs one more round
+// trip).  Wave 0 then resolves the levels from LDS, the tie slot t* comes out of the registers, and
+// the single pass over the slots classifies what the registers already hold.
+constexpr int kRegChunks = 5;               // 40 960 slots in registers; longer sequences load the rest on the fly
+constexpr int kChunkStride = kPlanThreads * 8;
+constexpr int kRowSlicesLds = 16;           // level-1 rows kept in LDS for the tie-slice search (else re-read)
+
+struct PlanLds {
+    SelLds<kPlanThreads> sel;
+    int rows[kRowSlicesLds][256];
+    uint32_t keep[kSelSlice / 4];          // keep flags of my positions, one byte each
+};
+
+template <int DT>
+__device__ inline void chunk_keys(const uint4* kw, uint32_t* key) {
+    if constexpr (Act<DT>::kBytes == 2) {
+        const uint32_t w[4] = {kw[0].x, kw[0].y, kw[0].z, kw[0].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            key[2 * e] = order_key<DT>(w[e] & 0xffffu);
+            key[2 * e + 1] = order_key<DT>(w[e] >> 16);
+        }
     } else {
-        lv[((size_t)(level - 1) * pp.n_slices + blockIdx.x) * 256 + tid] = t;
+        key[0] = order_key<DT>(kw[0].x); key[1] = order_key<DT>(kw[0].y); key[2] = order_key<DT>(kw[0].z); key[3] = order_key<DT>(kw[0].w);
+        key[4] = order_key<DT>(kw[1].x); key[5] = order_key<DT>(kw[1].y); key[6] = order_key<DT>(kw[1].z); key[7] = order_key<DT>(kw[1].w);
     }
 }
 
+// positions and raw values of the 8 slots [t0, t0 + 8): raw buffer loads (range-checked per dword:
+// whatever lies beyond the arrays reads 0), so the loads of all chunks are straight-line code and
+// go out back to back; slots >= L are masked where they are used
 template <int DT>
-__global__ __launch_bounds__(kSliceThreads) void k_hist_level(
-    const void* __restrict__ values, int cap, PlanParams pp, int level, const int64_t* __restrict__ stats,
-    const int* __restrict__ l0, int* __restrict__ lv, int* __restrict__ l0_out) {
-    __shared__ SliceLds s;
-    hist_level_body<DT>(values, cap, pp, level, stats, l0, lv, l0_out, s);
+__device__ inline void load_chunk(__amdgpu_buffer_rsrc_t values, __amdgpu_buffer_rsrc_t order, bool has_order, int t0,
+                                  uint4* po, uint4* kw) {
+    constexpr int KW = Act<DT>::kBytes == 2 ? 1 : 2;
+    // (no order: the resource is empty and the loads return 0; the identity is substituted where the
+    // positions are USED - a select here would make the compiler wait for the loads at this point)
+    (void)has_order;
+    po[0] = buf_load16(order, (uint32_t)t0 * 4u);
+    po[1] = buf_load16(order, (uint32_t)t0 * 4u + 16u);
+#pragma unroll
+    for (int x = 0; x < KW; ++x) kw[x] = buf_load16(values, (uint32_t)t0 * (uint32_t)Act<DT>::kBytes + 16u * x);
 }
 
-// ---- k_flags ----------------------------------------------------------------------------------------
-// Slice g of the by-patch slots (then the non-visual tail of `order`).  Slot 0 never folds: it has
-// no predecessor (the reference would wrap to order[-1], main.py:290; reachable only when top-k
-// exceeds the number of valid pairs).
 template <int DT>
-__device__ inline void flags_body(const void* values, int cap, const PlanParams& pp, const int* l0, const int* lv,
-                                  int64_t* stats, const int32_t* order, int L, uint8_t* member, uint8_t* keep,
-                                  SliceLds& s) {
+__global__ __launch_bounds__(kPlanThreads) void k_plan(
+    const void* __restrict__ values, int cap, PlanParams pp, const int* __restrict__ l0, int* t16_end,
+    const int* __restrict__ lv, int64_t* __restrict__ stats, const int32_t* __restrict__ order, int L,
+    uint8_t* __restrict__ member, uint8_t* __restrict__ keep, int32_t* __restrict__ dst,
+    int64_t* host_mapped, int64_t seq) {
     using A = Act<DT>;
     constexpr int kLevels = A::kKeyBits / 8;
-    const int tid = threadIdx.x;
-    // every load is independent of the others: values, row indices, counts and all tables first
-    const int j0 = blockIdx.x * kSlice + tid * kEpt;
-    const RawKeys<DT> raw = load_raw<DT>(values, j0, cap);
-    int ord[kEpt];
-    const int n_here = min(max(L - j0, 0), kEpt);
-    if (order) {
-        if (n_here == kEpt) {
-            const uint4* po = (const uint4*)(order + j0);
+    constexpr int KW = A::kBytes == 2 ? 1 : 2;
+    constexpr int NW = kPlanThreads / kWave;
+    constexpr int NQ = kPlanThreads / 256;
+    constexpr int kSpec = 3;                      // speculative level-1 slices per thread (12 slices = 49 152 values)
+    __shared__ PlanLds s;
+    const int tid = threadIdx.x, lane = lane_id(), c = tid & 255, q = tid >> 8;
+    const int base = blockIdx.x * kSelSlice;
+    const bool fast = kLevels == 2 && pp.n_slices <= kRowSlicesLds;
+    // phase stamps of the last workgroup (100 MHz steady counter), published in stats[FF_STAT_T_PLAN ..]
+    long long stamp[6];
+    stamp[0] = wall_clock64();
+
+    // ---- round 1: everything that does not depend on the decision; the small tables first (loads
+    // return in order: the first barrier then only waits for them, not for the slot chunks)
+    const long long nv_raw = stats[FF_STAT_NV];
+    const long long ftn = stats[FF_STAT_FTN];
+    // (raw values only: any arithmetic on them here would make the compiler wait before the chunk
+    // loads below are even issued)
+    int l0v[kL0Copies / NQ], specv[kSpec][kT16Copies];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint4 o4 = po[q];
-                ord[4 * q] = o4.x; ord[4 * q + 1] = o4.y; ord[4 * q + 2] = o4.z; ord[4 * q + 3] = o4.w;
+    for (int x = 0; x < kL0Copies / NQ; ++x) l0v[x] = l0[(q + x * NQ) * kL0Stride + c];
+    const int l0cnt_raw = l0[(tid & (kL0Copies - 1)) * kL0Stride + 256];
+    if (fast) {
+#pragma unroll
+        for (int j = 0; j < kSpec; ++j) {
+            const int g = min(q + j * NQ, pp.n_slices - 1);          // (clamped: the value is only used for g < n_slices)
+            const int* row = t16_slice(t16_end, g) + t16_bin(((uint32_t)pp.p0_guess << 8) | (uint32_t)c);
+#pragma unroll
+            for (int x = 0; x < kT16Copies; ++x) specv[j][x] = row[x * 65536];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);            // the table loads stay AHEAD of the chunk loads in issue order
+    const __amdgpu_buffer_rsrc_t val_rsrc = make_rsrc(values, (uint32_t)cap * (uint32_t)A::kBytes);
+    const __amdgpu_buffer_rsrc_t ord_rsrc = make_rsrc(order ? (const void*)order : values, order ? (uint32_t)L * 4u : 0u);
+    const bool has_order = order != nullptr;
+    uint4 po[kRegChunks][2], kw[kRegChunks][KW];
+#pragma unroll
+    for (int x = 0; x < kRegChunks; ++x) load_chunk<DT>(val_rsrc, ord_rsrc, has_order, tid * 8 + x * kChunkStride, po[x], kw[x]);
+    __builtin_amdgcn_sched_barrier(0);
+    const long long stamp_issued = wall_clock64();          // all round-1 loads issued, none awaited
+    __builtin_amdgcn_sched_barrier(0);
+    const int nv = pp.mode == 0 ? (int)nv_raw : L;
+    const int lo = pp.mode == 0 ? 0 : pp.lo, hi = pp.mode == 0 ? nv : pp.hi;
+    for (int x = tid; x < kSelSlice / 4; x += kPlanThreads) s.keep[x] = 0;
+    int l0part = 0;
+#pragma unroll
+    for (int x = 0; x < kL0Copies / NQ; ++x) l0part += l0v[x];
+    const int l0cnt = tid < kL0Copies ? l0cnt_raw : 0;
+    int spec[kSpec] = {0, 0, 0};
+    if (fast) {
+#pragma unroll
+        for (int j = 0; j < kSpec; ++j)
+#pragma unroll
+            for (int x = 0; x < kT16Copies; ++x) spec[j] += specv[j][x];
+    }
+
+    // ---- decision + k-th key -------------------------------------------------------------------------
+    Resolved r;
+    int sl = 0, want = 0;                         // the want-th (1-based) entry equal to kth inside slice sl is the last one taken
+    stamp[1] = stamp[0];
+    if (fast) {
+        // bcast: [0] topk, [1] count, [2] k (clamped, fits an int), [3] p0, [4] remaining after level 0
+        s.sel.part[q][c] = l0part;
+        if (tid < kL0Copies) s.sel.scratch[tid] = l0cnt;
+        __syncthreads();
+        stamp[1] = wall_clock64();
+        if (tid < kWave) {
+            int cnt = lane < kL0Copies ? s.sel.scratch[lane] : 0;
+            cnt = wave_sum_i(cnt);
+            bool topk;
+            long long k;
+            if (pp.mode == 0 && pp.k_given >= 0) {
+                topk = true;                                  // fixed-sparsity policy (modeling_qwen2_baseline.py:920,1001)
+                k = pp.k_given > nv ? (long long)nv : pp.k_given;
+            } else if (pp.mode == 0) {
+                // main.py:114-116 in double, as python: ratio = count / ftn ; ratio < sub ?
+                const double ratio = ftn > 0 ? (double)cnt / (double)ftn : 0.0;
+                topk = !(ratio < pp.sub);
+                k = 0;
+                if (topk) {
+                    k = (long long)(pp.sub * (double)ftn);   // int(sub * ftn), main.py:122
+                    if (k > nv) k = nv;
+                    if (k < 0) k = 0;
+                }
+            } else {
+                topk = true;
+                k = pp.k_given;
             }
-        } else {
+            int p0 = 0, rem = (int)k;
+            if (topk && k > 0) {
+                const int top = 255 - 4 * lane;
+                int v[4];
 #pragma unroll
-            for (int e = 0; e < kEpt; ++e) ord[e] = e < n_here ? order[j0 + e] : 0;
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = 0;
+#pragma unroll
+                    for (int x = 0; x < NQ; ++x) v[e] += s.sel.part[x][top - e];
+                }
+                const int sum = v[0] + v[1] + v[2] + v[3];
+                const int incl = wave_incl_scan(sum);
+                const int first = __ffsll((long long)__ballot(incl >= rem)) - 1;
+                int ab = incl - sum, bin = top;
+                if (ab + v[0] >= rem) { bin = top; }
+                else if (ab + v[0] + v[1] >= rem) { ab += v[0]; bin = top - 1; }
+                else if (ab + v[0] + v[1] + v[2] >= rem) { ab += v[0] + v[1]; bin = top - 2; }
+                else { ab += v[0] + v[1] + v[2]; bin = top - 3; }
+                p0 = __builtin_amdgcn_readlane(bin, first);
+                rem -= __builtin_amdgcn_readlane(ab, first);
+            }
+            if (lane == 0) {
+                s.sel.bcast[0] = topk ? 1 : 0; s.sel.bcast[1] = cnt; s.sel.bcast[2] = (int)k; s.sel.bcast[3] = p0; s.sel.bcast[4] = rem;
+            }
+        }
+        __syncthreads();
+        r.topk = s.sel.bcast[0] != 0; r.count = s.sel.bcast[1]; r.k = s.sel.bcast[2];
+        const int p0 = s.sel.bcast[3];
+        r.prefix = 0; r.remaining = 0;
+        if (r.topk && r.k > 0) {
+            // level-1 rows of p0: the speculated ones if the guess was right
+            int a = 0;
+            for (int g = q, j = 0; g < pp.n_slices; g += NQ, ++j) {
+                int v = 0;
+                if (j < kSpec && p0 == pp.p0_guess) {
+                    v = j == 0 ? spec[0] : (j == 1 ? spec[1] : spec[2]);
+                } else {
+                    const int* row = t16_slice(t16_end, g) + t16_bin(((uint32_t)p0 << 8) | (uint32_t)c);
+#pragma unroll
+                    for (int x = 0; x < kT16Copies; ++x) v += row[x * 65536];
+                }
+                s.rows[g][c] = v;
+                a += v;
+            }
+            s.sel.part[q][c] = a;
+            __syncthreads();
+            if (tid < kWave) {
+                int rem = s.sel.bcast[4];
+                const int top = 255 - 4 * lane;
+                int v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = 0;
+#pragma unroll
+                    for (int x = 0; x < NQ; ++x) v[e] += s.sel.part[x][top - e];
+                }
+                const int sum = v[0] + v[1] + v[2] + v[3];
+                const int incl = wave_incl_scan(sum);
+                const int first = __ffsll((long long)__ballot(incl >= rem)) - 1;
+                int ab = incl - sum, bin = top;
+                if (ab + v[0] >= rem) { bin = top; }
+                else if (ab + v[0] + v[1] >= rem) { ab += v[0]; bin = top - 1; }
+                else if (ab + v[0] + v[1] + v[2] >= rem) { ab += v[0] + v[1]; bin = top - 2; }
+                else { ab += v[0] + v[1] + v[2]; bin = top - 3; }
+                const int p1 = __builtin_amdgcn_readlane(bin, first);
+                rem -= __builtin_amdgcn_readlane(ab, first);
+                // the slice that holds the rem-th entry equal to the k-th key (entries per slice = rows[g][p1])
+                const int ties = lane < pp.n_slices ? s.rows[lane][p1] : 0;
+                const int tincl = wave_incl_scan(ties);
+                const int hit = __ffsll((long long)__ballot(tincl >= rem)) - 1;
+                const int before_hit = __builtin_amdgcn_readlane(tincl - ties, hit);
+                if (lane == 0) {
+                    s.sel.bcast[5] = (p0 << 8) | p1; s.sel.bcast[6] = rem; s.sel.bcast[7] = hit;
+                    s.sel.bcast[4] = rem - before_hit;
+                }
+            }
+            __syncthreads();
+            r.prefix = (uint32_t)s.sel.bcast[5];
+            r.remaining = s.sel.bcast[6];
+            sl = s.sel.bcast[7];
+            want = s.sel.bcast[4];
         }
     } else {
+        r = resolve<kPlanThreads>(pp, l0, t16_end, lv, kLevels, ftn, nv, s.sel);
+        if (r.topk && r.k > 0) {
+            // entries equal to kth per slice: the last level's rows count exactly those
+            const int per = (pp.n_slices + kPlanThreads - 1) / kPlanThreads;
+            const int g0 = tid * per, g1 = min(g0 + per, pp.n_slices);
+            auto ties_of = [&](int g) {
+                int cnt = 0;
+                if constexpr (kLevels == 2) {
+                    const int* row = t16_slice(t16_end, g) + t16_bin(r.prefix);
 #pragma unroll
-        for (int e = 0; e < kEpt; ++e) ord[e] = j0 + e;
+                    for (int x = 0; x < kT16Copies; ++x) cnt += row[x * 65536];
+                } else {
+                    cnt = lv[((size_t)(kLevels - 3) * pp.n_slices + g) * 256 + (r.prefix & 255u)];
+                }
+                return cnt;
+            };
+            int mine = 0;
+            for (int g = g0; g < g1; ++g) mine += ties_of(g);
+            int total;
+            const int before_me = block_excl_scan<NW>(mine, s.sel.scratch, total);
+            if (before_me < r.remaining && r.remaining <= before_me + mine) {      // exactly one thread
+                int acc = before_me;
+                for (int g = g0; g < g1; ++g) {
+                    const int cnt = ties_of(g);
+                    if (r.remaining <= acc + cnt) { s.sel.bcast[7] = g; s.sel.bcast[4] = r.remaining - acc; break; }
+                    acc += cnt;
+                }
+            }
+            __syncthreads();
+            sl = s.sel.bcast[7];
+            want = s.sel.bcast[4];
+        }
     }
-    const int nv = (int)stats[FF_STAT_NV];
-    const long long ftn = stats[FF_STAT_FTN];
-    int l0col, l0cnt, lvcol[3] = {0, 0, 0}, lvbefore[3] = {0, 0, 0};
-    sum_l0(pp, l0, l0col, l0cnt);
-#pragma unroll
-    for (int l = 1; l < kLevels; ++l)
-        sum_level(lv + (size_t)(l - 1) * pp.n_slices * 256, pp.n_slices, (int)blockIdx.x, lvcol[l - 1], lvbefore[l - 1]);
-    int lo, hi;
-    slice_range(pp, nv, lo, hi);
-    const Resolved r = resolve(pp, l0col, l0cnt, lvcol, kLevels, ftn, nv, s);
-    const bool select_topk = r.topk;
+    const bool topk = r.topk && r.k > 0;
     const uint32_t kth = r.prefix;
-    const int need = r.remaining;                 // entries equal to kth that belong to the top k
-    // entries equal to kth in earlier slices: the last level's rows count exactly those, and the
-    // thread that owns column (kth & 255) already holds their sum
-    __syncthreads();
-    if (tid == (int)(kth & 255u)) s.bcast[3] = lvbefore[kLevels - 2];
-    __syncthreads();
-    const int ties_before = (select_topk && r.k > 0) ? s.bcast[3] : 0;
-    const int n_flag = pp.mode == 0 ? nv : L;
-    uint32_t key[kEpt], valid;
-    keys_of<DT>(raw, j0, n_flag, key, valid);
-    int mine = 0;
-    if (select_topk && r.k > 0) {
+    const int need = r.remaining;                 // entries equal to kth that belong to the top k (>= 1)
+    stamp[2] = wall_clock64();
+
+    // ---- t*: the slot of the want-th entry equal to kth inside slice sl (lowest-index tie rule) ----------
+    int tstar = -1;
+    if (topk) {
+        const int cstar = sl >> 1;                // the chunk index that covers slice sl (chunk stride = 2 slices)
+        const int t0 = tid * 8 + cstar * kChunkStride;
+        const bool mine_in = t0 >= sl * kSelSlice && t0 < (sl + 1) * kSelSlice;
+        uint32_t key[8];
+        bool have = false;
 #pragma unroll
-        for (int e = 0; e < kEpt; ++e)
-            mine += (((valid >> e) & 1u) && j0 + e >= lo && j0 + e < hi && key[e] == kth) ? 1 : 0;
-    }
-    int slice_ties;
-    int rank = ties_before + block_excl_scan<kSliceThreads / kWave>(mine, s.scratch, slice_ties);
-    uint32_t mem = 0;
+        for (int x = 0; x < kRegChunks; ++x)
+            if (x == cstar) { chunk_keys<DT>(kw[x], key); have = true; }
+        if (!have) {
+            uint4 pq[2], kq[KW];
+            load_chunk<DT>(val_rsrc, ord_rsrc, false, t0, pq, kq);
+            chunk_keys<DT>(kq, key);
+        }
+        unsigned tie = 0;
+        if (mine_in) {
 #pragma unroll
-    for (int e = 0; e < kEpt; ++e) {
-        const int j = j0 + e;
-        if (!((valid >> e) & 1u)) continue;
-        const bool in = j >= lo && j < hi;
-        bool sel;
-        if (select_topk) {
-            sel = false;
-            if (in && r.k > 0) {
-                if (key[e] > kth) sel = true;
-                else if (key[e] == kth) { sel = rank < need; ++rank; }
+            for (int e = 0; e < 8; ++e) {
+                const int t = t0 + e;
+                if (t >= lo && t < hi && key[e] == kth) tie |= 1u << e;
             }
-        } else {
-            sel = key[e] >= pp.thr_key && key[e] != nan_key<DT>();
         }
-        const bool m = pp.mode == 0 ? (sel && j > 0) : (in && !sel);
-        if (m) mem |= 1u << e;
+        int slice_total;
+        const int ex = block_excl_scan<NW>(__popc(tie), s.sel.scratch, slice_total);
+        if (ex < want && want <= ex + __popc(tie)) {
+            int seen = ex;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if ((tie >> e) & 1u) { if (++seen == want) s.sel.bcast[0] = t0 + e; }
+        }
+        __syncthreads();
+        tstar = s.sel.bcast[0];
     }
-    if (j0 < L) {
-        if (n_here == kEpt && (((uintptr_t)(member + j0)) & 15) == 0) {
-            uint32_t mb[4];
+
+    stamp[3] = wall_clock64();
+    // ---- one pass over all slots: kept positions before my range, keep flags of my range, member
+    // flags of my slots
+    int before = 0;
+    auto classify = [&](int t0, const uint4* pq, const uint4* kq) {
+        int pos[8] = {(int)pq[0].x, (int)pq[0].y, (int)pq[0].z, (int)pq[0].w, (int)pq[1].x, (int)pq[1].y, (int)pq[1].z, (int)pq[1].w};
+        if (!has_order) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                mb[q] = 0;
+            for (int e = 0; e < 8; ++e) pos[e] = t0 + e;
+        }
+        uint32_t key[8];
+        chunk_keys<DT>(kq, key);
+        uint32_t mem = 0;
 #pragma unroll
-                for (int bb = 0; bb < 4; ++bb) mb[q] |= ((mem >> (4 * q + bb)) & 1u) << (8 * bb);
+        for (int e = 0; e < 8; ++e) {
+            const int t = t0 + e;
+            const bool in = t >= lo && t < hi;
+            bool sel;
+            if (r.topk) sel = topk && in && (key[e] > kth || (key[e] == kth && t <= tstar));
+            else sel = in && key[e] >= pp.thr_key && key[e] != nan_key<DT>();
+            const bool m = pp.mode == 0 ? (sel && t > 0) : (in && !sel);
+            if (m) mem |= 1u << e;
+            if (t < L) {
+                before += (!m && pos[e] < base) ? 1 : 0;
+                const unsigned rel = (unsigned)(pos[e] - base);
+                if (rel < (unsigned)kSelSlice && !m) ((uint8_t*)s.keep)[rel] = 1;
             }
-            *(uint4*)(member + j0) = make_uint4(mb[0], mb[1], mb[2], mb[3]);
-        } else {
-            for (int e = 0; e < n_here; ++e) member[j0 + e] = (mem >> e) & 1u;
         }
+        if (t0 >= base && t0 < base + kSelSlice) {          // my slots (chunks never straddle a slice)
+            if (t0 + 8 <= L) {
+                uint32_t lo4 = 0, hi4 = 0;
 #pragma unroll
-        for (int e = 0; e < kEpt; ++e)
-            if (e < n_here) keep[ord[e]] = ((mem >> e) & 1u) ? 0 : 1;
-    }
-    if (blockIdx.x == 0 && tid == 0) {
-        if (pp.mode == 0) {
-            const double ratio = ftn > 0 ? (double)r.count / (double)ftn : 0.0;
-            stats[FF_STAT_COUNT] = r.count;
-            stats[FF_STAT_BRANCH] = r.topk ? 1 : 0;
-            stats[FF_STAT_BELOW_LB] = (!r.topk && ratio < pp.ratio_lb) ? 1 : 0;
-        } else {
-            stats[FF_STAT_NV] = L;
+                for (int e = 0; e < 4; ++e) {
+                    lo4 |= ((mem >> e) & 1u) << (8 * e);
+                    hi4 |= ((mem >> (4 + e)) & 1u) << (8 * e);
+                }
+                *(uint2*)(member + t0) = make_uint2(lo4, hi4);
+            } else {
+                for (int e = 0; e < 8 && t0 + e < L; ++e) member[t0 + e] = (mem >> e) & 1u;
+            }
         }
-        stats[FF_STAT_K] = r.k;
-        stats[FF_STAT_KTH_KEY] = kth;
-        stats[FF_STAT_TIES_TAKEN] = (select_topk && r.k > 0) ? need : 0;
+    };
+#pragma unroll
+    for (int x = 0; x < kRegChunks; ++x) {
+        const int t0 = tid * 8 + x * kChunkStride;
+        if (x * kChunkStride < L) classify(t0, po[x], kw[x]);        // (uniform: whole chunk rows beyond L are skipped)
+    }
+    for (int t0 = tid * 8 + kRegChunks * kChunkStride; t0 < L; t0 += kChunkStride) {
+        uint4 pq[2], kq[KW];
+        load_chunk<DT>(val_rsrc, ord_rsrc, has_order, t0, pq, kq);
+        classify(t0, pq, kq);
+    }
+    before = block_sum_i<NW>(before, s.sel.scratch);         // (barriers: the LDS keep flags are complete)
+    stamp[4] = wall_clock64();
+
+    // ---- compaction scan of my positions
+    const int i0 = base + tid * 4;
+    const uint32_t kb = s.keep[tid];
+    int span_total;
+    int p = before + block_excl_scan<NW>(__popc(kb), s.sel.scratch, span_total);
+    if (i0 < L) {
+        int d[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int kp = (kb >> (8 * e)) & 1u;
+            d[e] = kp ? p : -1;
+            p += kp;
+        }
+        if (i0 + 4 <= L) {
+            *(uint4*)(dst + i0) = make_uint4(d[0], d[1], d[2], d[3]);
+            *(uint32_t*)(keep + i0) = kb;
+        } else {
+            for (int e = 0; e < 4 && i0 + e < L; ++e) { dst[i0 + e] = d[e]; keep[i0 + e] = (kb >> (8 * e)) & 1u; }
+        }
+    }
+    if (blockIdx.x == gridDim.x - 1) {
+        if (tid == 0) {
+            stamp[5] = wall_clock64();
+#pragma unroll
+            for (int x = 1; x < 6; ++x) stats[FF_STAT_T_PLAN + x] = stamp[x] - stamp[0];
+            stats[FF_STAT_T_PLAN] = stamp[0];
+            stats[FF_STAT_T_PLAN + 6] = stamp_issued - stamp[0];
+            const int l_out = before + span_total;
+            stats[FF_STAT_LOUT] = l_out;
+            stats[FF_STAT_MERGED] = L - l_out;
+            if (pp.mode == 0) {
+                const double ratio = ftn > 0 ? (double)r.count / (double)ftn : 0.0;
+                stats[FF_STAT_COUNT] = r.count;
+                stats[FF_STAT_BRANCH] = r.topk ? 1 : 0;
+                stats[FF_STAT_BELOW_LB] = (!r.topk && ratio < pp.ratio_lb) ? 1 : 0;
+            } else {
+                stats[FF_STAT_NV] = L;
+            }
+            stats[FF_STAT_K] = r.k;
+            stats[FF_STAT_KTH_KEY] = kth;
+            stats[FF_STAT_TIES_TAKEN] = topk ? need : 0;
+        }
+        __syncthreads();
+        if (host_mapped && tid < kWave) publish(stats, host_mapped, seq);
     }
 }
 
-template <int DT>
-__global__ __launch_bounds__(kSliceThreads) void k_flags(
-    const void* __restrict__ values, int cap, PlanParams pp, const int* __restrict__ l0, const int* __restrict__ lv,
-    int64_t* __restrict__ stats, const int32_t* __restrict__ order, int L,
-    uint8_t* __restrict__ member, uint8_t* __restrict__ keep) {
-    __shared__ SliceLds s;
-    flags_body<DT>(values, cap, pp, l0, lv, stats, order, L, member, keep, s);
-}
-
-// Explicit merge set (merge_tokens_and_get_mask, main.py:243-319): member bytes were zeroed, set them.
+// ---- explicit merge set (merge_tokens_and_get_mask, main.py:243-319) --------------------------------
 __global__ __launch_bounds__(256) void k_mark_index(const int64_t* __restrict__ merge_index, int n_merge,
                                                     const int64_t* __restrict__ stats, uint8_t* __restrict__ member) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -451,30 +741,14 @@ __global__ __launch_bounds__(256) void k_keep_from_member(const uint8_t* __restr
     keep[order ? order[t] : t] = member[t] ? 0 : 1;
 }
 
-// ---- k_scan -------------------------------------------------------------------------------------------
+// dst[] from given keep bytes: workgroup g recounts keep[0, 4096 g) itself and scans its own span
 constexpr int kScanThreads = 256;
-constexpr int kScanSpan = kScanThreads * kEpt;     // 4096 positions per workgroup
-
-// Copy of the result block into device-visible pinned host memory: one lane per word (a single
-// store instruction crosses PCIe once), a system fence, then the sequence word the host polls.
-__device__ inline void publish(int64_t* __restrict__ stats, int64_t* host_mapped, int64_t seq) {
-    const int lane = threadIdx.x;          // called by wave 0
-    if (lane < FF_STAT_WORDS && lane != FF_STAT_SEQ)
-        __hip_atomic_store(&host_mapped[lane], stats[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (lane == FF_STAT_ERROR) stats[lane] = 0;     // reported; the next call starts clean
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-    if (lane == 0) __hip_atomic_store(&host_mapped[FF_STAT_SEQ], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-__device__ inline void scan_body(const uint8_t* keep, int L, int32_t* dst, int64_t* stats, int64_t* host_mapped,
-                                 int64_t seq, int* zero_me, int* scratch) {
+constexpr int kScanSpan = kScanThreads * kEpt;
+__global__ __launch_bounds__(kScanThreads) void k_scan(const uint8_t* __restrict__ keep, int L,
+                                                       int32_t* __restrict__ dst, int64_t* __restrict__ stats) {
+    __shared__ int scratch[kScanThreads / kWave + 1];
     const int tid = threadIdx.x;
-    // the level-0 statistics table the NEXT call's similarity kernel will accumulate into
-    if (zero_me)
-        for (int x = blockIdx.x * kScanThreads + tid; x < kL0Copies * kRowStride; x += gridDim.x * kScanThreads)
-            zero_me[x] = 0;
     const int base = blockIdx.x * kScanSpan;
-    // kept positions before my span: keep bytes are 0/1, so popcount of the words counts them
     int before = 0;
     for (int off = tid * 16; off < base; off += kScanThreads * 16) {
         const uint4 k4 = *(const uint4*)(keep + off);
@@ -493,117 +767,51 @@ __device__ inline void scan_body(const uint8_t* keep, int L, int32_t* dst, int64
     const int mine = __popc(kb[0]) + __popc(kb[1]) + __popc(kb[2]) + __popc(kb[3]);
     int span_total;
     int pos = before + block_excl_scan<kScanThreads / kWave>(mine, scratch, span_total);
-    if (n_here > 0) {
-        int d[kEpt];
-#pragma unroll
-        for (int e = 0; e < kEpt; ++e) {
-            const int kp = (kb[e >> 2] >> (8 * (e & 3))) & 1u;
-            d[e] = kp ? pos : -1;
-            pos += kp;
-        }
-        if (n_here == kEpt) {
-            uint4* p = (uint4*)(dst + i0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) p[q] = make_uint4(d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]);
-        } else {
-#pragma unroll
-            for (int e = 0; e < kEpt; ++e)
-                if (e < n_here) dst[i0 + e] = d[e];
-        }
+    for (int e = 0; e < n_here; ++e) {
+        const int kp = (kb[e >> 2] >> (8 * (e & 3))) & 1u;
+        dst[i0 + e] = kp ? pos : -1;
+        pos += kp;
     }
-    if (blockIdx.x == gridDim.x - 1) {
-        if (tid == 0) {
-            const int l_out = before + span_total;
-            stats[FF_STAT_LOUT] = l_out;
-            stats[FF_STAT_MERGED] = L - l_out;
-        }
-        __syncthreads();
-        if (host_mapped && tid < kWave) publish(stats, host_mapped, seq);
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+        const int l_out = before + span_total;
+        stats[FF_STAT_LOUT] = l_out;
+        stats[FF_STAT_MERGED] = L - l_out;
     }
-}
-
-__global__ __launch_bounds__(kScanThreads) void k_scan(const uint8_t* __restrict__ keep, int L,
-                                                       int32_t* __restrict__ dst, int64_t* __restrict__ stats,
-                                                       int64_t* host_mapped, int64_t seq, int* __restrict__ zero_me) {
-    __shared__ int scratch[kScanThreads / kWave + 1];
-    scan_body(keep, L, dst, stats, host_mapped, seq, zero_me, scratch);
-}
-
-// ---- fused plan: the radix levels, the flags and the scan in ONE launch ----------------------------------
-// The three stages need the results of ALL workgroups of the previous stage, so they are separated by
-// a grid barrier instead of a kernel boundary: only ceil(L / 4096) workgroups exist (9 at 64 x 576),
-// all co-resident on a 256-CU chip, and a kernel boundary costs a cold start per stage (the two
-// streaming passes flush the instruction lines of these tiny kernels out of L2 every call).
-// Barrier = the counter form of the release/acquire hand-off (cdna_hip_programming.md, G16): stores ->
-// __syncthreads -> lane 0: agent release + vmcnt(0) + relaxed agent add, relaxed poll with s_sleep,
-// agent acquire -> __syncthreads -> plain loads.  The counter is monotonic within a call and the
-// last stage clears the other parity's counter for the next call; a bounded spin turns a lost
-// workgroup into an error word instead of a hang.
-constexpr int kMaxFusedSlices = 64;
-
-__device__ inline void grid_barrier(int* counter, int target, int64_t* stats) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int spins = 0;
-        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1 << 24)) { stats[FF_STAT_ERROR] = 1; break; }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-}
-
-template <int DT>
-__global__ __launch_bounds__(kSliceThreads) void k_plan_fused(
-    const void* values, int cap, PlanParams pp, const int* l0, int* lv, int64_t* stats, const int32_t* order, int L,
-    uint8_t* member, uint8_t* keep, int32_t* dst, int64_t* host_mapped, int64_t seq, int* zero_l0,
-    int* bar, int* bar_next) {
-    constexpr int kLevels = Act<DT>::kKeyBits / 8;
-    __shared__ SliceLds s;
-    const int G = (int)gridDim.x;
-    int phase = 0;
-    for (int level = 1; level < kLevels; ++level) {
-        hist_level_body<DT>(values, cap, pp, level, stats, l0, lv, (int*)nullptr, s);
-        grid_barrier(bar, ++phase * G, stats);
-    }
-    flags_body<DT>(values, cap, pp, l0, lv, stats, order, L, member, keep, s);
-    grid_barrier(bar, ++phase * G, stats);
-    if (blockIdx.x == 0 && threadIdx.x == 0) *bar_next = 0;
-    scan_body(keep, L, dst, stats, host_mapped, seq, zero_l0, s.scratch);
 }
 
 // ---- launchers (also used by the fused step in ff_abi.hip) ------------------------------------------
 static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
 
-// Workspace layout (ints): [2][kL0Copies][kRowStride] level-0 tables filled by the similarity kernel
-// (double-buffered by call parity), 64 ints for the grid-barrier counters, [G][kRowStride] level-0 rows for the stand-alone entry points,
-// [3][G][256] rows of levels 1..3;  G = ceil(L / 4096).
-constexpr int kBarrierInts = 64;
-size_t plan_ws_bytes(int64_t L) {
-    const size_t G = (size_t)((L + kSlice - 1) / kSlice) + 1;
-    const size_t b = (2 * (size_t)kL0Copies * kRowStride + kBarrierInts + G * kRowStride + 3 * G * 256) * sizeof(int) + 256;
+// Workspace layout: [kL0Ints ints: level-0 tables][3 x G x 256 ints: fp32 level rows][K0's per-slice
+// rows, ff_order.hip] ... free ... [G slices of level-1 tables, down from the end];  G = ceil(L / 4096).
+size_t plan_ws_front_bytes(int64_t L) {
+    const size_t G = (size_t)((L + kSelSlice - 1) / kSelSlice) + 1;
+    const size_t b = ((size_t)kL0Ints + 2 * G * 256) * sizeof(int) + 256;
     return (b + 255) & ~(size_t)255;
 }
-// the two grid-barrier counters sit at a FIXED offset (they persist across calls of any length)
-static int* ws_barrier(void* ws, int64_t seq) {
-    return (int*)ws + 2 * (size_t)kL0Copies * kRowStride + 16 * (seq & 1);
+size_t plan_ws_tail_bytes(int64_t L) {
+    const size_t G = (size_t)((L + kSelSlice - 1) / kSelSlice) + 1;
+    return G * kT16SliceInts * sizeof(int);
 }
-int* ws_l0_copies(void* ws, int64_t seq) { return (int*)ws + (size_t)(seq & 1) * kL0Copies * kRowStride; }
-static int* ws_l0_rows(void* ws) { return (int*)ws + 2 * (size_t)kL0Copies * kRowStride + kBarrierInts; }
-static int* ws_levels(void* ws, int64_t L) {
-    const size_t G = (size_t)((L + kSlice - 1) / kSlice) + 1;
-    return ws_l0_rows(ws) + G * kRowStride;
-}
+int* ws_l0(void* ws) { return (int*)ws; }
+int* ws_t16_end(void* ws, size_t ws_bytes) { return (int*)((char*)ws + (ws_bytes & ~(size_t)15)); }
+static int* ws_levels(void* ws) { return (int*)ws + kL0Ints; }
 
-static int launch_scan(const uint8_t* keep, int64_t L, int32_t* dst, int64_t* stats, int64_t* host_mapped,
-                       int64_t seq, int* zero_me, hipStream_t st) {
-    hipLaunchKernelGGL(k_scan, dim3(cdiv(L, kScanSpan)), dim3(kScanThreads), 0, st, keep, (int)L, dst, stats,
-                       host_mapped, seq, zero_me);
-    return (int)hipGetLastError();
+// the regions a call over L values dirties (zeroed again by the merge kernel or by memsets)
+void table_regions(void* ws, size_t ws_bytes, int64_t L, void** a, size_t* a_bytes, void** b, size_t* b_bytes) {
+    const size_t G = (size_t)cdiv(L, kSelSlice);
+    *a = ws;
+    *a_bytes = (size_t)kL0Ints * sizeof(int);
+    *b = t16_slice(ws_t16_end(ws, ws_bytes), (int)G - 1);
+    *b_bytes = G * kT16SliceInts * sizeof(int);
+}
+int zero_tables(void* ws, size_t ws_bytes, int64_t L, hipStream_t st) {
+    void *a, *b;
+    size_t ab, bb;
+    table_regions(ws, ws_bytes, L, &a, &ab, &b, &bb);
+    hipError_t e = hipMemsetAsync(a, 0, ab, st);
+    if (e == hipSuccess) e = hipMemsetAsync(b, 0, bb, st);
+    return (int)e;
 }
 
 template <int DT>
@@ -625,93 +833,73 @@ template <> uint32_t host_thr_key<FF_F16>(double thr) {
     return (b & 0x8000u) ? ((uint32_t)(~b) & 0xffffu) : ((uint32_t)b | 0x8000u);
 }
 
-struct FusedTail {          // what the fused launch needs to also run the scan stage
-    int32_t* dst;
-    int64_t* host_mapped;
-    int64_t seq;
-    int* zero_l0;
-    int* bar;
-    int* bar_next;
-    bool done;
-};
-
-// values/selection -> member, keep (+ dst when fused).  l0 == nullptr: level 0 is computed here.
+// values + tables -> member, keep, dst, stats.  have_tables == false: build them here (k_tables) and
+// restore the zero state afterwards (memsets) - the stand-alone entry points.
 template <int DT>
-static int launch_select_flags(const void* values, PlanParams pp, const int* l0, int64_t cap, int64_t L,
-                               const int32_t* order, uint8_t* member, uint8_t* keep, int64_t* stats, void* ws,
-                               FusedTail* fused, hipStream_t st) {
+static int launch_plan(const void* values, PlanParams pp, bool have_tables, int64_t cap, int64_t L,
+                       const int32_t* order, uint8_t* member, uint8_t* keep, int32_t* dst, int64_t* stats,
+                       void* ws, size_t ws_bytes, int64_t* host_mapped, int64_t seq, hipStream_t st) {
     constexpr int kLevels = Act<DT>::kKeyBits / 8;
-    const unsigned G = cdiv(L, kSlice);
+    const unsigned G = cdiv(L, kSelSlice);
     pp.n_slices = (int)G;
-    int* lv = ws_levels(ws, L);
-    if (!l0) {
-        int* rows = ws_l0_rows(ws);
-        pp.l0_rows = (int)G;
-        hipLaunchKernelGGL(k_hist_level<DT>, dim3(G), dim3(kSliceThreads), 0, st, values, (int)cap, pp, 0, stats,
-                           (const int*)nullptr, lv, rows);
-        l0 = rows;
+    int* l0 = ws_l0(ws);
+    int* t16_end = ws_t16_end(ws, ws_bytes);
+    int* lv = ws_levels(ws);
+    if (!have_tables) {
+        int rc = zero_tables(ws, ws_bytes, L, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_tables<DT>, dim3(G), dim3(kSliceThreads), 0, st, values, (int)cap, pp.mode == 0 ? 0 : pp.lo,
+                           pp.mode == 0 ? -1 : pp.hi, (const int64_t*)stats, pp.thr_key, l0, t16_end);
     }
-    if (fused && G <= (unsigned)kMaxFusedSlices) {
-        // radix levels + flags + scan in one launch (grid barriers between the stages)
-        hipLaunchKernelGGL(k_plan_fused<DT>, dim3(G), dim3(kSliceThreads), 0, st, values, (int)cap, pp, l0, lv, stats,
-                           order, (int)L, member, keep, fused->dst, fused->host_mapped, fused->seq, fused->zero_l0,
-                           fused->bar, fused->bar_next);
-        fused->done = true;
-        return (int)hipGetLastError();
-    }
-    for (int level = 1; level < kLevels; ++level)
-        hipLaunchKernelGGL(k_hist_level<DT>, dim3(G), dim3(kSliceThreads), 0, st, values, (int)cap, pp, level, stats, l0, lv,
-                           (int*)nullptr);
-    hipLaunchKernelGGL(k_flags<DT>, dim3(G), dim3(kSliceThreads), 0, st, values, (int)cap, pp, l0, (const int*)lv, stats, order,
-                       (int)L, member, keep);
-    return (int)hipGetLastError();
+    for (int level = 2; level < kLevels; ++level)
+        hipLaunchKernelGGL(k_hist_level<DT>, dim3(G), dim3(kSliceThreads), 0, st, values, (int)cap, pp, level,
+                           (const int64_t*)stats, (const int*)l0, t16_end, lv);
+    hipLaunchKernelGGL(k_plan<DT>, dim3(G), dim3(kPlanThreads), 0, st, values, (int)cap, pp, (const int*)l0, t16_end,
+                       (const int*)lv, stats, order, (int)L, member, keep, dst, host_mapped, seq);
+    int rc = (int)hipGetLastError();
+    if (rc) return rc;
+    if (!have_tables) return zero_tables(ws, ws_bytes, L, st);
+    return FF_OK;
 }
 
-// l0_copies: the table the similarity kernel filled for this call (fused path) or nullptr.
 int launch_plan_merge(const void* sim, int dtype, const int32_t* order, int64_t L, double thr, double sub,
                       double ratio_lb, uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
-                      void* ws, const int* l0_copies, int* zero_next, int64_t* host_mapped, int64_t seq,
+                      void* ws, size_t ws_bytes, bool have_tables, int64_t* host_mapped, int64_t seq,
                       hipStream_t st, long long force_k) {
     PlanParams pp;
-    pp.mode = 0; pp.lo = 0; pp.hi = -1; pp.k_given = force_k; pp.sub = sub; pp.ratio_lb = ratio_lb;
-    pp.l0_rows = kL0Copies; pp.n_slices = 0;
-    int rc;
-    static int use_fused = -1;
-    if (use_fused < 0) { const char* e = getenv("FF_PLAN_FUSED"); use_fused = e ? atoi(e) : 0; }
-    FusedTail tail{dst, host_mapped, seq, zero_next, ws_barrier(ws, seq), ws_barrier(ws, seq + 1), false};
-    FusedTail* ft = (use_fused && l0_copies) ? &tail : nullptr;     // only with the per-call workspace protocol
+    pp.mode = 0; pp.lo = 0; pp.hi = -1; pp.k_given = force_k; pp.sub = sub; pp.ratio_lb = ratio_lb; pp.n_slices = 0;
+    // the k-th similarity of a video sits in the binade of typical thresholds: [0.5, 1)
+    const double guess_value = force_k >= 0 ? 0.75 : thr;
+    pp.p0_guess = (int)(dtype == FF_F32 ? host_thr_key<FF_F32>(guess_value) >> 24
+                        : dtype == FF_BF16 ? host_thr_key<FF_BF16>(guess_value) >> 8 : host_thr_key<FF_F16>(guess_value) >> 8);
     switch (dtype) {
         case FF_F32:
             pp.thr_key = host_thr_key<FF_F32>(thr);
-            rc = launch_select_flags<FF_F32>(sim, pp, l0_copies, L, L, order, member, keep, stats, ws, ft, st);
-            break;
+            return launch_plan<FF_F32>(sim, pp, have_tables, L, L, order, member, keep, dst, stats, ws, ws_bytes, host_mapped, seq, st);
         case FF_BF16:
             pp.thr_key = host_thr_key<FF_BF16>(thr);
-            rc = launch_select_flags<FF_BF16>(sim, pp, l0_copies, L, L, order, member, keep, stats, ws, ft, st);
-            break;
+            return launch_plan<FF_BF16>(sim, pp, have_tables, L, L, order, member, keep, dst, stats, ws, ws_bytes, host_mapped, seq, st);
         default:
             pp.thr_key = host_thr_key<FF_F16>(thr);
-            rc = launch_select_flags<FF_F16>(sim, pp, l0_copies, L, L, order, member, keep, stats, ws, ft, st);
+            return launch_plan<FF_F16>(sim, pp, have_tables, L, L, order, member, keep, dst, stats, ws, ws_bytes, host_mapped, seq, st);
     }
-    if (rc) return rc;
-    if (tail.done) return FF_OK;
-    return launch_scan(keep, L, dst, stats, host_mapped, seq, zero_next, st);
 }
 
 int launch_plan_prune(const void* imp, int dtype, int64_t S, int64_t start, int64_t n_img, int64_t k,
-                      uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats, void* ws,
-                      int64_t* host_mapped, int64_t seq, hipStream_t st) {
+                      uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats, void* ws, size_t ws_bytes,
+                      bool have_tables, hipStream_t st) {
     PlanParams pp;
     pp.mode = 1; pp.lo = (int)start; pp.hi = (int)(start + n_img); pp.k_given = k; pp.sub = 0; pp.ratio_lb = 0;
-    pp.thr_key = 0; pp.l0_rows = 0; pp.n_slices = 0;
-    int rc;
+    pp.thr_key = 0xffffffffu; pp.n_slices = 0;
+    // importances are probabilities of ~1/S: guess the binade of 1/n_img
+    const double guess_value = n_img > 0 ? 1.0 / (double)n_img : 1.0;
+    pp.p0_guess = (int)(dtype == FF_F32 ? host_thr_key<FF_F32>(guess_value) >> 24
+                        : dtype == FF_BF16 ? host_thr_key<FF_BF16>(guess_value) >> 8 : host_thr_key<FF_F16>(guess_value) >> 8);
     switch (dtype) {
-        case FF_F32: rc = launch_select_flags<FF_F32>(imp, pp, nullptr, S, S, nullptr, member, keep, stats, ws, nullptr, st); break;
-        case FF_BF16: rc = launch_select_flags<FF_BF16>(imp, pp, nullptr, S, S, nullptr, member, keep, stats, ws, nullptr, st); break;
-        default: rc = launch_select_flags<FF_F16>(imp, pp, nullptr, S, S, nullptr, member, keep, stats, ws, nullptr, st);
+        case FF_F32: return launch_plan<FF_F32>(imp, pp, have_tables, S, S, nullptr, member, keep, dst, stats, ws, ws_bytes, nullptr, 0, st);
+        case FF_BF16: return launch_plan<FF_BF16>(imp, pp, have_tables, S, S, nullptr, member, keep, dst, stats, ws, ws_bytes, nullptr, 0, st);
+        default: return launch_plan<FF_F16>(imp, pp, have_tables, S, S, nullptr, member, keep, dst, stats, ws, ws_bytes, nullptr, 0, st);
     }
-    if (rc) return rc;
-    return launch_scan(keep, S, dst, stats, host_mapped, seq, nullptr, st);
 }
 
 int launch_plan_from_index(const int64_t* merge_index, int64_t n_merge, const int32_t* order, int64_t L,
@@ -721,9 +909,8 @@ int launch_plan_from_index(const int64_t* merge_index, int64_t n_merge, const in
     if (n_merge > 0)
         hipLaunchKernelGGL(k_mark_index, dim3(cdiv(n_merge, 256)), dim3(256), 0, st, merge_index, (int)n_merge, stats, member);
     hipLaunchKernelGGL(k_keep_from_member, dim3(cdiv(L, 256)), dim3(256), 0, st, member, order, (int)L, keep);
-    int rc = (int)hipGetLastError();
-    if (rc) return rc;
-    return launch_scan(keep, L, dst, stats, nullptr, 0, nullptr, st);
+    hipLaunchKernelGGL(k_scan, dim3(cdiv(L, kScanSpan)), dim3(kScanThreads), 0, st, (const uint8_t*)keep, (int)L, dst, stats);
+    return (int)hipGetLastError();
 }
 
 }  // namespace ff
@@ -732,7 +919,7 @@ static int check_plan_args(const void* a, const void* b, const void* c, const vo
                            int64_t L, void* ws, size_t ws_bytes) {
     if (!a || !b || !c || !d || !e || !ws || L < 0) return FF_ERR_ARG;
     if (L >= (1ll << 31) - 65536) return FF_ERR_UNSUPPORTED;
-    if (ws_bytes < ff::plan_ws_bytes(L)) return FF_ERR_WORKSPACE;
+    if (ws_bytes < ff_workspace_bytes(L, 1)) return FF_ERR_WORKSPACE;
     return FF_OK;
 }
 
@@ -745,10 +932,12 @@ extern "C" int ff_plan_merge(const void* sim, int dtype, const int32_t* order, i
     if (rc) return rc;
     if (!order) return FF_ERR_ARG;
     if (dtype != FF_F32 && dtype != FF_BF16 && dtype != FF_F16) return FF_ERR_ARG;
-    if (!aligned16(sim) || !aligned16(dst) || !aligned16(keep) || !aligned16(ws)) return FF_ERR_ALIGN;
+    if (!aligned16(sim) || !aligned16(dst) || !aligned16(keep) || !aligned16(ws) || !aligned16(order) ||
+        ((uintptr_t)member & 7))
+        return FF_ERR_ALIGN;
     if (L == 0) return FF_OK;
-    return ff::launch_plan_merge(sim, dtype, order, L, threshold, sub, ratio_lb, member, dst, keep, stats, ws,
-                                 nullptr, nullptr, nullptr, 0, (hipStream_t)stream, -1);
+    return ff::launch_plan_merge(sim, dtype, order, L, threshold, sub, ratio_lb, member, dst, keep, stats, ws, ws_bytes,
+                                 false, nullptr, 0, (hipStream_t)stream, -1);
 }
 
 extern "C" int ff_plan_topk(const void* sim, int dtype, const int32_t* order, int64_t L, int64_t k, uint8_t* member,
@@ -758,9 +947,11 @@ extern "C" int ff_plan_topk(const void* sim, int dtype, const int32_t* order, in
     if (rc) return rc;
     if (!order || k < 0) return FF_ERR_ARG;
     if (dtype != FF_F32 && dtype != FF_BF16 && dtype != FF_F16) return FF_ERR_ARG;
-    if (!aligned16(sim) || !aligned16(dst) || !aligned16(keep) || !aligned16(ws)) return FF_ERR_ALIGN;
+    if (!aligned16(sim) || !aligned16(dst) || !aligned16(keep) || !aligned16(ws) || !aligned16(order) ||
+        ((uintptr_t)member & 7))
+        return FF_ERR_ALIGN;
     if (L == 0) return FF_OK;
-    return ff::launch_plan_merge(sim, dtype, order, L, 0.0, 0.0, 0.0, member, dst, keep, stats, ws, nullptr, nullptr,
+    return ff::launch_plan_merge(sim, dtype, order, L, 0.0, 0.0, 0.0, member, dst, keep, stats, ws, ws_bytes, false,
                                  nullptr, 0, (hipStream_t)stream, k);
 }
 
@@ -782,8 +973,9 @@ extern "C" int ff_plan_prune(const void* importance, int dtype, int64_t S, int64
     if (rc) return rc;
     if (dtype != FF_F32 && dtype != FF_BF16 && dtype != FF_F16) return FF_ERR_ARG;
     if (start < 0 || n_img < 0 || start + n_img > S || k < 0) return FF_ERR_ARG;
-    if (!aligned16(importance) || !aligned16(dst) || !aligned16(keep) || !aligned16(ws)) return FF_ERR_ALIGN;
+    if (!aligned16(importance) || !aligned16(dst) || !aligned16(keep) || !aligned16(ws) || ((uintptr_t)member & 7))
+        return FF_ERR_ALIGN;
     if (S == 0) return FF_OK;
-    return ff::launch_plan_prune(importance, dtype, S, start, n_img, k, member, dst, keep, stats, ws, nullptr, 0,
+    return ff::launch_plan_prune(importance, dtype, S, start, n_img, k, member, dst, keep, stats, ws, ws_bytes, false,
                                  (hipStream_t)stream);
 }

@@ -13,8 +13,6 @@
 // Rounding recipe, T = activation dtype:
 //     dot = T(sum_fp32 T(a_i*b_i));  na = T(sqrt_fp32(sum_fp32 a_i^2));  sim = T(dot / T(na*nb))
 // sqrt and divide are the correctly rounded fp32 forms (hipcc default).
-#include <stdlib.h>
-
 #include "ff_common.h"
 
 namespace ff {
@@ -34,7 +32,7 @@ template <int DT, int kPairs, int kSimThreads, bool kHint>
 __global__ __launch_bounds__(kSimThreads) void k_pair_similarity(
     const char* __restrict__ hidden, uint32_t row_bytes, const int64_t* __restrict__ ptype,
     const int32_t* __restrict__ order, const int64_t* __restrict__ stats, void* __restrict__ sim,
-    int* __restrict__ l0, float thr, const LayoutHint hint, int32_t* __restrict__ order_out,
+    int* __restrict__ l0, int* t16_end, float thr, const LayoutHint hint, int32_t* __restrict__ order_out,
     int64_t* __restrict__ stats_out) {
     using A = Act<DT>;
     constexpr int E = A::kPer16;
@@ -169,29 +167,22 @@ __global__ __launch_bounds__(kSimThreads) void k_pair_similarity(
         }
     }
     if (l0) {
-        // level-0 statistics of the select that follows (ff_plan.hip): top byte of the
-        // order-preserving key + count(sim >= thr), folded over the wave's kPairs values and added
-        // to one of 16 table copies so the (non-returning) atomics never pile up on one L2 word
-        int* tab = l0 + (blockIdx.x & 15) * 260;
+        // select statistics of the plan kernel that follows (ff_plan.hip): the top byte of the
+        // order-preserving key + count(sim >= thr) into one of kL0Copies level-0 tables, and the top
+        // 16 bits into the level-1 table of this wave's slice - equal values of the wave folded into
+        // one non-returning atomic each, copies chosen per workgroup so that the atomics of a video's
+        // dozen distinct similarity values never pile up on one memory-side word
         uint32_t bits;
         if constexpr (DT == FF_F32) bits = __float_as_uint(mine);
         else if constexpr (DT == FF_BF16) bits = __float_as_uint(mine) >> 16;
         else { _Float16 h = (_Float16)mine; bits = (uint32_t)__builtin_bit_cast(uint16_t, h); }
-        const int bin = (int)(order_key<DT>(bits) >> (A::kKeyBits - 8));
-        const unsigned long long vm = __ballot(have);
+        const uint32_t key = order_key<DT>(bits);
+        int* tab = l0 + (blockIdx.x & (kL0Copies - 1)) * kL0Stride;
         const int n_ge = __popcll(__ballot(have && mine >= thr));
         if (lane == 0 && n_ge) atomicAdd(&tab[256], n_ge);
-        int mult = 0;
-        bool leader = have;
-#pragma unroll
-        for (int q = 0; q < kPairs; ++q) {
-            const int bq = __builtin_amdgcn_readlane(bin, q);
-            if (((vm >> q) & 1ull) && bq == bin) {
-                ++mult;
-                if (q < lane) leader = false;
-            }
-        }
-        if (leader) atomicAdd(&tab[bin], mult);
+        wave_agg_add<kPairs>(tab, key >> (A::kKeyBits - 8), have);
+        int* t16 = t16_slice(t16_end, j0 / kSelSlice) + (blockIdx.x & (kT16Copies - 1)) * 65536;
+        wave_agg_add<kPairs>(t16, t16_bin(key >> (A::kKeyBits - 16)), have);
     }
 }
 
@@ -203,6 +194,7 @@ struct SimArgs {
     const int64_t* stats;
     void* sim;
     int* l0;
+    int* t16_end;
     float thr;
     LayoutHint hint;          // frames == 0: no hint
     int32_t* order_out;
@@ -216,47 +208,23 @@ static int launch_similarity_pt(const SimArgs& a, hipStream_t st) {
     const int64_t blocks = (a.L + per_block - 1) / per_block;
     if (a.hint.frames > 0)
         hipLaunchKernelGGL((k_pair_similarity<DT, kPairs, kSimThreads, true>), dim3((unsigned)blocks), dim3(kSimThreads), 0,
-                           st, (const char*)a.hidden, (uint32_t)row_bytes, a.ptype, a.order, a.stats, a.sim, a.l0, a.thr,
+                           st, (const char*)a.hidden, (uint32_t)row_bytes, a.ptype, a.order, a.stats, a.sim, a.l0, a.t16_end, a.thr,
                            a.hint, a.order_out, a.stats_out);
     else
         hipLaunchKernelGGL((k_pair_similarity<DT, kPairs, kSimThreads, false>), dim3((unsigned)blocks), dim3(kSimThreads), 0,
-                           st, (const char*)a.hidden, (uint32_t)row_bytes, a.ptype, a.order, a.stats, a.sim, a.l0, a.thr,
+                           st, (const char*)a.hidden, (uint32_t)row_bytes, a.ptype, a.order, a.stats, a.sim, a.l0, a.t16_end, a.thr,
                            a.hint, (int32_t*)nullptr, (int64_t*)nullptr);
     return (int)hipGetLastError();
 }
 
-template <int DT, int kPairs>
-static int launch_similarity_p(const SimArgs& a, hipStream_t st) {
-    static int waves = 0;
-    if (!waves) { const char* e = getenv("FF_SIM_WAVES"); waves = e ? atoi(e) : 4; }
-    if (waves == 8) return launch_similarity_pt<DT, kPairs, 512>(a, st);
-    if (waves == 2) return launch_similarity_pt<DT, kPairs, 128>(a, st);
-    return launch_similarity_pt<DT, kPairs, 256>(a, st);
-}
-
-static int tune_pairs() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("FF_SIM_PAIRS");
-        v = e ? atoi(e) : 4;
-    }
-    return v;
-}
-
 template <int DT>
-static int launch_similarity(const SimArgs& a, hipStream_t st) {
-    switch (tune_pairs()) {
-        case 2: return launch_similarity_p<DT, 2>(a, st);
-        case 8: return launch_similarity_p<DT, 8>(a, st);
-        default: return launch_similarity_p<DT, 4>(a, st);
-    }
-}
+static int launch_similarity(const SimArgs& a, hipStream_t st) { return launch_similarity_pt<DT, 4, 256>(a, st); }
 
 // hint_frames > 0: frame-major closed form (see LayoutHint); `order` and `stats` are then outputs.
 int launch_similarity_any(const void* hidden, int dtype, int64_t L, int64_t d, const int64_t* ptype,
-                          int32_t* order, int64_t* stats, void* sim, int* l0, double thr,
+                          int32_t* order, int64_t* stats, void* sim, int* l0, int* t16_end, double thr,
                           int64_t hint_pre, int64_t hint_patches, int64_t hint_frames, hipStream_t st) {
-    SimArgs a{hidden, L, d, ptype, order, stats, sim, l0, (float)thr,
+    SimArgs a{hidden, L, d, ptype, order, stats, sim, l0, t16_end, (float)thr,
               LayoutHint{(int)hint_pre, (int)hint_patches, (int)hint_frames, (int)L}, order, stats};
     switch (dtype) {
         case FF_F32: return launch_similarity<FF_F32>(a, st);
@@ -277,5 +245,5 @@ extern "C" int ff_pair_similarity(const void* hidden, int dtype, int64_t L, int6
     if (L >= (1ll << 31) || d * esz >= (1ll << 31)) return FF_ERR_UNSUPPORTED;
     if (L == 0) return FF_OK;
     return ff::launch_similarity_any(hidden, dtype, L, d, patch_type, const_cast<int32_t*>(order),
-                                     const_cast<int64_t*>(stats), sim, nullptr, 0.0, 0, 0, 0, (hipStream_t)stream);
+                                     const_cast<int64_t*>(stats), sim, nullptr, nullptr, 0.0, 0, 0, 0, (hipStream_t)stream);
 }

@@ -49,7 +49,7 @@ class _Scratch:
     def __init__(self, device):
         self.device = device
         self.cap = 0
-        self.order_valid_for = None     # (patch_type data_ptr, L) the cached by-patch order belongs to
+        self.order_valid_for = None     # (patch_type generation, L) the cached by-patch order belongs to
 
     def ensure(self, L: int, sim_dtype):
         if L > self.cap:
@@ -100,6 +100,7 @@ class FrameFusion(nn.Module):
         self.similarity_lower_bound = similarity_lower_bound
         self.ratio_lower_bound = ratio_lower_bound
         self._scratch = {}
+        self._ptype_gen = 0       # bumped whenever patch_type is (re)assigned: keys the cached by-patch order
         self.last_call = None     # diagnostics of the most recent reduction (tests / bench)
 
     _PLAIN = (bool, int, float, str, list, tuple, dict, type(None), torch.Tensor)
@@ -109,10 +110,30 @@ class FrameFusion(nn.Module):
         # (flags, scalars, the patch_type tensor) rewritten on every call.  nn.Module.__setattr__
         # spends ~2 us per assignment on parameter/buffer/submodule bookkeeping before it ends up in
         # __dict__ as well, so plain values go there directly.
+        if name == "patch_type":
+            # ANY assignment (prepare(), the compaction of a merge call, a caller writing the attribute
+            # as the reference allows) invalidates the by-patch order kept in the scratch
+            self.__dict__["_ptype_gen"] = self.__dict__.get("_ptype_gen", 0) + 1
         if type(value) in FrameFusion._PLAIN:
             object.__setattr__(self, name, value)
         else:
             super().__setattr__(name, value)
+
+    def __getstate__(self):
+        # The scratch holds device buffers and a raw pointer into pinned host memory that the device
+        # publishes results into: a copy.deepcopy / pickle of a used instance must not share it.
+        state = self.__dict__.copy()
+        state["_scratch"] = {}
+        state["last_call"] = None
+        return state
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = type(self).__new__(type(self))
+        memo[id(self)] = new
+        for k, v in self.__getstate__().items():
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
 
     # ---- reference main.py:15-38 -----------------------------------------------------------
     def prepare(self, patch_type: torch.Tensor, patch_num: int, image_token_start_index,
@@ -273,8 +294,7 @@ class FrameFusion(nn.Module):
         sc = self._scratch_for(device, L, dtype)
         stream = _lib.stream_ptr()
         sim_ptr = sc.sim32.data_ptr()
-        order_key = (ptype.data_ptr(), L)
-        order_valid = 1 if sc.order_valid_for == order_key else 0
+        order_valid = 1 if sc.order_valid_for == (self._ptype_gen, L) else 0
 
         # first half (K0 + K1) goes out before any output tensor exists: the allocations below
         # overlap the similarity pass
@@ -327,7 +347,12 @@ class FrameFusion(nn.Module):
         # pinned host memory (sequence word last) BEFORE the merge kernel runs, so the host learns
         # L_out while the second streaming pass is still in flight and returns without waiting for it.
         st = sc.wait_stats(seq)
-        if int(st[_lib.STAT_ERROR]) & _lib.ERR_BIT_LAYOUT:
+        err = int(st[_lib.STAT_ERROR])
+        if err & ~_lib.ERR_BIT_LAYOUT:
+            sc.dirty = True
+            sc.order_valid_for = None
+            raise FrameFusionHipError(f"device-side check failed in the merge call (error bits {err:#x})")
+        if err & _lib.ERR_BIT_LAYOUT:
             # patch_type is not the frame-major layout the prepare() scalars suggested (e.g. text
             # between the frames): everything this call enqueued is void.  Repeat it through K0 and
             # stop hinting for this prefill.
@@ -356,7 +381,7 @@ class FrameFusion(nn.Module):
             # in the scratch still describes the (unchanged) patch_type
             self.last_call = dict(kind="merge", L_in=L, L_out=L, nv=nv, ftn=ftn, count=count, branch=branch,
                                   k=int(st[_lib.STAT_K]), scratch=sc, dtype=dtype, order=sc.order)
-            sc.order_valid_for = (self.patch_type.data_ptr(), L)
+            sc.order_valid_for = (self._ptype_gen, L)
             return pending["inputs"]
 
         self.patch_type = ptype_out[:, :L_out]                                      # main.py:132
@@ -365,7 +390,7 @@ class FrameFusion(nn.Module):
         self.last_call = dict(kind="merge", L_in=L, L_out=L_out, nv=nv, ftn=ftn, count=count, branch=branch,
                               k=int(st[_lib.STAT_K]), scratch=sc, dtype=dtype, order=sc.order)
         sc.order, sc.order_next = sc.order_next, sc.order
-        sc.order_valid_for = (ptype_out.data_ptr(), L_out)
+        sc.order_valid_for = (self._ptype_gen, L_out)
         hidden_states = out[:, :L_out]
         position_embeddings = rebuild(L_out)
         if mask_out is not None:
@@ -400,38 +425,40 @@ class FrameFusion(nn.Module):
         _lib.require_gpu(w, "FrameFusion.forward(self_attn_weights)")
         if w.ndim != 4 or w.shape[0] != 1 or w.shape[-1] != q_len:
             raise FrameFusionHipError(f"self_attn_weights of shape {tuple(w.shape)} is not [1, H, num, {q_len}]")
-        if w.dtype != dtype:
-            w = w.to(dtype)
+        # the head mean and the top-k run in the WEIGHTS' dtype (main.py:69-76: torch.mean / topk of the
+        # tensor the attention hook handed over), whatever the activation dtype is
+        w_code = _lib.DTYPE_CODE.get(w.dtype)
+        if w_code is None:
+            raise FrameFusionHipError(f"unsupported attention-weight dtype {w.dtype} (fp32 / bf16 / fp16 only)")
         w = w.contiguous()
         if w.data_ptr() & 15:
             w = w.clone()
-        imp = sc.sim(dtype, q_len)
         pruning_ratio = self._compute_pruning_ratio(self.sparsity_list, self.cost)  # main.py:73
         k = round(n_img * (1 - pruning_ratio))                                      # main.py:76
         if k < 0 or k > n_img:
             raise RuntimeError("selected index k out of range")                     # torch.topk's error
         L_out = q_len - n_img + k
-        # the index kernels go out first (head mean, main.py:69-70, + top-k plan): they need no output
-        # tensor, so the allocations below overlap them; nothing is read back (L_out is known)
-        imp_ptr = w.data_ptr()
-        if w.shape[1] * w.shape[2] != 1:
-            _lib.check(lib.ff_head_mean(w.data_ptr(), code, w.shape[1], w.shape[2], q_len, imp.data_ptr(), stream),
-                       "ff_head_mean")
-            imp_ptr = imp.data_ptr()
-        _lib.check(lib.ff_plan_prune(imp_ptr, code, q_len, start, n_img, k, sc.member.data_ptr(), sc.dst.data_ptr(),
-                                     sc.keep.data_ptr(), sc.stats.data_ptr(), sc.ws.data_ptr(), sc.ws_bytes, stream),
-                   "ff_plan_prune")
+        if sc.dirty:                 # a merge call died half-way: the select tables must start from zero
+            sc.ws.zero_()
+            sc.stats.zero_()
+            sc.dirty = False
+        # nothing is read back (L_out is known): head mean + select tables, plan, gather - one host call
         out = torch.empty(1, L_out, d, dtype=dtype, device=device)
         srcs, outs, rebuild = self._aux_for_positions(position_embeddings, q_len, L_out)
         aux = (FFAux * _lib.MAX_AUX)()
         n_aux = self._fill_aux(aux, 0, srcs, outs, q_len)
-        _lib.check(lib.ff_merge_compact(hidden.data_ptr(), out.data_ptr(), code, q_len, d, L_out, None,
-                                        sc.member.data_ptr(), 0, sc.dst.data_ptr(), sc.keep.data_ptr(), aux, n_aux,
-                                        stream), "ff_merge_compact")
+        imp = sc.sim32[:q_len]       # fp32-sized slots: room for any weight dtype
+        sc.dirty = True
+        _lib.check(lib.ff_prune_step(hidden.data_ptr(), out.data_ptr(), code, q_len, d, L_out,
+                                     w.data_ptr(), w_code, w.shape[1], w.shape[2], imp.data_ptr(), 0,
+                                     start, n_img, k, sc.member.data_ptr(), sc.dst.data_ptr(), sc.keep.data_ptr(),
+                                     sc.stats.data_ptr(), aux, n_aux, sc.ws.data_ptr(), sc.ws_bytes, stream),
+                   "ff_prune_step")
+        sc.dirty = False
         if attention_mask is not None:
             attention_mask = self._gather_mask(attention_mask, q_len, L_out, sc.dst, stream)
         self.finish_pruning = True                                                  # main.py:101
-        self.last_call = dict(kind="prune", L_in=q_len, L_out=L_out, k=k, nv=q_len, scratch=sc, dtype=dtype)
+        self.last_call = dict(kind="prune", L_in=q_len, L_out=L_out, k=k, nv=q_len, scratch=sc, dtype=w.dtype)
         return out, rebuild(L_out), attention_mask
 
     # ---- static parity entry points ---------------------------------------------------------------

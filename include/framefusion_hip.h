@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FF_ABI_VERSION 2
+#define FF_ABI_VERSION 3
 
 enum { FF_F32 = 0, FF_BF16 = 1, FF_F16 = 2 };
 
@@ -281,11 +281,15 @@ int ff_merge_finish_topk(const void* hidden, void* hidden_out, int dtype, int64_
                          void* ws, size_t ws_bytes, ff_stream_t stream);
 
 /* One FrameFusion.forward prune call (main.py:61-101) from a single host call: head mean of the
- * attention weights (skipped when H*num == 1: the weights are then already the importance),
- * ff_plan_prune, ff_merge_compact(order = NULL, fold = 0).  The output length
- * S - n_img + k is known to the host, so nothing is read back. */
+ * attention weights [H, num, S] of dtype w_dtype (main.py:69-70: mean and top-k run in the WEIGHTS'
+ * dtype, which need not be the activations'), the select + scan (ff_plan_prune) and
+ * ff_merge_compact(order = NULL, fold = FF_FOLD_DROP).  H*num == 1: attn_w already IS the importance
+ * [S]; tables_ready != 0 then says that its producer (ff_last_query_attention with a workspace) has
+ * accumulated the select tables in `ws`.  `importance` is scratch for S values of w_dtype.  The output
+ * length S - n_img + k is known to the host, so nothing is read back.  `ws` follows the workspace
+ * protocol of ff_merge_begin (zero on entry, left zero). */
 int ff_prune_step(const void* hidden, void* hidden_out, int dtype, int64_t S, int64_t d, int64_t L_cap,
-                  const void* attn_w, int64_t H, int64_t num, void* importance,
+                  const void* attn_w, int w_dtype, int64_t H, int64_t num, void* importance, int tables_ready,
                   int64_t start, int64_t n_img, int64_t k,
                   uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
                   const ff_aux_t* aux_host, int n_aux, void* ws, size_t ws_bytes, ff_stream_t stream);

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(_lib.LIB_PATH)
     for name in declared_functions():
         assert hasattr(lib, name), name
-    assert _lib.load().ff_abi_version() == _lib.ABI_VERSION == 2
+    assert _lib.load().ff_abi_version() == _lib.ABI_VERSION == 3
 
 
 def test_stat_enum_matches_binding():
@@ -60,7 +60,7 @@ def test_argument_validation_without_gpu():
     assert lib.ff_pair_similarity(16, 1, 10, 3, 16, 16, 16, 16, None) == -2           # 6-byte rows: alignment
     assert lib.ff_pair_similarity(24, 1, 10, 64, 16, 16, 16, 16, None) == -2          # base not 16-byte aligned
     assert lib.ff_plan_merge(None, 1, None, 10, 0.6, 0.7, 0.1, None, None, None, None, None, 0, None) == -1
-    assert lib.ff_plan_prune(16, 1, 10, 8, 5, 2, 16, 16, 16, 16, 16, 1 << 20, None) == -1  # start + n_img > S
+    assert lib.ff_plan_prune(16, 1, 10, 8, 5, 2, 16, 16, 16, 16, 16, 1 << 24, None) == -1  # start + n_img > S
     assert lib.ff_plan_prune(16, 1, 10, 2, 5, 2, 16, 16, 16, 16, 16, 64, None) == -4       # workspace too small
     assert lib.ff_merge_compact(None, None, 1, 10, 64, 10, None, None, 1, None, None, None, 0, None) == -1
     assert lib.ff_head_mean(None, 1, 4, 1, 10, None, None) == -1

@@ -374,7 +374,7 @@ def test_order_maintenance():
         assert torch.equal(pg.cpu(), po) and same_bits(hg.cpu(), ho)
         sc = f.last_call["scratch"]
         n = hg.shape[1]
-        assert sc.order_valid_for == (f.patch_type.data_ptr(), n)
+        assert sc.order_valid_for == (f._ptype_gen, n)
         fresh, stats = hip_order(f.patch_type.cpu(), 37)
         assert torch.equal(sc.order[:n].cpu().long(), fresh)
         assert int(sc.stats[_lib.STAT_NV]) == int(stats[_lib.STAT_NV])

@@ -22,7 +22,7 @@ for r in rows:
     if k == "k_merge_compact":
         calls.append(cur)
         cur = []
-tail = ["k_pair_similarity", "k_hist_level", "k_flags", "k_scan", "k_merge_compact"]
+tail = ["k_pair_similarity", "k_plan", "k_merge_compact"]
 shapes = [["k_order_stats", "k_build_order"] + tail, tail]
 calls = [c for c in calls if [k for k, _, _ in c] in shapes]
 if calls:
