@@ -146,7 +146,7 @@ def main():
         def cur_hidden():           # same alternation as the timed loop (set per repetition below)
             return hidden_alt if rep_no[0] & 1 else hidden
         stages = {
-            "order": lambda: lib.ff_build_order(ptype.data_ptr(), L, P, order_buf.data_ptr(), sc.stats.data_ptr(),
+            "order": lambda: lib.ff_build_order(ptype.data_ptr(), L, P, order_buf.data_ptr(), None, sc.stats.data_ptr(),
                                                 sc.ws.data_ptr(), sc.ws_bytes, stream),
             "similarity": lambda: lib.ff_pair_similarity(cur_hidden().data_ptr(), _lib.FF_BF16, L, d, ptype.data_ptr(),
                                                          order_buf.data_ptr(), sc.stats.data_ptr(), sim.data_ptr(), stream),

@@ -28,7 +28,7 @@ STAT_ERROR = 11
 ERR_BIT_BARRIER, ERR_BIT_LAYOUT = 1, 2
 STAT_WORDS = 32
 MAX_AUX = 4
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class FFAux(C.Structure):
@@ -50,7 +50,7 @@ PROTOTYPES = {
     "ff_abi_version": (C.c_int, []),
     "ff_error_string": (C.c_char_p, [_i32]),
     "ff_workspace_bytes": (_sz, [_i64, _i64]),
-    "ff_build_order": (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "ff_build_order": (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ff_pair_similarity": (_i32, [_vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "ff_plan_merge": (_i32, [_vp, _i32, _vp, _i64, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ff_plan_from_index": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -61,20 +61,20 @@ PROTOTYPES = {
     "ff_head_mean": (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _vp]),
     "ff_last_query_attention": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _i64, _i64, _f64, _i32, _vp, _vp, _vp,
                                        _sz, _vp]),
-    "ff_merge_begin": (_i32, [_vp, _i32, _i64, _i64, _vp, _i64, _i32, _f64, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _sz,
+    "ff_merge_begin": (_i32, [_vp, _i32, _i64, _i64, _vp, _i64, _i32, _f64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _sz,
                               _vp]),
-    "ff_merge_finish": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                               _i64, C.POINTER(FFAux), _i32, _vp, _vp, _sz, _vp]),
+    "ff_merge_finish": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                               _i64, C.POINTER(FFAux), _i32, _vp, _vp, _vp, _sz, _vp]),
     "ff_prune_step": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _i32, _i64, _i64, _vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp,
                              _vp, C.POINTER(FFAux), _i32, _vp, _sz, _vp]),
     "ff_plan_topk": (_i32, [_vp, _i32, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "ff_merge_finish_topk": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                    _i64, C.POINTER(FFAux), _i32, _vp, _vp, _sz, _vp]),
+    "ff_merge_finish_topk": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                    _i64, C.POINTER(FFAux), _i32, _vp, _vp, _vp, _sz, _vp]),
     "ff_token_span": (_i32, [_vp, _i64, _i64, _vp, _vp]),
     "ff_fill_patch_type": (_i32, [_vp, _i64, C.POINTER(FFSegment), _i64, _vp]),
     "ff_patch_type_from_mask": (_i32, [_vp, _i64, _i64, _vp, _vp, _vp]),
-    "ff_merge_step": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _i64, _i32, _f64, _f64, _f64, _vp, _vp, _vp,
-                             _vp, _vp, _vp, _vp, _i64, C.POINTER(FFAux), _i32, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "ff_merge_step": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _i64, _i32, _f64, _f64, _f64, _vp, _vp, _vp, _vp,
+                             _vp, _vp, _vp, _vp, _i64, C.POINTER(FFAux), _i32, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
 }
 
 _lib = None

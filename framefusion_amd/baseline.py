@@ -125,7 +125,8 @@ class FixedSparsityMerging:
         seq = sc.seq
         sc.dirty = True
         _lib.check(lib.ff_merge_begin(hidden.data_ptr(), code, L, d, ptype.data_ptr(), int(self.patch_num), order_valid,
-                                      0.0, sc.order.data_ptr(), sc.sim32.data_ptr(), sc.stats.data_ptr(), seq, 0, 0,
+                                      0.0, sc.order.data_ptr(), sc.inv.data_ptr(), sc.sim32.data_ptr(), sc.stats.data_ptr(),
+                                      seq, 0, 0,
                                       sc.ws.data_ptr(), sc.ws_bytes, stream), "ff_merge_begin")
 
         out = torch.empty(1, L, d, dtype=dtype, device=device)
@@ -146,9 +147,10 @@ class FixedSparsityMerging:
             res_out = torch.empty_like(res)
             n_aux = FrameFusion._fill_aux(aux, n_aux, [res], [res_out], L)
         _lib.check(lib.ff_merge_finish_topk(hidden.data_ptr(), out.data_ptr(), code, L, d, L, prune_num, _lib.FOLD_MEAN,
-                                            sc.order.data_ptr(), sc.sim32.data_ptr(), sc.member.data_ptr(),
-                                            sc.dst.data_ptr(), sc.keep.data_ptr(), sc.stats.data_ptr(),
-                                            sc.stats_host_ptr, seq, aux, n_aux, sc.order_next.data_ptr(),
+                                            sc.order.data_ptr(), sc.inv.data_ptr(), sc.sim32.data_ptr(),
+                                            sc.member.data_ptr(), sc.dst.data_ptr(), sc.keep.data_ptr(),
+                                            sc.stats.data_ptr(), sc.stats_host_ptr, seq, aux, n_aux,
+                                            sc.order_next.data_ptr(), sc.inv_next.data_ptr(),
                                             sc.ws.data_ptr(), sc.ws_bytes, stream), "ff_merge_finish_topk")
         sc.dirty = False
         token_mask = sc.keep[:L].bool().view(1, L)          # a copy: the scratch is reused by the next layer
@@ -174,6 +176,7 @@ class FixedSparsityMerging:
         self.last_call = dict(kind="merge", L_in=L, L_out=L_out, nv=nv, ftn=ftn, k=int(st[_lib.STAT_K]),
                               scratch=sc, dtype=dtype, order=sc.order)
         sc.order, sc.order_next = sc.order_next, sc.order
+        sc.inv, sc.inv_next = sc.inv_next, sc.inv
         sc.order_valid_for = (self._ptype_gen, L_out)
         if rebuild is not None:
             rebuild(L_out)

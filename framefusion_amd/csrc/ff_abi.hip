@@ -4,8 +4,8 @@
 #include "ff_common.h"
 
 namespace ff {
-int launch_plan_merge(const void* sim, int dtype, const int32_t* order, int64_t L, double thr, double sub,
-                      double ratio_lb, uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
+int launch_plan_merge(const void* sim, int dtype, const int32_t* order, const int32_t* inv, int64_t L, double thr,
+                      double sub, double ratio_lb, uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
                       void* ws, size_t ws_bytes, bool have_tables, int64_t* host_mapped, int64_t seq,
                       hipStream_t st, long long force_k);
 int launch_plan_prune(const void* imp, int dtype, int64_t S, int64_t start, int64_t n_img, int64_t k,
@@ -20,10 +20,10 @@ int zero_tables(void* ws, size_t ws_bytes, int64_t L, hipStream_t st);
 int launch_merge_compact(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
                          const int32_t* order, const uint8_t* member, int fold, const int32_t* dst,
                          const uint8_t* keep, const ff_aux_t* aux_host, int n_aux, int32_t* order_next,
-                         int64_t* stats, hipStream_t st, bool skip_identity, void* zero_a, size_t zero_a_bytes,
-                         void* zero_b, size_t zero_b_bytes);
+                         int32_t* inv_next, int64_t* stats, hipStream_t st, bool skip_identity, void* zero_a,
+                         size_t zero_a_bytes, const void* zero_keys, int64_t zero_n, int zero_key_dt, int* t16_end);
 int launch_similarity_any(const void* hidden, int dtype, int64_t L, int64_t d, const int64_t* ptype,
-                          int32_t* order, int64_t* stats, void* sim, int* l0, int* t16_end, double thr,
+                          int32_t* order, int32_t* inv, int64_t* stats, void* sim, int* l0, int* t16_end, double thr,
                           int64_t hint_pre, int64_t hint_patches, int64_t hint_frames, hipStream_t st);
 int launch_head_mean(const void* attn_w, int dtype, int64_t H, int64_t num, int64_t S, void* importance,
                      int64_t lo, int64_t hi, int* l0, int* t16_end, hipStream_t st);
@@ -51,10 +51,10 @@ extern "C" size_t ff_workspace_bytes(int64_t L, int64_t patch_num) {
 }
 
 extern "C" int ff_merge_begin(const void* hidden, int dtype, int64_t L, int64_t d, const int64_t* patch_type,
-                              int64_t patch_num, int order_valid, double threshold, int32_t* order, void* sim,
-                              int64_t* stats, int64_t seq, int64_t hint_pre, int64_t hint_frames, void* ws,
+                              int64_t patch_num, int order_valid, double threshold, int32_t* order, int32_t* inv,
+                              void* sim, int64_t* stats, int64_t seq, int64_t hint_pre, int64_t hint_frames, void* ws,
                               size_t ws_bytes, ff_stream_t stream) {
-    if (!hidden || !patch_type || !order || !sim || !stats || !ws) return FF_ERR_ARG;
+    if (!hidden || !patch_type || !order || !inv || !sim || !stats || !ws) return FF_ERR_ARG;
     if (ws_bytes < ff_workspace_bytes(L, patch_num)) return FF_ERR_WORKSPACE;
     if (dtype != FF_F32 && dtype != FF_BF16 && dtype != FF_F16) return FF_ERR_ARG;
     const int64_t esz = dtype == FF_F32 ? 4 : 2;
@@ -64,14 +64,14 @@ extern "C" int ff_merge_begin(const void* hidden, int dtype, int64_t L, int64_t 
     const bool hinted = !order_valid && hint_frames > 0 && hint_pre >= 0 && patch_num >= 1 &&
                         hint_pre + hint_frames * patch_num <= L;
     if (!order_valid && !hinted) {
-        int rc = ff_build_order(patch_type, L, patch_num, order, stats, ws, ws_bytes, stream);
+        int rc = ff_build_order(patch_type, L, patch_num, order, inv, stats, ws, ws_bytes, stream);
         if (rc) return rc;
     }
     if (L == 0) return FF_OK;
     // the similarity kernel also accumulates the select tables of this call (zero on entry: cleared by
     // the previous call's merge kernel)
     (void)seq;
-    return ff::launch_similarity_any(hidden, dtype, L, d, patch_type, order, stats, sim, ff::ws_l0(ws),
+    return ff::launch_similarity_any(hidden, dtype, L, d, patch_type, order, inv, stats, sim, ff::ws_l0(ws),
                                      ff::ws_t16_end(ws, ws_bytes), threshold, hint_pre, patch_num,
                                      hinted ? hint_frames : 0, (hipStream_t)stream);
 }
@@ -80,10 +80,12 @@ extern "C" int ff_merge_begin(const void* hidden, int dtype, int64_t L, int64_t 
 // rounding, 2: the baseline's fp32 mean) + compaction
 static int merge_finish(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
                         double threshold, double sub, double ratio_lb, long long force_k, int fold,
-                        const int32_t* order, const void* sim, uint8_t* member, int32_t* dst, uint8_t* keep,
-                        int64_t* stats, int64_t* stats_host_mapped, int64_t seq, const ff_aux_t* aux_host, int n_aux,
-                        int32_t* order_next, void* ws, size_t ws_bytes, ff_stream_t stream) {
-    if (!hidden || !hidden_out || !order || !sim || !member || !dst || !keep || !stats || !ws) return FF_ERR_ARG;
+                        const int32_t* order, const int32_t* inv, const void* sim, uint8_t* member, int32_t* dst,
+                        uint8_t* keep, int64_t* stats, int64_t* stats_host_mapped, int64_t seq, const ff_aux_t* aux_host,
+                        int n_aux, int32_t* order_next, int32_t* inv_next, void* ws, size_t ws_bytes,
+                        ff_stream_t stream) {
+    if (!hidden || !hidden_out || !order || !inv || !sim || !member || !dst || !keep || !stats || !ws) return FF_ERR_ARG;
+    if ((order_next == nullptr) != (inv_next == nullptr)) return FF_ERR_ARG;
     if (ws_bytes < ff_workspace_bytes(L, 1)) return FF_ERR_WORKSPACE;
     if (L_cap < L) return FF_ERR_ARG;
     if (dtype != FF_F32 && dtype != FF_BF16 && dtype != FF_F16) return FF_ERR_ARG;
@@ -93,9 +95,9 @@ static int merge_finish(const void* hidden, void* hidden_out, int dtype, int64_t
     if (order_next && ((uintptr_t)member & 15)) return FF_ERR_ALIGN;
     if (L == 0) return FF_OK;
     if (((uintptr_t)member & 7) || ((uintptr_t)dst & 15) || ((uintptr_t)keep & 15) || ((uintptr_t)order & 15) ||
-        ((uintptr_t)sim & 15) || ((uintptr_t)ws & 15))
+        ((uintptr_t)sim & 15) || ((uintptr_t)ws & 15) || ((uintptr_t)inv & 15))
         return FF_ERR_ALIGN;
-    int rc = ff::launch_plan_merge(sim, dtype, order, L, threshold, sub, ratio_lb, member, dst, keep, stats, ws, ws_bytes,
+    int rc = ff::launch_plan_merge(sim, dtype, order, inv, L, threshold, sub, ratio_lb, member, dst, keep, stats, ws, ws_bytes,
                                    true, stats_host_mapped, seq, (hipStream_t)stream, force_k);
     if (rc) return rc;
     // when the select folds nothing the merge kernel exits at once: see ff_merge_finish in the header;
@@ -104,41 +106,43 @@ static int merge_finish(const void* hidden, void* hidden_out, int dtype, int64_t
     size_t zab, zbb;
     ff::table_regions(ws, ws_bytes, L, &za, &zab, &zb, &zbb);
     return ff::launch_merge_compact(hidden, hidden_out, dtype, L, d, L_cap, order, member, fold, dst, keep, aux_host,
-                                    n_aux, order_next, stats, (hipStream_t)stream, true, za, zab, zb, zbb);
+                                    n_aux, order_next, inv_next, stats, (hipStream_t)stream, true, za, zab, sim, L, dtype,
+                                    ff::ws_t16_end(ws, ws_bytes));
 }
 
 extern "C" int ff_merge_finish(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
-                               double threshold, double sub, double ratio_lb, const int32_t* order, const void* sim,
-                               uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
+                               double threshold, double sub, double ratio_lb, const int32_t* order, const int32_t* inv,
+                               const void* sim, uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
                                int64_t* stats_host_mapped, int64_t seq, const ff_aux_t* aux_host, int n_aux,
-                               int32_t* order_next, void* ws, size_t ws_bytes, ff_stream_t stream) {
-    return merge_finish(hidden, hidden_out, dtype, L, d, L_cap, threshold, sub, ratio_lb, -1, FF_FOLD_SEQUENTIAL, order, sim,
-                        member, dst, keep, stats, stats_host_mapped, seq, aux_host, n_aux, order_next, ws, ws_bytes,
-                        stream);
+                               int32_t* order_next, int32_t* inv_next, void* ws, size_t ws_bytes, ff_stream_t stream) {
+    return merge_finish(hidden, hidden_out, dtype, L, d, L_cap, threshold, sub, ratio_lb, -1, FF_FOLD_SEQUENTIAL, order, inv,
+                        sim, member, dst, keep, stats, stats_host_mapped, seq, aux_host, n_aux, order_next, inv_next, ws,
+                        ws_bytes, stream);
 }
 
 extern "C" int ff_merge_finish_topk(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d,
-                                    int64_t L_cap, int64_t k, int fold, const int32_t* order, const void* sim,
-                                    uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
+                                    int64_t L_cap, int64_t k, int fold, const int32_t* order, const int32_t* inv,
+                                    const void* sim, uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
                                     int64_t* stats_host_mapped, int64_t seq, const ff_aux_t* aux_host, int n_aux,
-                                    int32_t* order_next, void* ws, size_t ws_bytes, ff_stream_t stream) {
+                                    int32_t* order_next, int32_t* inv_next, void* ws, size_t ws_bytes,
+                                    ff_stream_t stream) {
     if (k < 0 || (fold != FF_FOLD_SEQUENTIAL && fold != FF_FOLD_MEAN)) return FF_ERR_ARG;
-    return merge_finish(hidden, hidden_out, dtype, L, d, L_cap, 0.0, 0.0, 0.0, k, fold, order, sim, member, dst, keep,
-                        stats, stats_host_mapped, seq, aux_host, n_aux, order_next, ws, ws_bytes, stream);
+    return merge_finish(hidden, hidden_out, dtype, L, d, L_cap, 0.0, 0.0, 0.0, k, fold, order, inv, sim, member, dst, keep,
+                        stats, stats_host_mapped, seq, aux_host, n_aux, order_next, inv_next, ws, ws_bytes, stream);
 }
 
 extern "C" int ff_merge_step(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
                              const int64_t* patch_type, int64_t patch_num, int order_valid, double threshold,
-                             double sub, double ratio_lb, int32_t* order, void* sim, uint8_t* member,
+                             double sub, double ratio_lb, int32_t* order, int32_t* inv, void* sim, uint8_t* member,
                              int32_t* dst, uint8_t* keep, int64_t* stats, int64_t* stats_host_mapped,
                              int64_t seq, const ff_aux_t* aux_host, int n_aux, int64_t hint_pre,
-                             int64_t hint_frames, int32_t* order_next, void* ws, size_t ws_bytes,
+                             int64_t hint_frames, int32_t* order_next, int32_t* inv_next, void* ws, size_t ws_bytes,
                              ff_stream_t stream) {
-    int rc = ff_merge_begin(hidden, dtype, L, d, patch_type, patch_num, order_valid, threshold, order, sim, stats,
+    int rc = ff_merge_begin(hidden, dtype, L, d, patch_type, patch_num, order_valid, threshold, order, inv, sim, stats,
                             seq, hint_pre, hint_frames, ws, ws_bytes, stream);
     if (rc) return rc;
-    return ff_merge_finish(hidden, hidden_out, dtype, L, d, L_cap, threshold, sub, ratio_lb, order, sim, member, dst,
-                           keep, stats, stats_host_mapped, seq, aux_host, n_aux, order_next, ws, ws_bytes, stream);
+    return ff_merge_finish(hidden, hidden_out, dtype, L, d, L_cap, threshold, sub, ratio_lb, order, inv, sim, member, dst,
+                           keep, stats, stats_host_mapped, seq, aux_host, n_aux, order_next, inv_next, ws, ws_bytes, stream);
 }
 
 extern "C" int ff_prune_step(const void* hidden, void* hidden_out, int dtype, int64_t S, int64_t d, int64_t L_cap,
@@ -173,8 +177,10 @@ extern "C" int ff_prune_step(const void* hidden, void* hidden_out, int dtype, in
     void *za = nullptr, *zb = nullptr;
     size_t zab = 0, zbb = 0;
     if (have_tables) ff::table_regions(ws, ws_bytes, S, &za, &zab, &zb, &zbb);
+    (void)zb; (void)zbb;
     const int64_t esz = dtype == FF_F32 ? 4 : 2;
     if (((uintptr_t)hidden & 15) || ((uintptr_t)hidden_out & 15) || ((d * esz) & 15)) return FF_ERR_ALIGN;
     return ff::launch_merge_compact(hidden, hidden_out, dtype, S, d, L_cap, nullptr, member, FF_FOLD_DROP, dst, keep,
-                                    aux_host, n_aux, nullptr, nullptr, st, false, za, zab, zb, zbb);
+                                    aux_host, n_aux, nullptr, nullptr, nullptr, st, false, za, zab, have_tables ? imp : nullptr,
+                                    S, w_dtype, ff::ws_t16_end(ws, ws_bytes));
 }

@@ -145,6 +145,18 @@ __device__ inline int wave_incl_scan(int v) {
     return v;
 }
 
+// Inclusive wave scan on the DPP network (row shifts + row broadcasts, gfx9 family): VALU-rate, no
+// LDS round trips - for the latency-bound index kernels, where a ds_bpermute chain costs ~0.3 us.
+__device__ inline int wave_incl_scan_dpp(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);     // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);     // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);     // row_bcast:15 -> rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);     // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+
 // Exclusive scan of one int per thread across a block of NW waves; `total` = block sum.
 // `scratch` = NW + 1 ints of LDS; safe to call back to back (two barriers inside).
 template <int NW>
@@ -179,10 +191,13 @@ constexpr int kT16Copies = 2;
 constexpr size_t kT16SliceInts = (size_t)kT16Copies * 65536;
 
 __device__ __host__ inline int* t16_slice(int* t16_end, int g) { return t16_end - (size_t)(g + 1) * kT16SliceInts; }
-// bin of the 16-bit key prefix inside a level-1 table: the two bytes swapped, so that NEIGHBOURING key
-// values (a video's similarities are a dozen adjacent bf16 values) sit 1 KiB apart - on different
-// cache lines and memory channels - instead of sharing one line whose atomics would serialise
-__device__ __host__ inline uint32_t t16_bin(uint32_t key16) { return ((key16 & 0xffu) << 8) | (key16 >> 8); }
+// bin of the 16-bit key prefix inside a level-1 table: the low byte transposed as a 16 x 16 matrix, so
+// that NEIGHBOURING key values (a video's similarities are a dozen adjacent bf16 values) sit 64 bytes
+// apart - on different cache lines - instead of sharing one line whose atomics would serialise, while
+// the 256 bins of one top byte stay one contiguous KiB for the plan kernel's row reads
+__device__ __host__ inline uint32_t t16_bin(uint32_t key16) {
+    return (key16 & 0xff00u) | ((key16 & 15u) << 4) | ((key16 >> 4) & 15u);
+}
 
 // table[idx] += 1 for every lane with `valid`.  Lanes that hold the same idx are folded into ONE
 // non-returning atomic for the first kIters distinct values (video similarities take a dozen distinct

@@ -69,20 +69,35 @@ struct Batch {
     bool last;
 };
 
-// Select tables to clear for the next call (ff_plan.hip): two byte ranges, multiples of 16.
+// Select tables to clear for the next call (ff_plan.hip).  The level-0 table (a few KB) is cleared as a
+// byte range; the per-slice level-1 tables are megabytes of which a few hundred bins are non-zero, so
+// they are cleared BY KEY: every value that was counted names its bin (streaming zeros over the whole
+// table inside this kernel cost 8 us at 64 x 576 - measured).
 struct ZeroJob {
-    uint4* a; uint4* b;
-    long long a_n16, b_n16;
+    uint4* a;                 // level-0 table
+    int a_n16;
+    const void* keys;         // the values the producer counted (n of them, dtype key_dt), or NULL
+    int n, key_dt;
+    int* t16_end;
     int n_blocks;
 };
+
+template <int KDT>
+__device__ inline void zero_by_key(const ZeroJob& z, int t) {
+    using K = Act<KDT>;
+    const uint32_t bin = t16_bin(order_key<KDT>(K::bits1(z.keys, t)) >> (K::kKeyBits - 16));
+    int* tab = t16_slice(z.t16_end, t / kSelSlice) + bin;
+#pragma unroll
+    for (int x = 0; x < kT16Copies; ++x) tab[x * 65536] = 0;
+}
 
 template <int DT>
 __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
     const char* __restrict__ hidden, char* __restrict__ out, uint32_t row_bytes, int L, int64_t L_cap,
     const int32_t* __restrict__ order, const uint8_t* __restrict__ member, int fold,
     const int32_t* __restrict__ dst, const uint8_t* __restrict__ keep, AuxPack aux, int n_main,
-    int n_aux_blocks, int n_next_blocks, int32_t* __restrict__ order_next, int64_t* __restrict__ stats,
-    const int64_t* __restrict__ identity_stats, ZeroJob zero) {
+    int n_aux_blocks, int n_next_blocks, int32_t* __restrict__ order_next, int32_t* __restrict__ inv_next,
+    int64_t* __restrict__ stats, const int64_t* __restrict__ identity_stats, ZeroJob zero) {
     using A = Act<DT>;
     constexpr int E = A::kPer16;
     constexpr int kDepth = 4;                     // row pieces requested per batch (two batches in flight)
@@ -92,13 +107,16 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
         // ---- the select tables of this call have been consumed by the plan kernel: clear them for the
         // next call's producer (runs even when nothing is folded)
         if (blockIdx.y != 0) return;
-        const long long total = zero.a_n16 + zero.b_n16;
-        const long long per = (total + zero.n_blocks - 1) / zero.n_blocks;
-        const long long z0 = ((long long)blockIdx.x - n_main - n_aux_blocks - n_next_blocks) * per;
-        const long long z1 = min(z0 + per, total);
-        for (long long z = z0 + threadIdx.x; z < z1; z += kMergeThreads) {
-            uint4* p = z < zero.a_n16 ? zero.a + z : zero.b + (z - zero.a_n16);
-            *p = make_uint4(0, 0, 0, 0);
+        const int zb = (int)blockIdx.x - n_main - n_aux_blocks - n_next_blocks;
+        if (zb == 0)
+            for (int z = threadIdx.x; z < zero.a_n16; z += kMergeThreads) zero.a[z] = make_uint4(0, 0, 0, 0);
+        if (zero.keys) {
+            const int t0 = (zb * kMergeThreads + threadIdx.x) * 16;
+            for (int t = t0; t < min(t0 + 16, zero.n); ++t) {
+                if (zero.key_dt == FF_BF16) zero_by_key<FF_BF16>(zero, t);
+                else if (zero.key_dt == FF_F16) zero_by_key<FF_F16>(zero, t);
+                else zero_by_key<FF_F32>(zero, t);
+            }
         }
         return;
     }
@@ -127,7 +145,12 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
         int total;
         int pos = before + block_excl_scan<kMergeWaves>(__popc(nonmem), scratch, total);
         for (int e = 0; e < n_here; ++e) {
-            if ((nonmem >> e) & 1u) order_next[pos++] = dst[order[s0 + e]];
+            if ((nonmem >> e) & 1u) {
+                const int np = dst[order[s0 + e]];      // the slot's position in the compacted sequence
+                order_next[pos] = np;
+                if (inv_next) inv_next[np] = pos;
+                ++pos;
+            }
         }
         if (base + kMergeThreads * 16 >= L && tid == 0) {
             const int64_t merged = stats[FF_STAT_MERGED];
@@ -287,8 +310,8 @@ __global__ __launch_bounds__(256) void k_gather_mask(const char* __restrict__ ma
 int launch_merge_compact(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
                          const int32_t* order, const uint8_t* member, int fold, const int32_t* dst,
                          const uint8_t* keep, const ff_aux_t* aux_host, int n_aux, int32_t* order_next,
-                         int64_t* stats, hipStream_t st, bool skip_identity, void* zero_a, size_t zero_a_bytes,
-                         void* zero_b, size_t zero_b_bytes) {
+                         int32_t* inv_next, int64_t* stats, hipStream_t st, bool skip_identity, void* zero_a,
+                         size_t zero_a_bytes, const void* zero_keys, int64_t zero_n, int zero_key_dt, int* t16_end) {
     AuxPack pack;
     pack.n = keep ? n_aux : 0;
     for (int x = 0; x < pack.n; ++x) pack.a[x] = aux_host[x];
@@ -299,9 +322,8 @@ int launch_merge_compact(const void* hidden, void* hidden_out, int dtype, int64_
     const int n_aux_blocks = pack.n ? (int)((L + kMergeWaves * 4 - 1) / (kMergeWaves * 4)) : 0;
     if (!order || !stats) order_next = nullptr;
     const int n_next_blocks = order_next ? (int)((L + kMergeThreads * 16 - 1) / (kMergeThreads * 16)) : 0;
-    ZeroJob zero{(uint4*)zero_a, (uint4*)zero_b, (long long)(zero_a_bytes / 16), (long long)(zero_b_bytes / 16), 0};
-    const long long z16 = zero.a_n16 + zero.b_n16;
-    if (z16 > 0) zero.n_blocks = (int)min((long long)256, (z16 + kMergeThreads * 16 - 1) / (kMergeThreads * 16));
+    ZeroJob zero{(uint4*)zero_a, (int)(zero_a_bytes / 16), zero_keys, (int)zero_n, zero_key_dt, t16_end, 0};
+    if (zero_a) zero.n_blocks = zero_keys ? (int)((zero_n + kMergeThreads * 16 - 1) / (kMergeThreads * 16)) : 1;
     const dim3 grid((unsigned)(n_main + n_aux_blocks + n_next_blocks + zero.n_blocks),
                     (unsigned)((nblk + kMergeWaves - 1) / kMergeWaves));
     const char* h = (const char*)hidden;
@@ -309,8 +331,8 @@ int launch_merge_compact(const void* hidden, void* hidden_out, int dtype, int64_
     const int64_t* ident = (skip_identity && stats) ? stats : nullptr;
 #define FF_MC_LAUNCH(DT)                                                                                               \
     hipLaunchKernelGGL((k_merge_compact<DT>), grid, dim3(kMergeThreads), 0, st, h, o, (uint32_t)row_bytes, (int)L, L_cap, \
-                       order, member, fold, dst, keep, pack, n_main, n_aux_blocks, n_next_blocks, order_next, stats, ident, \
-                       zero)
+                       order, member, fold, dst, keep, pack, n_main, n_aux_blocks, n_next_blocks, order_next, inv_next, stats, \
+                       ident, zero)
     switch (dtype) {
         case FF_F32: FF_MC_LAUNCH(FF_F32); break;
         case FF_BF16: FF_MC_LAUNCH(FF_BF16); break;
@@ -339,8 +361,8 @@ extern "C" int ff_merge_compact(const void* hidden, void* hidden_out, int dtype,
     if (L >= (1ll << 29) || d * esz >= (1ll << 31)) return FF_ERR_UNSUPPORTED;
     if (L == 0) return FF_OK;
     return ff::launch_merge_compact(hidden, hidden_out, dtype, L, d, L_cap, order, member, fold, dst, keep, aux_host, n_aux,
-                                    nullptr, nullptr,
-                                    (hipStream_t)stream, false, nullptr, 0, nullptr, 0);
+                                    nullptr, nullptr, nullptr,
+                                    (hipStream_t)stream, false, nullptr, 0, nullptr, 0, 0, nullptr);
 }
 
 extern "C" int ff_gather_mask(const void* mask, void* out, int64_t elem_bytes, int64_t L, int64_t L_cap,

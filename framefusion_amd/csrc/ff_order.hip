@@ -25,7 +25,7 @@ __device__ inline int bin_of(int64_t t, int P) { return (t >= 0 && t < P) ? (int
 
 // One 64-token step of the stable placement for wave-private histogram row `my`.
 __device__ inline void place_step(int* my, int key, bool valid, int i, int32_t* __restrict__ order,
-                                  unsigned long long lt_mask) {
+                                  int32_t* __restrict__ inv, unsigned long long lt_mask) {
     int pre = 0, slot = 0;
     if (valid) pre = my[key];
     __builtin_amdgcn_wave_barrier();
@@ -40,7 +40,10 @@ __device__ inline void place_step(int* my, int key, bool valid, int i, int32_t* 
         if (valid && key == k) slot = pre + __popcll(same & lt_mask);
         todo &= ~same;
     }
-    if (valid) order[slot] = i;
+    if (valid) {
+        order[slot] = i;
+        if (inv) inv[i] = slot;
+    }
 }
 
 // ---- pass 1: per-slice facts about patch_type (many workgroups, 4096 positions each) ---------------
@@ -126,7 +129,8 @@ __global__ __launch_bounds__(kStatThreads) void k_order_stats(const int64_t* __r
 template <bool kKeysInLds>
 __global__ __launch_bounds__(kOrderThreads) void k_build_order(
     const int64_t* __restrict__ ptype, int L, int P, int n_seg, int seg_len,
-    int32_t* __restrict__ order, int64_t* __restrict__ stats, const OrderRow* __restrict__ rows, int n_rows) {
+    int32_t* __restrict__ order, int32_t* __restrict__ inv, int64_t* __restrict__ stats,
+    const OrderRow* __restrict__ rows, int n_rows) {
     extern __shared__ __attribute__((aligned(16))) int lds[];
     const int bins = P + 1;
     int* hist = lds;                       // [n_seg][bins]
@@ -203,9 +207,17 @@ __global__ __launch_bounds__(kOrderThreads) void k_build_order(
                     for (int e = 0; e < 16; ++e)
                         if (j0 + e < nv) order[j0 + e] = v[e];
                 }
+                if (inv) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if (j0 + e < nv) inv[v[e]] = j0 + e;
+                }
             }
-            for (int q = blockIdx.x * kOrderThreads + tid; q < L - nv; q += gridDim.x * kOrderThreads)
-                order[nv + q] = q < pre ? q : q + nv;
+            for (int q = blockIdx.x * kOrderThreads + tid; q < L - nv; q += gridDim.x * kOrderThreads) {
+                const int i = q < pre ? q : q + nv;
+                order[nv + q] = i;
+                if (inv) inv[i] = nv + q;
+            }
             if (blockIdx.x == 0 && tid == 0) {
                 stats[FF_STAT_NV] = nv;
                 stats[FF_STAT_FTN] = misc[0];
@@ -289,7 +301,7 @@ __global__ __launch_bounds__(kOrderThreads) void k_build_order(
             for (int i0 = seg_lo; i0 < seg_hi; i0 += kWave) {
                 const int i = i0 + lane;
                 const bool valid = i < seg_hi;
-                place_step(my, valid ? (int)keys[i] : -1, valid, i, order, lt_mask);
+                place_step(my, valid ? (int)keys[i] : -1, valid, i, order, inv, lt_mask);
             }
         } else {
             for (int i0 = seg_lo; i0 < seg_hi; i0 += 8 * kWave) {
@@ -302,7 +314,7 @@ __global__ __launch_bounds__(kOrderThreads) void k_build_order(
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int i = i0 + u * kWave + lane;
-                    if (i0 + u * kWave < seg_hi) place_step(my, bin_of(t[u], P), i < seg_hi, i, order, lt_mask);
+                    if (i0 + u * kWave < seg_hi) place_step(my, bin_of(t[u], P), i < seg_hi, i, order, inv, lt_mask);
                 }
             }
         }
@@ -316,7 +328,7 @@ __global__ __launch_bounds__(kOrderThreads) void k_build_order(
 }  // namespace ff
 
 extern "C" int ff_build_order(const int64_t* patch_type, int64_t L, int64_t patch_num, int32_t* order,
-                              int64_t* stats, void* ws, size_t ws_bytes, ff_stream_t stream) {
+                              int32_t* inv, int64_t* stats, void* ws, size_t ws_bytes, ff_stream_t stream) {
     if (!patch_type || !order || !stats || !ws || L < 0 || patch_num < 1) return FF_ERR_ARG;
     if (ws_bytes < ff::plan_ws_front_bytes(L) + ((size_t)(L / ff::kStatSpan) + 1) * sizeof(ff::OrderRow)) return FF_ERR_WORKSPACE;
     if (((uintptr_t)patch_type & 15) || ((uintptr_t)order & 15) || ((uintptr_t)ws & 15)) return FF_ERR_ALIGN;
@@ -356,9 +368,9 @@ extern "C" int ff_build_order(const int64_t* patch_type, int64_t L, int64_t patc
     const unsigned nb = (unsigned)((L + ff::kOrderThreads * 16 - 1) / (ff::kOrderThreads * 16));
     if (in_regs)
         hipLaunchKernelGGL(ff::k_build_order<true>, dim3(nb), dim3(ff::kOrderThreads), lds, (hipStream_t)stream,
-                           patch_type, (int)L, (int)patch_num, n_seg, seg_len, order, stats, rows, n_rows);
+                           patch_type, (int)L, (int)patch_num, n_seg, seg_len, order, inv, stats, rows, n_rows);
     else
         hipLaunchKernelGGL(ff::k_build_order<false>, dim3(nb), dim3(ff::kOrderThreads), lds, (hipStream_t)stream,
-                           patch_type, (int)L, (int)patch_num, n_seg, seg_len, order, stats, rows, n_rows);
+                           patch_type, (int)L, (int)patch_num, n_seg, seg_len, order, inv, stats, rows, n_rows);
     return (int)hipGetLastError();
 }

@@ -316,27 +316,35 @@ __device__ inline void publish(int64_t* __restrict__ stats, int64_t* host_mapped
 }
 
 // ---- k_plan ---------------------------------------------------------------------------------------
-// Workgroup g owns by-patch slots AND sequence positions [4096 g, 4096 g + 4096).
-// mode 0 (merge): slot t of `order` (visual slots [0, nv), then the non-visual tail) is folded iff it is
-//   selected and t > 0 (slot 0 has no predecessor: the reference would wrap to order[-1],
-//   main.py:290; reachable only when top-k exceeds the number of valid pairs);
-// mode 1 (prune): order = identity, position i in [lo, hi) is DROPPED iff it is not selected.
+// Workgroup g owns by-patch slots AND sequence positions [4096 g, 4096 g + 4096), 4 of each per thread.
+// mode 0 (merge): slot t of the by-patch order (visual slots [0, nv), then the non-visual tail) is folded
+//   iff it is selected and t > 0 (slot 0 has no predecessor: the reference would wrap to order[-1],
+//   main.py:290; reachable only when top-k exceeds the number of valid pairs).  `inv` is the inverse
+//   of the by-patch order (slot of every sequence position), maintained next to `order` by its
+//   producers (K0, the hinted similarity kernel, the merge kernel's next-order blocks);
+// mode 1 (prune): identity order (inv = NULL), position i in [lo, hi) is DROPPED iff it is not selected.
 //
 // Latency structure: the kernel is a chain of dependent steps on a cold chip (its predecessor streamed
 // hundreds of MB), so every load that does not depend on the decision is issued in the FIRST round:
-// the values and order[] of up to kRegChunks x 8192 slots (8 consecutive slots per thread per chunk,
-// kept in registers), the level-0 tables, and - speculatively - the level-1 rows of the top byte the
-// k-th key is expected to have (pp.p0_guess: the threshold's; a wrong guess costs one more round
-// trip).  Wave 0 then resolves the levels from LDS, the tie slot t* comes out of the registers, and
-// the single pass over the slots classifies what the registers already hold.
+// the level-0 tables, - speculatively - the level-1 rows of the top byte the k-th key is expected
+// to have (pp.p0_guess: the threshold's; a wrong guess costs one more round trip), inv[] of my
+// positions, and ALL values (8 consecutive slots per thread per chunk, up to kRegChunks x 8192
+// slots kept in registers: the tie slot t* then comes out of registers, whatever slice it is in).
+// Wave 0 resolves the levels from LDS.  Each workgroup classifies only its own 4096 slots (member
+// flags) and 4096 positions (keep flags, values gathered through inv[]); the number of kept positions
+// BEFORE its range comes from the other workgroups' totals: every workgroup publishes its own total
+// as ONE 8-byte {tag, count} granule (agent-scope store, the data is the flag) and sums the granules
+// of its predecessors - all workgroups publish at about the same time, so this is one hop, not a
+// chain.  The tag is a per-workspace launch counter kept on the device (graph-replay safe).
 constexpr int kRegChunks = 5;               // 40 960 slots in registers; longer sequences load the rest on the fly
 constexpr int kChunkStride = kPlanThreads * 8;
 constexpr int kRowSlicesLds = 16;           // level-1 rows kept in LDS for the tie-slice search (else re-read)
+constexpr int kMaxPlanGroups = 240;         // every workgroup must be resident (one per CU): L < 983 040
+static_assert(65536 / 1024 <= 64, "k_plan_fast polls its predecessors in one pass of 64 lanes");
 
 struct PlanLds {
     SelLds<kPlanThreads> sel;
     int rows[kRowSlicesLds][256];
-    uint32_t keep[kSelSlice / 4];          // keep flags of my positions, one byte each
 };
 
 template <int DT>
@@ -354,53 +362,88 @@ __device__ inline void chunk_keys(const uint4* kw, uint32_t* key) {
     }
 }
 
-// positions and raw values of the 8 slots [t0, t0 + 8): raw buffer loads (range-checked per dword:
-// whatever lies beyond the arrays reads 0), so the loads of all chunks are straight-line code and
-// go out back to back; slots >= L are masked where they are used
+// An odd number of 2-byte values ends in the middle of a dword, which the range check of the buffer
+// loads zeroes as a whole: the last value is loaded on its own (by every thread: a broadcast) and
+// patched into the chunk that holds it.
 template <int DT>
-__device__ inline void load_chunk(__amdgpu_buffer_rsrc_t values, __amdgpu_buffer_rsrc_t order, bool has_order, int t0,
-                                  uint4* po, uint4* kw) {
+__device__ inline void patch_last(uint32_t* key, int t0, int cap, uint32_t last_key) {
+    if constexpr (Act<DT>::kBytes == 2) {
+        if (cap & 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (t0 + e == cap - 1) key[e] = last_key;
+        }
+    }
+}
+
+// raw values of the 8 slots [t0, t0 + 8): raw buffer loads (range-checked per dword: whatever lies
+// beyond the array reads 0), so the loads of all chunks are straight-line code and go out back to back
+template <int DT>
+__device__ inline void load_chunk(__amdgpu_buffer_rsrc_t values, int t0, uint4* kw) {
     constexpr int KW = Act<DT>::kBytes == 2 ? 1 : 2;
-    // (no order: the resource is empty and the loads return 0; the identity is substituted where the
-    // positions are USED - a select here would make the compiler wait for the loads at this point)
-    (void)has_order;
-    po[0] = buf_load16(order, (uint32_t)t0 * 4u);
-    po[1] = buf_load16(order, (uint32_t)t0 * 4u + 16u);
 #pragma unroll
     for (int x = 0; x < KW; ++x) kw[x] = buf_load16(values, (uint32_t)t0 * (uint32_t)Act<DT>::kBytes + 16u * x);
 }
 
-template <int DT>
+// wave 0: the bin, from the top, in which the running count over tot[q][*] reaches `rem`
+template <int NQ>
+__device__ inline void wave_pick(const int (*part)[256], int lane, int rem, int& bin_out, int& above_out) {
+    const int top = 255 - 4 * lane;
+    int v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v[e] = 0;
+#pragma unroll
+        for (int x = 0; x < NQ; ++x) v[e] += part[x][top - e];
+    }
+    const int sum = v[0] + v[1] + v[2] + v[3];
+    const int incl = wave_incl_scan(sum);
+    const int first = __ffsll((long long)__ballot(incl >= rem)) - 1;
+    int ab = incl - sum, bin = top;
+    if (ab + v[0] >= rem) { bin = top; }
+    else if (ab + v[0] + v[1] >= rem) { ab += v[0]; bin = top - 1; }
+    else if (ab + v[0] + v[1] + v[2] >= rem) { ab += v[0] + v[1]; bin = top - 2; }
+    else { ab += v[0] + v[1] + v[2]; bin = top - 3; }
+    bin_out = __builtin_amdgcn_readlane(bin, first);
+    above_out = __builtin_amdgcn_readlane(ab, first);
+}
+
+// kFast: 16-bit keys, at most kRowSlicesLds slices, every value chunk in registers (L <= kRegChunks x 8192):
+// the common case gets a kernel without the general paths - this kernel starts with a cold
+// instruction cache (its predecessor streamed hundreds of MB through every L2), and what it costs is
+// mostly the number of instruction lines it walks through.
+template <int DT, bool kFast>
 __global__ __launch_bounds__(kPlanThreads) void k_plan(
     const void* __restrict__ values, int cap, PlanParams pp, const int* __restrict__ l0, int* t16_end,
-    const int* __restrict__ lv, int64_t* __restrict__ stats, const int32_t* __restrict__ order, int L,
+    const int* __restrict__ lv, int64_t* __restrict__ stats, const int32_t* __restrict__ inv, int L,
     uint8_t* __restrict__ member, uint8_t* __restrict__ keep, int32_t* __restrict__ dst,
-    int64_t* host_mapped, int64_t seq) {
+    unsigned long long* agg, uint32_t* tagword, int64_t* host_mapped, int64_t seq) {
     using A = Act<DT>;
     constexpr int kLevels = A::kKeyBits / 8;
     constexpr int KW = A::kBytes == 2 ? 1 : 2;
     constexpr int NW = kPlanThreads / kWave;
     constexpr int NQ = kPlanThreads / 256;
     constexpr int kSpec = 3;                      // speculative level-1 slices per thread (12 slices = 49 152 values)
+    static_assert(!kFast || kLevels == 2, "the fast variant resolves exactly two radix levels");
     __shared__ PlanLds s;
     const int tid = threadIdx.x, lane = lane_id(), c = tid & 255, q = tid >> 8;
     const int base = blockIdx.x * kSelSlice;
-    const bool fast = kLevels == 2 && pp.n_slices <= kRowSlicesLds;
-    // phase stamps of the last workgroup (100 MHz steady counter), published in stats[FF_STAT_T_PLAN ..]
+#ifdef FF_PLAN_PROBE
     long long stamp[6];
     stamp[0] = wall_clock64();
+#endif
 
     // ---- round 1: everything that does not depend on the decision; the small tables first (loads
-    // return in order: the first barrier then only waits for them, not for the slot chunks)
+    // return in order: the first barrier then only waits for them, not for the value chunks).  Raw
+    // values only: any arithmetic on them here would make the compiler wait before the later loads
+    // are even issued.
     const long long nv_raw = stats[FF_STAT_NV];
     const long long ftn = stats[FF_STAT_FTN];
-    // (raw values only: any arithmetic on them here would make the compiler wait before the chunk
-    // loads below are even issued)
     int l0v[kL0Copies / NQ], specv[kSpec][kT16Copies];
 #pragma unroll
     for (int x = 0; x < kL0Copies / NQ; ++x) l0v[x] = l0[(q + x * NQ) * kL0Stride + c];
     const int l0cnt_raw = l0[(tid & (kL0Copies - 1)) * kL0Stride + 256];
-    if (fast) {
+    if constexpr (kFast) {
 #pragma unroll
         for (int j = 0; j < kSpec; ++j) {
             const int g = min(q + j * NQ, pp.n_slices - 1);          // (clamped: the value is only used for g < n_slices)
@@ -409,144 +452,138 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan(
             for (int x = 0; x < kT16Copies; ++x) specv[j][x] = row[x * 65536];
         }
     }
+    const uint32_t tag_prev = *tagword;
+    const int i0 = base + tid * 4;                // my positions
+    const __amdgpu_buffer_rsrc_t inv_rsrc = make_rsrc(inv ? (const void*)inv : values, inv ? (uint32_t)L * 4u : 0u);
+    const uint4 inv4 = buf_load16(inv_rsrc, (uint32_t)i0 * 4u);
+    const uint32_t last_bits = A::bits1(values, max(cap - 1, 0));
     __builtin_amdgcn_sched_barrier(0);            // the table loads stay AHEAD of the chunk loads in issue order
     const __amdgpu_buffer_rsrc_t val_rsrc = make_rsrc(values, (uint32_t)cap * (uint32_t)A::kBytes);
-    const __amdgpu_buffer_rsrc_t ord_rsrc = make_rsrc(order ? (const void*)order : values, order ? (uint32_t)L * 4u : 0u);
-    const bool has_order = order != nullptr;
-    uint4 po[kRegChunks][2], kw[kRegChunks][KW];
+    uint4 kw[kRegChunks][KW];
 #pragma unroll
-    for (int x = 0; x < kRegChunks; ++x) load_chunk<DT>(val_rsrc, ord_rsrc, has_order, tid * 8 + x * kChunkStride, po[x], kw[x]);
+    for (int x = 0; x < kRegChunks; ++x) load_chunk<DT>(val_rsrc, tid * 8 + x * kChunkStride, kw[x]);
     __builtin_amdgcn_sched_barrier(0);
-    const long long stamp_issued = wall_clock64();          // all round-1 loads issued, none awaited
+    // the values of my positions' slots: one dependent gather, in flight while the levels are resolved
+    int pslot[4] = {(int)inv4.x, (int)inv4.y, (int)inv4.z, (int)inv4.w};
+    if (!inv) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pslot[e] = i0 + e;
+    }
+    uint32_t pbits[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pbits[e] = A::bits1(values, min(max(pslot[e], 0), cap - 1));
     __builtin_amdgcn_sched_barrier(0);
     const int nv = pp.mode == 0 ? (int)nv_raw : L;
     const int lo = pp.mode == 0 ? 0 : pp.lo, hi = pp.mode == 0 ? nv : pp.hi;
-    for (int x = tid; x < kSelSlice / 4; x += kPlanThreads) s.keep[x] = 0;
-    int l0part = 0;
+    const uint32_t last_key = order_key<DT>(last_bits);
+
+    // the 8 keys of register chunk x (wave-uniform x): select the raw words, extract once
+    auto keys_of_chunk = [&](int x, int t0, uint32_t* key) {
+        uint4 sel[KW];
 #pragma unroll
-    for (int x = 0; x < kL0Copies / NQ; ++x) l0part += l0v[x];
-    const int l0cnt = tid < kL0Copies ? l0cnt_raw : 0;
-    int spec[kSpec] = {0, 0, 0};
-    if (fast) {
+        for (int w = 0; w < KW; ++w) sel[w] = kw[0][w];
 #pragma unroll
-        for (int j = 0; j < kSpec; ++j)
+        for (int y = 1; y < kRegChunks; ++y)
+            if (x == y) {
 #pragma unroll
-            for (int x = 0; x < kT16Copies; ++x) spec[j] += specv[j][x];
-    }
+                for (int w = 0; w < KW; ++w) sel[w] = kw[y][w];
+            }
+        if constexpr (!kFast) {
+            if (x >= kRegChunks) load_chunk<DT>(val_rsrc, t0, sel);
+        }
+        chunk_keys<DT>(sel, key);
+        patch_last<DT>(key, t0, cap, last_key);
+    };
 
     // ---- decision + k-th key -------------------------------------------------------------------------
     Resolved r;
     int sl = 0, want = 0;                         // the want-th (1-based) entry equal to kth inside slice sl is the last one taken
-    stamp[1] = stamp[0];
-    if (fast) {
-        // bcast: [0] topk, [1] count, [2] k (clamped, fits an int), [3] p0, [4] remaining after level 0
-        s.sel.part[q][c] = l0part;
-        if (tid < kL0Copies) s.sel.scratch[tid] = l0cnt;
-        __syncthreads();
-        stamp[1] = wall_clock64();
-        if (tid < kWave) {
-            int cnt = lane < kL0Copies ? s.sel.scratch[lane] : 0;
-            cnt = wave_sum_i(cnt);
-            bool topk;
-            long long k;
-            if (pp.mode == 0 && pp.k_given >= 0) {
-                topk = true;                                  // fixed-sparsity policy (modeling_qwen2_baseline.py:920,1001)
-                k = pp.k_given > nv ? (long long)nv : pp.k_given;
-            } else if (pp.mode == 0) {
-                // main.py:114-116 in double, as python: ratio = count / ftn ; ratio < sub ?
-                const double ratio = ftn > 0 ? (double)cnt / (double)ftn : 0.0;
-                topk = !(ratio < pp.sub);
-                k = 0;
-                if (topk) {
-                    k = (long long)(pp.sub * (double)ftn);   // int(sub * ftn), main.py:122
-                    if (k > nv) k = nv;
-                    if (k < 0) k = 0;
-                }
-            } else {
-                topk = true;
-                k = pp.k_given;
-            }
-            int p0 = 0, rem = (int)k;
-            if (topk && k > 0) {
-                const int top = 255 - 4 * lane;
-                int v[4];
+    if constexpr (kFast) {
+        // two rounds (radix levels 0 and 1), each: every thread drops its partial column sum into LDS,
+        // wave 0 picks the bin.  bcast: [0] topk, [1] count, [2] k, [3] prefix so far, [4] remaining,
+        // [5] tie slice, [6] want
+        int colsum = 0;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = 0;
-#pragma unroll
-                    for (int x = 0; x < NQ; ++x) v[e] += s.sel.part[x][top - e];
-                }
-                const int sum = v[0] + v[1] + v[2] + v[3];
-                const int incl = wave_incl_scan(sum);
-                const int first = __ffsll((long long)__ballot(incl >= rem)) - 1;
-                int ab = incl - sum, bin = top;
-                if (ab + v[0] >= rem) { bin = top; }
-                else if (ab + v[0] + v[1] >= rem) { ab += v[0]; bin = top - 1; }
-                else if (ab + v[0] + v[1] + v[2] >= rem) { ab += v[0] + v[1]; bin = top - 2; }
-                else { ab += v[0] + v[1] + v[2]; bin = top - 3; }
-                p0 = __builtin_amdgcn_readlane(bin, first);
-                rem -= __builtin_amdgcn_readlane(ab, first);
-            }
-            if (lane == 0) {
-                s.sel.bcast[0] = topk ? 1 : 0; s.sel.bcast[1] = cnt; s.sel.bcast[2] = (int)k; s.sel.bcast[3] = p0; s.sel.bcast[4] = rem;
-            }
-        }
-        __syncthreads();
-        r.topk = s.sel.bcast[0] != 0; r.count = s.sel.bcast[1]; r.k = s.sel.bcast[2];
-        const int p0 = s.sel.bcast[3];
-        r.prefix = 0; r.remaining = 0;
-        if (r.topk && r.k > 0) {
-            // level-1 rows of p0: the speculated ones if the guess was right
-            int a = 0;
-            for (int g = q, j = 0; g < pp.n_slices; g += NQ, ++j) {
-                int v = 0;
-                if (j < kSpec && p0 == pp.p0_guess) {
-                    v = j == 0 ? spec[0] : (j == 1 ? spec[1] : spec[2]);
-                } else {
-                    const int* row = t16_slice(t16_end, g) + t16_bin(((uint32_t)p0 << 8) | (uint32_t)c);
-#pragma unroll
-                    for (int x = 0; x < kT16Copies; ++x) v += row[x * 65536];
-                }
-                s.rows[g][c] = v;
-                a += v;
-            }
-            s.sel.part[q][c] = a;
+        for (int x = 0; x < kL0Copies / NQ; ++x) colsum += l0v[x];
+        if (tid < kL0Copies) s.sel.scratch[tid] = l0cnt_raw;
+        r.topk = false; r.k = 0; r.count = 0; r.prefix = 0; r.remaining = 0;
+#pragma unroll 1
+        for (int level = 0; level < 2; ++level) {
+            s.sel.part[q][c] = colsum;
             __syncthreads();
             if (tid < kWave) {
-                int rem = s.sel.bcast[4];
-                const int top = 255 - 4 * lane;
-                int v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = 0;
-#pragma unroll
-                    for (int x = 0; x < NQ; ++x) v[e] += s.sel.part[x][top - e];
+                int rem, prefix = 0;
+                bool go;
+                if (level == 0) {
+                    int cnt = lane < kL0Copies ? s.sel.scratch[lane] : 0;
+                    cnt = wave_sum_i(cnt);
+                    bool topk;
+                    long long k;
+                    if (pp.mode == 0 && pp.k_given >= 0) {
+                        topk = true;                              // fixed-sparsity policy (modeling_qwen2_baseline.py:920,1001)
+                        k = pp.k_given > nv ? (long long)nv : pp.k_given;
+                    } else if (pp.mode == 0) {
+                        // main.py:114-116 in double, as python: ratio = count / ftn ; ratio < sub ?
+                        const double ratio = ftn > 0 ? (double)cnt / (double)ftn : 0.0;
+                        topk = !(ratio < pp.sub);
+                        k = 0;
+                        if (topk) {
+                            k = (long long)(pp.sub * (double)ftn);   // int(sub * ftn), main.py:122
+                            if (k > nv) k = nv;
+                            if (k < 0) k = 0;
+                        }
+                    } else {
+                        topk = true;
+                        k = pp.k_given;
+                    }
+                    if (lane == 0) { s.sel.bcast[0] = topk ? 1 : 0; s.sel.bcast[1] = cnt; s.sel.bcast[2] = (int)k; }
+                    rem = (int)k;
+                    go = topk && k > 0;
+                } else {
+                    rem = s.sel.bcast[4];
+                    prefix = s.sel.bcast[3];
+                    go = true;
                 }
-                const int sum = v[0] + v[1] + v[2] + v[3];
-                const int incl = wave_incl_scan(sum);
-                const int first = __ffsll((long long)__ballot(incl >= rem)) - 1;
-                int ab = incl - sum, bin = top;
-                if (ab + v[0] >= rem) { bin = top; }
-                else if (ab + v[0] + v[1] >= rem) { ab += v[0]; bin = top - 1; }
-                else if (ab + v[0] + v[1] + v[2] >= rem) { ab += v[0] + v[1]; bin = top - 2; }
-                else { ab += v[0] + v[1] + v[2]; bin = top - 3; }
-                const int p1 = __builtin_amdgcn_readlane(bin, first);
-                rem -= __builtin_amdgcn_readlane(ab, first);
-                // the slice that holds the rem-th entry equal to the k-th key (entries per slice = rows[g][p1])
-                const int ties = lane < pp.n_slices ? s.rows[lane][p1] : 0;
-                const int tincl = wave_incl_scan(ties);
-                const int hit = __ffsll((long long)__ballot(tincl >= rem)) - 1;
-                const int before_hit = __builtin_amdgcn_readlane(tincl - ties, hit);
-                if (lane == 0) {
-                    s.sel.bcast[5] = (p0 << 8) | p1; s.sel.bcast[6] = rem; s.sel.bcast[7] = hit;
-                    s.sel.bcast[4] = rem - before_hit;
+                int bin = 0, above = 0;
+                if (go) wave_pick<NQ>(s.sel.part, lane, rem, bin, above);
+                rem -= above;
+                prefix = (prefix << 8) | bin;
+                if (level == 1) {
+                    // the slice that holds the rem-th entry equal to the k-th key (entries per slice = rows[g][bin])
+                    const int ties = lane < pp.n_slices ? s.rows[lane][bin] : 0;
+                    const int tincl = wave_incl_scan(ties);
+                    const int hit = __ffsll((long long)__ballot(tincl >= rem)) - 1;
+                    const int before_hit = __builtin_amdgcn_readlane(tincl - ties, hit);
+                    if (lane == 0) { s.sel.bcast[5] = hit; s.sel.bcast[6] = rem - before_hit; }
                 }
+                if (lane == 0) { s.sel.bcast[3] = prefix; s.sel.bcast[4] = rem; }
             }
             __syncthreads();
-            r.prefix = (uint32_t)s.sel.bcast[5];
-            r.remaining = s.sel.bcast[6];
-            sl = s.sel.bcast[7];
-            want = s.sel.bcast[4];
+            if (level == 0) {
+                r.topk = s.sel.bcast[0] != 0; r.count = s.sel.bcast[1]; r.k = s.sel.bcast[2];
+                if (!(r.topk && r.k > 0)) break;                    // (uniform)
+                // level-1 rows of the level-0 bin: the speculated ones if the guess was right
+                const int p0 = s.sel.bcast[3];
+                colsum = 0;
+                for (int g = q, j = 0; g < pp.n_slices; g += NQ, ++j) {
+                    int v = 0;
+                    if (j < kSpec && p0 == pp.p0_guess) {
+#pragma unroll
+                        for (int x = 0; x < kT16Copies; ++x) v += j == 0 ? specv[0][x] : (j == 1 ? specv[1][x] : specv[2][x]);
+                    } else {
+                        const int* row = t16_slice(t16_end, g) + t16_bin(((uint32_t)p0 << 8) | (uint32_t)c);
+#pragma unroll
+                        for (int x = 0; x < kT16Copies; ++x) v += row[x * 65536];
+                    }
+                    s.rows[g][c] = v;
+                    colsum += v;
+                }
+            } else {
+                r.prefix = (uint32_t)s.sel.bcast[3];
+                r.remaining = s.sel.bcast[4];
+                sl = s.sel.bcast[5];
+                want = s.sel.bcast[6];
+            }
         }
     } else {
         r = resolve<kPlanThreads>(pp, l0, t16_end, lv, kLevels, ftn, nv, s.sel);
@@ -573,38 +610,31 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan(
                 int acc = before_me;
                 for (int g = g0; g < g1; ++g) {
                     const int cnt = ties_of(g);
-                    if (r.remaining <= acc + cnt) { s.sel.bcast[7] = g; s.sel.bcast[4] = r.remaining - acc; break; }
+                    if (r.remaining <= acc + cnt) { s.sel.bcast[5] = g; s.sel.bcast[6] = r.remaining - acc; break; }
                     acc += cnt;
                 }
             }
             __syncthreads();
-            sl = s.sel.bcast[7];
-            want = s.sel.bcast[4];
+            sl = s.sel.bcast[5];
+            want = s.sel.bcast[6];
         }
     }
     const bool topk = r.topk && r.k > 0;
     const uint32_t kth = r.prefix;
     const int need = r.remaining;                 // entries equal to kth that belong to the top k (>= 1)
-    stamp[2] = wall_clock64();
+#ifdef FF_PLAN_PROBE
+    stamp[1] = wall_clock64();
+#endif
 
     // ---- t*: the slot of the want-th entry equal to kth inside slice sl (lowest-index tie rule) ----------
     int tstar = -1;
     if (topk) {
         const int cstar = sl >> 1;                // the chunk index that covers slice sl (chunk stride = 2 slices)
         const int t0 = tid * 8 + cstar * kChunkStride;
-        const bool mine_in = t0 >= sl * kSelSlice && t0 < (sl + 1) * kSelSlice;
         uint32_t key[8];
-        bool have = false;
-#pragma unroll
-        for (int x = 0; x < kRegChunks; ++x)
-            if (x == cstar) { chunk_keys<DT>(kw[x], key); have = true; }
-        if (!have) {
-            uint4 pq[2], kq[KW];
-            load_chunk<DT>(val_rsrc, ord_rsrc, false, t0, pq, kq);
-            chunk_keys<DT>(kq, key);
-        }
+        keys_of_chunk(cstar, t0, key);
         unsigned tie = 0;
-        if (mine_in) {
+        if (t0 >= sl * kSelSlice && t0 < (sl + 1) * kSelSlice) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int t = t0 + e;
@@ -622,67 +652,75 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan(
         __syncthreads();
         tstar = s.sel.bcast[0];
     }
-
-    stamp[3] = wall_clock64();
-    // ---- one pass over all slots: kept positions before my range, keep flags of my range, member
-    // flags of my slots
-    int before = 0;
-    auto classify = [&](int t0, const uint4* pq, const uint4* kq) {
-        int pos[8] = {(int)pq[0].x, (int)pq[0].y, (int)pq[0].z, (int)pq[0].w, (int)pq[1].x, (int)pq[1].y, (int)pq[1].z, (int)pq[1].w};
-        if (!has_order) {
+#ifdef FF_PLAN_PROBE
+    stamp[2] = wall_clock64();
+#endif
+    auto folded = [&](uint32_t key, int t) {            // is slot t (value key) folded (mode 0) / dropped (mode 1)?
+        const bool in = t >= lo && t < hi;
+        bool sel;
+        if (r.topk) sel = topk && in && (key > kth || (key == kth && t <= tstar));
+        else sel = in && key >= pp.thr_key && key != nan_key<DT>();
+        return pp.mode == 0 ? (sel && t > 0) : (in && !sel);
+    };
+    // ---- member flags of my slots: 8 consecutive slots for half of the threads, from the register chunk
+    {
+        const int cm = (int)blockIdx.x >> 1;          // the chunk that covers my slice
+        const int t0 = tid * 8 + cm * kChunkStride;
+        if (t0 >= base && t0 < base + kSelSlice && t0 < L) {
+            uint32_t key[8];
+            keys_of_chunk(cm, t0, key);
+            uint32_t lo4 = 0, hi4 = 0;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) pos[e] = t0 + e;
-        }
-        uint32_t key[8];
-        chunk_keys<DT>(kq, key);
-        uint32_t mem = 0;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int t = t0 + e;
-            const bool in = t >= lo && t < hi;
-            bool sel;
-            if (r.topk) sel = topk && in && (key[e] > kth || (key[e] == kth && t <= tstar));
-            else sel = in && key[e] >= pp.thr_key && key[e] != nan_key<DT>();
-            const bool m = pp.mode == 0 ? (sel && t > 0) : (in && !sel);
-            if (m) mem |= 1u << e;
-            if (t < L) {
-                before += (!m && pos[e] < base) ? 1 : 0;
-                const unsigned rel = (unsigned)(pos[e] - base);
-                if (rel < (unsigned)kSelSlice && !m) ((uint8_t*)s.keep)[rel] = 1;
+            for (int e = 0; e < 4; ++e) {
+                lo4 |= (folded(key[e], t0 + e) ? 1u : 0u) << (8 * e);
+                hi4 |= (folded(key[4 + e], t0 + 4 + e) ? 1u : 0u) << (8 * e);
             }
-        }
-        if (t0 >= base && t0 < base + kSelSlice) {          // my slots (chunks never straddle a slice)
             if (t0 + 8 <= L) {
-                uint32_t lo4 = 0, hi4 = 0;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    lo4 |= ((mem >> e) & 1u) << (8 * e);
-                    hi4 |= ((mem >> (4 + e)) & 1u) << (8 * e);
-                }
                 *(uint2*)(member + t0) = make_uint2(lo4, hi4);
             } else {
-                for (int e = 0; e < 8 && t0 + e < L; ++e) member[t0 + e] = (mem >> e) & 1u;
+                for (int e = 0; e < 8 && t0 + e < L; ++e) member[t0 + e] = ((e < 4 ? lo4 >> (8 * e) : hi4 >> (8 * (e - 4))) & 1u);
             }
         }
-    };
+    }
+    // ---- keep flags of my positions + their compaction scan inside the workgroup
+    uint32_t kb = 0;
 #pragma unroll
-    for (int x = 0; x < kRegChunks; ++x) {
-        const int t0 = tid * 8 + x * kChunkStride;
-        if (x * kChunkStride < L) classify(t0, po[x], kw[x]);        // (uniform: whole chunk rows beyond L are skipped)
-    }
-    for (int t0 = tid * 8 + kRegChunks * kChunkStride; t0 < L; t0 += kChunkStride) {
-        uint4 pq[2], kq[KW];
-        load_chunk<DT>(val_rsrc, ord_rsrc, has_order, t0, pq, kq);
-        classify(t0, pq, kq);
-    }
-    before = block_sum_i<NW>(before, s.sel.scratch);         // (barriers: the LDS keep flags are complete)
-    stamp[4] = wall_clock64();
-
-    // ---- compaction scan of my positions
-    const int i0 = base + tid * 4;
-    const uint32_t kb = s.keep[tid];
+    for (int e = 0; e < 4; ++e)
+        if (i0 + e < L && !folded(order_key<DT>(pbits[e]), pslot[e])) kb |= 1u << (8 * e);
     int span_total;
-    int p = before + block_excl_scan<NW>(__popc(kb), s.sel.scratch, span_total);
+    const int ex = block_excl_scan<NW>(__popc(kb), s.sel.scratch, span_total);
+#ifdef FF_PLAN_PROBE
+    stamp[3] = wall_clock64();
+#endif
+    // ---- kept positions before my range = the totals of the workgroups before me
+    uint32_t tag = tag_prev + 1u;
+    if (tag == 0u) tag = 1u;
+    if (tid == 0)
+        __hip_atomic_store(&agg[blockIdx.x], ((unsigned long long)tag << 32) | (unsigned long long)(uint32_t)span_total,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < kWave) {
+        int sum = 0;
+        for (int g0 = 0; g0 < (int)blockIdx.x; g0 += kWave) {
+            const int gg = g0 + lane;
+            const bool need_it = gg < (int)blockIdx.x;
+            unsigned long long v = 0;
+            for (int spins = 0;; ++spins) {
+                if (need_it) v = __hip_atomic_load(&agg[gg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all(!need_it || (uint32_t)(v >> 32) == tag)) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (spins > (1 << 22)) {             // a predecessor never arrived: report, do not hang
+                    if (lane == 0) atomicOr((unsigned long long*)(stats + FF_STAT_ERROR), (unsigned long long)FF_ERR_BIT_BARRIER);
+                    break;
+                }
+            }
+            sum += need_it ? (int)(uint32_t)v : 0;
+        }
+        sum = wave_sum_i(sum);
+        if (lane == 0) s.sel.bcast[1] = sum;
+    }
+    __syncthreads();
+    const int before = s.sel.bcast[1];
+    int p = before + ex;
     if (i0 < L) {
         int d[4];
 #pragma unroll
@@ -700,11 +738,12 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan(
     }
     if (blockIdx.x == gridDim.x - 1) {
         if (tid == 0) {
-            stamp[5] = wall_clock64();
+            *tagword = tag;                          // (every workgroup has read the old value: they all published)
+#ifdef FF_PLAN_PROBE
+            stamp[4] = wall_clock64();
 #pragma unroll
-            for (int x = 1; x < 6; ++x) stats[FF_STAT_T_PLAN + x] = stamp[x] - stamp[0];
-            stats[FF_STAT_T_PLAN] = stamp[0];
-            stats[FF_STAT_T_PLAN + 6] = stamp_issued - stamp[0];
+            for (int x = 1; x < 5; ++x) stats[FF_STAT_T_PLAN + x] = stamp[x] - stamp[0];
+#endif
             const int l_out = before + span_total;
             stats[FF_STAT_LOUT] = l_out;
             stats[FF_STAT_MERGED] = L - l_out;
@@ -717,6 +756,332 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan(
                 stats[FF_STAT_NV] = L;
             }
             stats[FF_STAT_K] = r.k;
+            stats[FF_STAT_KTH_KEY] = kth;
+            stats[FF_STAT_TIES_TAKEN] = topk ? need : 0;
+        }
+        __syncthreads();
+        if (host_mapped && tid < kWave) publish(stats, host_mapped, seq);
+    }
+}
+
+// ---- k_plan_fast: the same plan for 16-bit values of at most 65 536 tokens ------------------------------
+// The general kernel above is bound by instruction issue (16 waves on one CU walk ~2 500 instructions
+// each: register-chunk selection, shuffle scans through LDS, divergent branches) and pays a second
+// global round trip for whatever is not in registers.  Here a workgroup of 16 waves owns only 1024
+// slots and 1024 positions - ONE of each per thread - and ALL values sit in LDS (74 KB at 64 x 576,
+// filled by one batch of loads): any slot is one ds_read away, so the tie-slot search, the member flag
+// and the gather through inv[] need neither register selection nor another trip to memory; the wave
+// scans run on the DPP network and the classification is branch-free.  The rest is as above: tables ->
+// k-th key by wave 0, tie slot t*, per-workgroup totals exchanged as {tag, count} granules (published
+// before the member flags are computed, so the hop overlaps with work).
+#ifndef FF_FAST_THREADS
+#define FF_FAST_THREADS 512
+#endif
+constexpr int kFastThreads = FF_FAST_THREADS;
+constexpr int kFastSpan = kFastThreads;            // slots / positions per workgroup
+constexpr int kFastMaxL = 65536;                   // kRowSlicesLds slices
+constexpr int kTiePer = kSelSlice / kFastThreads;  // slots per thread in the tie-slot search
+
+template <int DT>
+__global__ __launch_bounds__(kFastThreads) void k_plan_fast(
+    const void* __restrict__ values, int cap, PlanParams pp, const int* __restrict__ l0, int* t16_end,
+    int64_t* __restrict__ stats, const int32_t* __restrict__ inv, int L,
+    uint8_t* __restrict__ member, uint8_t* __restrict__ keep, int32_t* __restrict__ dst,
+    unsigned long long* agg, uint32_t* tagword, int64_t* host_mapped, int64_t seq) {
+    using A = Act<DT>;
+    static_assert(A::kBytes == 2, "16-bit values only");
+    constexpr int NW = kFastThreads / kWave, NQ = kFastThreads / 256, kSpec = kRowSlicesLds / NQ;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    int (*rows)[256] = (int (*)[256])lds_raw;                                  // [kRowSlicesLds][256] level-1 rows
+    int (*part)[256] = (int (*)[256])(lds_raw + kRowSlicesLds * 256 * 4);       // [NQ][256] partial column sums
+    int* scratch = (int*)(lds_raw + (kRowSlicesLds + NQ) * 256 * 4);           // [2 * NW]
+    int* bcast = scratch + 2 * NW;                                              // [16]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = tid & 255, q = tid >> 8;
+    const int i0 = blockIdx.x * kFastSpan + tid;        // my position and my slot
+#ifdef FF_PLAN_PROBE
+    long long stamp[8];
+    stamp[0] = wall_clock64();
+    const long long wave_t0 = stamp[0];
+#endif
+
+    // ---- round 1: tables, inv[] of my position, and all values -> LDS (every load issued before any is used)
+    const long long nv_raw = stats[FF_STAT_NV];
+    const long long ftn = stats[FF_STAT_FTN];
+    const uint32_t tag_prev = *tagword;
+    int l0v[kL0Copies / NQ];
+#pragma unroll
+    for (int x = 0; x < kL0Copies / NQ; ++x) l0v[x] = l0[(q + x * NQ) * kL0Stride + c];
+    const int l0cnt_raw = l0[(tid & (kL0Copies - 1)) * kL0Stride + 256];
+    int specv[kSpec][kT16Copies];
+    {
+        const uint32_t bin = t16_bin(((uint32_t)pp.p0_guess << 8) | (uint32_t)c);
+#pragma unroll
+        for (int j = 0; j < kSpec; ++j) {
+            if (j * NQ < pp.n_slices) {                                     // (uniform; the row is clamped: used for g < n_slices only)
+                const int* row = t16_slice(t16_end, min(q + j * NQ, pp.n_slices - 1)) + bin;
+#pragma unroll
+                for (int x = 0; x < kT16Copies; ++x) specv[j][x] = row[x * 65536];
+            } else {
+#pragma unroll
+                for (int x = 0; x < kT16Copies; ++x) specv[j][x] = 0;
+            }
+        }
+    }
+    const __amdgpu_buffer_rsrc_t inv_rsrc = make_rsrc(inv ? (const void*)inv : values, inv ? (uint32_t)L * 4u : 0u);
+    const int inv1 = __builtin_amdgcn_raw_buffer_load_b32(inv_rsrc, i0 * 4, 0, 0);
+    const uint32_t my_bits = A::bits1(values, min(i0, cap - 1));          // the value of my slot
+    __builtin_amdgcn_sched_barrier(0);
+    const int nv = pp.mode == 0 ? (int)nv_raw : L;
+    const int lo = pp.mode == 0 ? 0 : pp.lo, hi = pp.mode == 0 ? nv : pp.hi;
+    {
+        int colsum = 0;
+#pragma unroll
+        for (int x = 0; x < kL0Copies / NQ; ++x) colsum += l0v[x];
+        part[q][c] = colsum;
+        if (tid < kL0Copies) scratch[tid] = l0cnt_raw;
+    }
+    // the value of my position's slot: one dependent gather, in flight while the levels are resolved
+    const int pslot = inv ? inv1 : i0;
+    const uint32_t pos_bits = A::bits1(values, min(max(pslot, 0), cap - 1));
+#ifdef FF_PLAN_PROBE
+    stamp[1] = wall_clock64();
+    __shared__ long long wstart[16], wready[16];
+    if (lane == 0) { wstart[wv] = wave_t0; wready[wv] = stamp[1]; }
+#endif
+    __syncthreads();
+#ifdef FF_PLAN_PROBE
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+        long long s_max = 0, r_max = 0, r_min = 1ll << 62;
+        for (int x = 0; x < NW; ++x) { s_max = max(s_max, wstart[x]); r_max = max(r_max, wready[x]); r_min = min(r_min, wready[x]); }
+        stats[FF_STAT_T_ORDER] = s_max - stamp[0]; stats[FF_STAT_T_ORDER + 1] = r_min - stamp[0]; stats[FF_STAT_T_ORDER + 2] = r_max - stamp[0];
+        long long packed = 0;       // per-wave ready times, 0.1 us units, 4 bits each (clamped)
+        for (int x = 0; x < NW; ++x) { long long u = (wready[x] - stamp[0]) / 40; packed |= (u > 15 ? 15 : u) << (4 * x); }
+        stats[FF_STAT_T_ORDER + 3] = packed;
+    }
+#endif
+#ifdef FF_PLAN_PROBE
+    stamp[2] = wall_clock64();
+#endif
+    // ---- level 0: decision + top byte of the k-th key (wave 0)
+    auto pick = [&](int rem, int& bin, int& above) {
+        const int top = 255 - 4 * lane;
+        int v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = 0;
+#pragma unroll
+            for (int x = 0; x < NQ; ++x) v[e] += part[x][top - e];
+        }
+        const int sum = v[0] + v[1] + v[2] + v[3];
+        const int incl = wave_incl_scan_dpp(sum);
+        const int first = __ffsll((long long)__ballot(incl >= rem)) - 1;
+        int ab = incl - sum, b = top;
+        if (ab + v[0] >= rem) { b = top; }
+        else if (ab + v[0] + v[1] >= rem) { ab += v[0]; b = top - 1; }
+        else if (ab + v[0] + v[1] + v[2] >= rem) { ab += v[0] + v[1]; b = top - 2; }
+        else { ab += v[0] + v[1] + v[2]; b = top - 3; }
+        bin = __builtin_amdgcn_readlane(b, first);
+        above = __builtin_amdgcn_readlane(ab, first);
+    };
+    if (wv == 0) {
+        int cnt = lane < kL0Copies ? scratch[lane] : 0;
+        cnt = __builtin_amdgcn_readlane(wave_incl_scan_dpp(cnt), 63);
+        bool topk;
+        long long k;
+        if (pp.mode == 0 && pp.k_given >= 0) {
+            topk = true;                                  // fixed-sparsity policy (modeling_qwen2_baseline.py:920,1001)
+            k = pp.k_given > nv ? (long long)nv : pp.k_given;
+        } else if (pp.mode == 0) {
+            // main.py:114-116 in double, as python: ratio = count / ftn ; ratio < sub ?
+            const double ratio = ftn > 0 ? (double)cnt / (double)ftn : 0.0;
+            topk = !(ratio < pp.sub);
+            k = 0;
+            if (topk) {
+                k = (long long)(pp.sub * (double)ftn);   // int(sub * ftn), main.py:122
+                if (k > nv) k = nv;
+                if (k < 0) k = 0;
+            }
+        } else {
+            topk = true;
+            k = pp.k_given;
+        }
+        int bin = 0, above = 0;
+        if (topk && k > 0) pick((int)k, bin, above);
+        if (lane == 0) { bcast[0] = topk ? 1 : 0; bcast[1] = cnt; bcast[2] = (int)k; bcast[3] = bin; bcast[4] = (int)k - above; }
+    }
+    __syncthreads();
+#ifdef FF_PLAN_PROBE
+    stamp[3] = wall_clock64();
+#endif
+    const bool is_topk = bcast[0] != 0;
+    const int count = bcast[1], k_sel = bcast[2];
+    const bool topk = is_topk && k_sel > 0;
+    uint32_t kth = 0;
+    int need = 0, tstar = -1;
+    if (topk) {                                              // (uniform)
+        // ---- level 1: the rows of the level-0 bin (the speculated ones if the guess was right)
+        const int p0 = bcast[3];
+        int colsum = 0;
+        if (p0 == pp.p0_guess) {
+#pragma unroll
+            for (int j = 0; j < kSpec; ++j) {
+                int a = 0;
+#pragma unroll
+                for (int x = 0; x < kT16Copies; ++x) a += specv[j][x];
+                a = q + j * NQ < pp.n_slices ? a : 0;
+                rows[q + j * NQ][c] = a;
+                colsum += a;
+            }
+        } else {
+            const uint32_t bin = t16_bin(((uint32_t)p0 << 8) | (uint32_t)c);
+#pragma unroll
+            for (int j = 0; j < kSpec; ++j) {
+                int a = 0;
+                if (q + j * NQ < pp.n_slices) {
+                    const int* row = t16_slice(t16_end, q + j * NQ) + bin;
+#pragma unroll
+                    for (int x = 0; x < kT16Copies; ++x) a += row[x * 65536];
+                }
+                rows[q + j * NQ][c] = a;
+                colsum += a;
+            }
+        }
+        part[q][c] = colsum;
+        __syncthreads();
+        if (wv == 0) {
+            int p1, above;
+            pick(bcast[4], p1, above);
+            const int rem = bcast[4] - above;
+            // the slice that holds the rem-th entry equal to the k-th key (entries per slice = rows[g][p1])
+            const int ties = lane < kRowSlicesLds ? rows[lane][p1] : 0;
+            const int tincl = wave_incl_scan_dpp(ties);
+            const int hit = __ffsll((long long)__ballot(tincl >= rem)) - 1;
+            const int before_hit = __builtin_amdgcn_readlane(tincl - ties, hit);
+            if (lane == 0) { bcast[5] = (p0 << 8) | p1; bcast[6] = rem; bcast[7] = hit; bcast[8] = rem - before_hit; }
+        }
+        __syncthreads();
+        kth = (uint32_t)bcast[5];
+        need = bcast[6];
+        const int sl = bcast[7], want = bcast[8];
+        // ---- t*: the slot of the want-th entry equal to kth inside slice sl: kTiePer slots per thread (the
+        // one load of the kernel that depends on the decision)
+        const int t0 = sl * kSelSlice + tid * kTiePer;
+        uint32_t w[kTiePer / 2];
+        if (t0 + kTiePer <= cap) {
+            const uint32_t* src = (const uint32_t*)((const uint16_t*)values + t0);
+#pragma unroll
+            for (int e = 0; e < kTiePer / 2; ++e) w[e] = src[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < kTiePer / 2; ++e) w[e] = 0u;
+            for (int e = 0; e < kTiePer; ++e)
+                if (t0 + e < cap) w[e >> 1] |= A::bits1(values, t0 + e) << (16 * (e & 1));
+        }
+        uint32_t tie = 0;
+#pragma unroll
+        for (int e = 0; e < kTiePer; ++e) {
+            const uint32_t key = order_key<DT>((w[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+            const int t = t0 + e;
+            tie |= (uint32_t)((t >= lo) & (t < hi) & (key == kth)) << e;
+        }
+        const int mine = __popc(tie);
+        const int wincl = wave_incl_scan_dpp(mine);
+        if (lane == 63) scratch[wv] = wincl;
+        __syncthreads();
+        int ex = wincl - mine;
+#pragma unroll
+        for (int x = 0; x < NW; ++x) ex += x < wv ? scratch[x] : 0;
+        if (ex < want && want <= ex + mine) {
+            int seen = ex, found = -1;
+#pragma unroll
+            for (int e = 0; e < kTiePer; ++e) {
+                seen += (tie >> e) & 1u;
+                found = (found < 0 && ((tie >> e) & 1u) && seen == want) ? t0 + e : found;
+            }
+            bcast[9] = found;
+        }
+        __syncthreads();
+        tstar = bcast[9];
+    }
+#ifdef FF_PLAN_PROBE
+    stamp[4] = wall_clock64();
+#endif
+    // is slot t (raw value bits) folded (mode 0) / dropped (mode 1)?  branch-free
+    auto folded = [&](uint32_t bits, int t) -> uint32_t {
+        const uint32_t key = order_key<DT>(bits);
+        const bool in = (t >= lo) & (t < hi);
+        const bool sel_topk = topk & in & ((key > kth) | ((key == kth) & (t <= tstar)));
+        const bool sel_thr = in & (key >= pp.thr_key) & (key != nan_key<DT>());
+        const bool sel = is_topk ? sel_topk : sel_thr;
+        return (uint32_t)(pp.mode == 0 ? (sel & (t > 0)) : (in & !sel));
+    };
+    // ---- keep flag of my position (its value through inv[]) + the scan inside the workgroup
+    const uint32_t kp = (uint32_t)(i0 < L) & (folded(pos_bits, pslot) ^ 1u);
+    const int wincl = wave_incl_scan_dpp((int)kp);
+    if (lane == 63) scratch[NW + wv] = wincl;
+    uint32_t tag = tag_prev + 1u;
+    if (tag == 0u) tag = 1u;
+    __syncthreads();
+    int span_total = 0, ex = wincl - (int)kp;
+#pragma unroll
+    for (int x = 0; x < NW; ++x) { span_total += scratch[NW + x]; ex += x < wv ? scratch[NW + x] : 0; }
+    // ---- kept positions before my range = the totals of the workgroups before me: publish mine first
+    if (tid == 0)
+        __hip_atomic_store(&agg[blockIdx.x], ((unsigned long long)tag << 32) | (unsigned long long)(uint32_t)span_total,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef FF_PLAN_PROBE
+    stamp[5] = wall_clock64();
+#endif
+    // ---- member flag of my slot (while the totals travel)
+    if (i0 < L) member[i0] = (uint8_t)folded(my_bits, i0);
+    if (wv == 0) {
+        int sum = 0;
+        for (int g0 = 0; g0 < (int)blockIdx.x; g0 += kWave) {
+            const int gg = g0 + lane;
+            const bool need_it = gg < (int)blockIdx.x;
+            unsigned long long v = 0;
+            for (int spins = 0;; ++spins) {
+                if (need_it) v = __hip_atomic_load(&agg[gg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all(!need_it || (uint32_t)(v >> 32) == tag)) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (spins > (1 << 22)) {             // a predecessor never arrived: report, do not hang
+                    if (lane == 0) atomicOr((unsigned long long*)(stats + FF_STAT_ERROR), (unsigned long long)FF_ERR_BIT_BARRIER);
+                    break;
+                }
+            }
+            sum += need_it ? (int)(uint32_t)v : 0;
+        }
+        sum = __builtin_amdgcn_readlane(wave_incl_scan_dpp(sum), 63);
+        if (lane == 0) bcast[10] = sum;
+    }
+    __syncthreads();
+    const int before = bcast[10];
+#ifdef FF_PLAN_PROBE
+    stamp[6] = wall_clock64();
+#endif
+    if (i0 < L) {
+        dst[i0] = kp ? before + ex : -1;
+        keep[i0] = (uint8_t)kp;
+    }
+    if (blockIdx.x == gridDim.x - 1) {
+        if (tid == 0) {
+            *tagword = tag;                          // (every workgroup has read the old value: they all published)
+#ifdef FF_PLAN_PROBE
+            stamp[7] = wall_clock64();
+            for (int x = 1; x < 8; ++x) stats[FF_STAT_T_PLAN + x - 1] = stamp[x] - stamp[0];
+#endif
+            const int l_out = before + span_total;
+            stats[FF_STAT_LOUT] = l_out;
+            stats[FF_STAT_MERGED] = L - l_out;
+            if (pp.mode == 0) {
+                const double ratio = ftn > 0 ? (double)count / (double)ftn : 0.0;
+                stats[FF_STAT_COUNT] = count;
+                stats[FF_STAT_BRANCH] = is_topk ? 1 : 0;
+                stats[FF_STAT_BELOW_LB] = (!is_topk && ratio < pp.ratio_lb) ? 1 : 0;
+            } else {
+                stats[FF_STAT_NV] = L;
+            }
+            stats[FF_STAT_K] = k_sel;
             stats[FF_STAT_KTH_KEY] = kth;
             stats[FF_STAT_TIES_TAKEN] = topk ? need : 0;
         }
@@ -782,11 +1147,14 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const uint8_t* __restrict
 // ---- launchers (also used by the fused step in ff_abi.hip) ------------------------------------------
 static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
 
-// Workspace layout: [kL0Ints ints: level-0 tables][3 x G x 256 ints: fp32 level rows][K0's per-slice
-// rows, ff_order.hip] ... free ... [G slices of level-1 tables, down from the end];  G = ceil(L / 4096).
+// Workspace layout: [kL0Ints ints: level-0 tables][16 ints: launch tag][2 x kMaxPlanGroups ints: the
+// workgroup totals][2 x G x 256 ints: fp32 level rows][L ints: inverse order of the stand-alone entry
+// points][K0's per-slice rows, ff_order.hip] ... free ... [G slices of level-1 tables, down from the
+// end];  G = ceil(L / 4096).
+constexpr int kWsFixedInts = kL0Ints + 16 + 2 * 512;          // (room for 512 workgroup totals)
 size_t plan_ws_front_bytes(int64_t L) {
     const size_t G = (size_t)((L + kSelSlice - 1) / kSelSlice) + 1;
-    const size_t b = ((size_t)kL0Ints + 2 * G * 256) * sizeof(int) + 256;
+    const size_t b = ((size_t)kWsFixedInts + 2 * G * 256 + (size_t)L + 16) * sizeof(int) + 256;
     return (b + 255) & ~(size_t)255;
 }
 size_t plan_ws_tail_bytes(int64_t L) {
@@ -795,7 +1163,18 @@ size_t plan_ws_tail_bytes(int64_t L) {
 }
 int* ws_l0(void* ws) { return (int*)ws; }
 int* ws_t16_end(void* ws, size_t ws_bytes) { return (int*)((char*)ws + (ws_bytes & ~(size_t)15)); }
-static int* ws_levels(void* ws) { return (int*)ws + kL0Ints; }
+static uint32_t* ws_tag(void* ws) { return (uint32_t*)((int*)ws + kL0Ints); }
+static unsigned long long* ws_agg(void* ws) { return (unsigned long long*)((int*)ws + kL0Ints + 16); }
+static int* ws_levels(void* ws) { return (int*)ws + kWsFixedInts; }
+static int32_t* ws_inv(void* ws, int64_t L) {
+    const size_t G = (size_t)((L + kSelSlice - 1) / kSelSlice) + 1;
+    return (int32_t*)(((uintptr_t)(ws_levels(ws) + 2 * G * 256) + 15) & ~(uintptr_t)15);
+}
+
+__global__ __launch_bounds__(256) void k_invert(const int32_t* __restrict__ order, int L, int32_t* __restrict__ inv) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < L) inv[order[t]] = t;
+}
 
 // the regions a call over L values dirties (zeroed again by the merge kernel or by memsets)
 void table_regions(void* ws, size_t ws_bytes, int64_t L, void** a, size_t* a_bytes, void** b, size_t* b_bytes) {
@@ -837,10 +1216,11 @@ template <> uint32_t host_thr_key<FF_F16>(double thr) {
 // restore the zero state afterwards (memsets) - the stand-alone entry points.
 template <int DT>
 static int launch_plan(const void* values, PlanParams pp, bool have_tables, int64_t cap, int64_t L,
-                       const int32_t* order, uint8_t* member, uint8_t* keep, int32_t* dst, int64_t* stats,
+                       const int32_t* inv, uint8_t* member, uint8_t* keep, int32_t* dst, int64_t* stats,
                        void* ws, size_t ws_bytes, int64_t* host_mapped, int64_t seq, hipStream_t st) {
     constexpr int kLevels = Act<DT>::kKeyBits / 8;
     const unsigned G = cdiv(L, kSelSlice);
+    if (G > (unsigned)kMaxPlanGroups) return FF_ERR_UNSUPPORTED;      // every workgroup must be resident
     pp.n_slices = (int)G;
     int* l0 = ws_l0(ws);
     int* t16_end = ws_t16_end(ws, ws_bytes);
@@ -854,18 +1234,43 @@ static int launch_plan(const void* values, PlanParams pp, bool have_tables, int6
     for (int level = 2; level < kLevels; ++level)
         hipLaunchKernelGGL(k_hist_level<DT>, dim3(G), dim3(kSliceThreads), 0, st, values, (int)cap, pp, level,
                            (const int64_t*)stats, (const int*)l0, t16_end, lv);
-    hipLaunchKernelGGL(k_plan<DT>, dim3(G), dim3(kPlanThreads), 0, st, values, (int)cap, pp, (const int*)l0, t16_end,
-                       (const int*)lv, stats, order, (int)L, member, keep, dst, host_mapped, seq);
+    if constexpr (kLevels == 2) {
+        if (L <= kFastMaxL) {
+            static bool attr_set[3] = {false, false, false};
+            const size_t lds = (size_t)(kRowSlicesLds + kFastThreads / 256) * 256 * 4 + (2 * (kFastThreads / kWave) + 16) * 4;
+            if (!attr_set[DT]) {
+                hipError_t e = hipFuncSetAttribute((const void*)k_plan_fast<DT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   156 * 1024);
+                if (e != hipSuccess) return (int)e;
+                attr_set[DT] = true;
+            }
+            hipLaunchKernelGGL(k_plan_fast<DT>, dim3(cdiv(L, kFastSpan)), dim3(kFastThreads), lds, st, values, (int)cap, pp,
+                               (const int*)l0, t16_end, stats, inv, (int)L, member, keep, dst, ws_agg(ws), ws_tag(ws),
+                               host_mapped, seq);
+            int rc0 = (int)hipGetLastError();
+            if (rc0) return rc0;
+            if (!have_tables) return zero_tables(ws, ws_bytes, L, st);
+            return FF_OK;
+        }
+    }
+    hipLaunchKernelGGL((k_plan<DT, false>), dim3(G), dim3(kPlanThreads), 0, st, values, (int)cap, pp, (const int*)l0, t16_end,
+                       (const int*)lv, stats, inv, (int)L, member, keep, dst, ws_agg(ws), ws_tag(ws), host_mapped, seq);
     int rc = (int)hipGetLastError();
     if (rc) return rc;
     if (!have_tables) return zero_tables(ws, ws_bytes, L, st);
     return FF_OK;
 }
 
-int launch_plan_merge(const void* sim, int dtype, const int32_t* order, int64_t L, double thr, double sub,
-                      double ratio_lb, uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
+// inv == nullptr: the inverse of `order` is built here (stand-alone entry points)
+int launch_plan_merge(const void* sim, int dtype, const int32_t* order, const int32_t* inv, int64_t L, double thr,
+                      double sub, double ratio_lb, uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
                       void* ws, size_t ws_bytes, bool have_tables, int64_t* host_mapped, int64_t seq,
                       hipStream_t st, long long force_k) {
+    if (!inv) {
+        int32_t* tmp = ws_inv(ws, L);
+        hipLaunchKernelGGL(k_invert, dim3(cdiv(L, 256)), dim3(256), 0, st, order, (int)L, tmp);
+        inv = tmp;
+    }
     PlanParams pp;
     pp.mode = 0; pp.lo = 0; pp.hi = -1; pp.k_given = force_k; pp.sub = sub; pp.ratio_lb = ratio_lb; pp.n_slices = 0;
     // the k-th similarity of a video sits in the binade of typical thresholds: [0.5, 1)
@@ -875,13 +1280,13 @@ int launch_plan_merge(const void* sim, int dtype, const int32_t* order, int64_t 
     switch (dtype) {
         case FF_F32:
             pp.thr_key = host_thr_key<FF_F32>(thr);
-            return launch_plan<FF_F32>(sim, pp, have_tables, L, L, order, member, keep, dst, stats, ws, ws_bytes, host_mapped, seq, st);
+            return launch_plan<FF_F32>(sim, pp, have_tables, L, L, inv, member, keep, dst, stats, ws, ws_bytes, host_mapped, seq, st);
         case FF_BF16:
             pp.thr_key = host_thr_key<FF_BF16>(thr);
-            return launch_plan<FF_BF16>(sim, pp, have_tables, L, L, order, member, keep, dst, stats, ws, ws_bytes, host_mapped, seq, st);
+            return launch_plan<FF_BF16>(sim, pp, have_tables, L, L, inv, member, keep, dst, stats, ws, ws_bytes, host_mapped, seq, st);
         default:
             pp.thr_key = host_thr_key<FF_F16>(thr);
-            return launch_plan<FF_F16>(sim, pp, have_tables, L, L, order, member, keep, dst, stats, ws, ws_bytes, host_mapped, seq, st);
+            return launch_plan<FF_F16>(sim, pp, have_tables, L, L, inv, member, keep, dst, stats, ws, ws_bytes, host_mapped, seq, st);
     }
 }
 
@@ -936,8 +1341,8 @@ extern "C" int ff_plan_merge(const void* sim, int dtype, const int32_t* order, i
         ((uintptr_t)member & 7))
         return FF_ERR_ALIGN;
     if (L == 0) return FF_OK;
-    return ff::launch_plan_merge(sim, dtype, order, L, threshold, sub, ratio_lb, member, dst, keep, stats, ws, ws_bytes,
-                                 false, nullptr, 0, (hipStream_t)stream, -1);
+    return ff::launch_plan_merge(sim, dtype, order, nullptr, L, threshold, sub, ratio_lb, member, dst, keep, stats, ws,
+                                 ws_bytes, false, nullptr, 0, (hipStream_t)stream, -1);
 }
 
 extern "C" int ff_plan_topk(const void* sim, int dtype, const int32_t* order, int64_t L, int64_t k, uint8_t* member,
@@ -951,8 +1356,8 @@ extern "C" int ff_plan_topk(const void* sim, int dtype, const int32_t* order, in
         ((uintptr_t)member & 7))
         return FF_ERR_ALIGN;
     if (L == 0) return FF_OK;
-    return ff::launch_plan_merge(sim, dtype, order, L, 0.0, 0.0, 0.0, member, dst, keep, stats, ws, ws_bytes, false,
-                                 nullptr, 0, (hipStream_t)stream, k);
+    return ff::launch_plan_merge(sim, dtype, order, nullptr, L, 0.0, 0.0, 0.0, member, dst, keep, stats, ws, ws_bytes,
+                                 false, nullptr, 0, (hipStream_t)stream, k);
 }
 
 extern "C" int ff_plan_from_index(const int64_t* merge_index, int64_t n_merge, const int32_t* order, int64_t L,

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(kSimThreads) void k_pair_similarity(
     const char* __restrict__ hidden, uint32_t row_bytes, const int64_t* __restrict__ ptype,
     const int32_t* __restrict__ order, const int64_t* __restrict__ stats, void* __restrict__ sim,
     int* __restrict__ l0, int* t16_end, float thr, const LayoutHint hint, int32_t* __restrict__ order_out,
-    int64_t* __restrict__ stats_out) {
+    int32_t* __restrict__ inv_out, int64_t* __restrict__ stats_out) {
     using A = Act<DT>;
     constexpr int E = A::kPer16;
     constexpr int R = kPairs + 1;
@@ -49,6 +49,7 @@ __global__ __launch_bounds__(kSimThreads) void k_pair_similarity(
             const int i = q < hint.pre ? q : q + nv;
             if (ptype[i] != -1) atomicOr((unsigned long long*)(stats_out + FF_STAT_ERROR), (unsigned long long)FF_ERR_BIT_LAYOUT);
             order_out[nv + q] = i;
+            if (inv_out) inv_out[i] = nv + q;
         }
         if (gtid == 0) {
             stats_out[FF_STAT_NV] = nv;
@@ -149,6 +150,7 @@ __global__ __launch_bounds__(kSimThreads) void k_pair_similarity(
                     if (my_type != (int64_t)slot_p[r])
                         atomicOr((unsigned long long*)(stats_out + FF_STAT_ERROR), (unsigned long long)FF_ERR_BIT_LAYOUT);
                     order_out[j] = slot_i[r];
+                    if (inv_out) inv_out[slot_i[r]] = j;
                     same_type = slot_f[r] != 0;            // the previous slot is the same patch one frame earlier
                 } else {
                     same_type = j > 0 && ptype[order[j - 1]] == ptype[order[j]];
@@ -198,6 +200,7 @@ struct SimArgs {
     float thr;
     LayoutHint hint;          // frames == 0: no hint
     int32_t* order_out;
+    int32_t* inv_out;
     int64_t* stats_out;
 };
 
@@ -209,11 +212,11 @@ static int launch_similarity_pt(const SimArgs& a, hipStream_t st) {
     if (a.hint.frames > 0)
         hipLaunchKernelGGL((k_pair_similarity<DT, kPairs, kSimThreads, true>), dim3((unsigned)blocks), dim3(kSimThreads), 0,
                            st, (const char*)a.hidden, (uint32_t)row_bytes, a.ptype, a.order, a.stats, a.sim, a.l0, a.t16_end, a.thr,
-                           a.hint, a.order_out, a.stats_out);
+                           a.hint, a.order_out, a.inv_out, a.stats_out);
     else
         hipLaunchKernelGGL((k_pair_similarity<DT, kPairs, kSimThreads, false>), dim3((unsigned)blocks), dim3(kSimThreads), 0,
                            st, (const char*)a.hidden, (uint32_t)row_bytes, a.ptype, a.order, a.stats, a.sim, a.l0, a.t16_end, a.thr,
-                           a.hint, (int32_t*)nullptr, (int64_t*)nullptr);
+                           a.hint, (int32_t*)nullptr, (int32_t*)nullptr, (int64_t*)nullptr);
     return (int)hipGetLastError();
 }
 
@@ -222,10 +225,10 @@ static int launch_similarity(const SimArgs& a, hipStream_t st) { return launch_s
 
 // hint_frames > 0: frame-major closed form (see LayoutHint); `order` and `stats` are then outputs.
 int launch_similarity_any(const void* hidden, int dtype, int64_t L, int64_t d, const int64_t* ptype,
-                          int32_t* order, int64_t* stats, void* sim, int* l0, int* t16_end, double thr,
+                          int32_t* order, int32_t* inv, int64_t* stats, void* sim, int* l0, int* t16_end, double thr,
                           int64_t hint_pre, int64_t hint_patches, int64_t hint_frames, hipStream_t st) {
     SimArgs a{hidden, L, d, ptype, order, stats, sim, l0, t16_end, (float)thr,
-              LayoutHint{(int)hint_pre, (int)hint_patches, (int)hint_frames, (int)L}, order, stats};
+              LayoutHint{(int)hint_pre, (int)hint_patches, (int)hint_frames, (int)L}, order, inv, stats};
     switch (dtype) {
         case FF_F32: return launch_similarity<FF_F32>(a, st);
         case FF_BF16: return launch_similarity<FF_BF16>(a, st);
@@ -244,6 +247,6 @@ extern "C" int ff_pair_similarity(const void* hidden, int dtype, int64_t L, int6
     if (((uintptr_t)hidden & 15) || ((d * esz) & 15)) return FF_ERR_ALIGN;
     if (L >= (1ll << 31) || d * esz >= (1ll << 31)) return FF_ERR_UNSUPPORTED;
     if (L == 0) return FF_OK;
-    return ff::launch_similarity_any(hidden, dtype, L, d, patch_type, const_cast<int32_t*>(order),
+    return ff::launch_similarity_any(hidden, dtype, L, d, patch_type, const_cast<int32_t*>(order), nullptr,
                                      const_cast<int64_t*>(stats), sim, nullptr, nullptr, 0.0, 0, 0, 0, (hipStream_t)stream);
 }

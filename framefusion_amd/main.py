@@ -57,6 +57,8 @@ class _Scratch:
             dev = self.device
             self.order = torch.empty(cap, dtype=torch.int32, device=dev)
             self.order_next = torch.empty(cap, dtype=torch.int32, device=dev)
+            self.inv = torch.empty(cap, dtype=torch.int32, device=dev)          # inverse of order (slot of a position)
+            self.inv_next = torch.empty(cap, dtype=torch.int32, device=dev)
             self.member = torch.empty(cap, dtype=torch.uint8, device=dev)
             self.dst = torch.empty(cap, dtype=torch.int32, device=dev)
             self.keep = torch.empty(cap, dtype=torch.uint8, device=dev)
@@ -313,7 +315,8 @@ class FrameFusion(nn.Module):
             hint = None
         hint_pre, hint_frames = hint if hint is not None else (0, 0)
         rc = lib.ff_merge_begin(hidden.data_ptr(), code, L, d, ptype.data_ptr(), int(self.patch_num), order_valid,
-                                thr, sc.order.data_ptr(), sim_ptr, sc.stats.data_ptr(), seq, hint_pre, hint_frames,
+                                thr, sc.order.data_ptr(), sc.inv.data_ptr(), sim_ptr, sc.stats.data_ptr(), seq, hint_pre,
+                                hint_frames,
                                 sc.ws.data_ptr(), sc.ws_bytes, stream)
         _lib.check(rc, "ff_merge_begin")
 
@@ -326,9 +329,10 @@ class FrameFusion(nn.Module):
         n_aux = self._fill_aux(aux, n_aux, srcs, outs, L)
         rc = lib.ff_merge_finish(hidden.data_ptr(), out.data_ptr(), code, L, d, L_cap,
                                  float(thr), float(sub), float(self.ratio_lower_bound),
-                                 sc.order.data_ptr(), sim_ptr, sc.member.data_ptr(), sc.dst.data_ptr(),
-                                 sc.keep.data_ptr(), sc.stats.data_ptr(), sc.stats_host_ptr, seq,
-                                 aux, n_aux, sc.order_next.data_ptr(), sc.ws.data_ptr(), sc.ws_bytes, stream)
+                                 sc.order.data_ptr(), sc.inv.data_ptr(), sim_ptr, sc.member.data_ptr(),
+                                 sc.dst.data_ptr(), sc.keep.data_ptr(), sc.stats.data_ptr(), sc.stats_host_ptr, seq,
+                                 aux, n_aux, sc.order_next.data_ptr(), sc.inv_next.data_ptr(), sc.ws.data_ptr(),
+                                 sc.ws_bytes, stream)
         _lib.check(rc, "ff_merge_finish")
         sc.dirty = False
         mask_out = None
@@ -390,6 +394,7 @@ class FrameFusion(nn.Module):
         self.last_call = dict(kind="merge", L_in=L, L_out=L_out, nv=nv, ftn=ftn, count=count, branch=branch,
                               k=int(st[_lib.STAT_K]), scratch=sc, dtype=dtype, order=sc.order)
         sc.order, sc.order_next = sc.order_next, sc.order
+        sc.inv, sc.inv_next = sc.inv_next, sc.inv
         sc.order_valid_for = (self._ptype_gen, L_out)
         hidden_states = out[:, :L_out]
         position_embeddings = rebuild(L_out)
@@ -479,7 +484,7 @@ class FrameFusion(nn.Module):
         ws_bytes = int(lib.ff_workspace_bytes(L, int(patch_num)))
         ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=device)
         stream = _lib.stream_ptr()
-        _lib.check(lib.ff_build_order(ptype.data_ptr(), L, int(patch_num), order.data_ptr(), stats.data_ptr(),
+        _lib.check(lib.ff_build_order(ptype.data_ptr(), L, int(patch_num), order.data_ptr(), None, stats.data_ptr(),
                                       ws.data_ptr(), ws_bytes, stream), "ff_build_order")
         _lib.check(lib.ff_pair_similarity(hidden.data_ptr(), code, L, d, ptype.data_ptr(), order.data_ptr(),
                                           stats.data_ptr(), sim.data_ptr(), stream), "ff_pair_similarity")

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FF_ABI_VERSION 3
+#define FF_ABI_VERSION 4
 
 enum { FF_F32 = 0, FF_BF16 = 1, FF_F16 = 2 };
 
@@ -57,12 +57,12 @@ enum {
     FF_STAT_SEQ = 10,      /* sequence number, copied from the call (host polling)                */
     FF_STAT_ERROR = 11,    /* bit mask of device-side checks that failed, FF_ERR_BIT_*; cleared once published */
     FF_STAT_T_ORDER = 16,  /* 2 words: shader-clock cycles of K0's second launch (diagnostics)    */
-    FF_STAT_T_PLAN = 24,   /* reserved for plan-kernel diagnostics                                */
+    FF_STAT_T_PLAN = 24,   /* 7 words: steady-counter stamps of the plan kernel's phases (diagnostics) */
     FF_STAT_WORDS = 32
 };
 
 enum {
-    FF_ERR_BIT_BARRIER = 1,  /* a grid barrier of the fused plan kernel timed out                    */
+    FF_ERR_BIT_BARRIER = 1,  /* a workgroup of the plan kernel never saw a predecessor's total (bounded spin) */
     FF_ERR_BIT_LAYOUT = 2    /* the frame-major layout hint of ff_merge_begin does not describe
                                 patch_type: the call's outputs are meaningless, repeat it unhinted  */
 };
@@ -72,7 +72,13 @@ typedef void* ff_stream_t; /* hipStream_t */
 int ff_abi_version(void);
 const char* ff_error_string(int code);
 
-/* Scratch bytes any entry point may need for a sequence of L tokens and `patch_num` patch types. */
+/* Scratch bytes any entry point may need for a sequence of L tokens and `patch_num` patch types.
+ * Workspace protocol: allocate it ZERO-INITIALISED and pass the SAME (ws, ws_bytes) to every call that
+ * works on one sample.  It holds the select tables (a level-0 histogram at the front, per-slice
+ * level-1 histograms laid out down from the end, so their place depends on neither L nor the call):
+ * the producer of the values (similarity / head-mean kernel) accumulates them, the plan kernel consumes
+ * them, the merge kernel of the same call clears them again - every entry point leaves the workspace
+ * as it found it.  After a failed call zero it again. */
 size_t ff_workspace_bytes(int64_t L, int64_t patch_num);
 
 /* ---- K0: by-patch order --------------------------------------------------------------------
@@ -80,11 +86,13 @@ size_t ff_workspace_bytes(int64_t L, int64_t patch_num);
  * order[0 .. Nv)  = sequence index of the visual tokens, stable-sorted by patch type;
  * order[Nv .. L)  = the remaining (text / out-of-range) positions in sequence order, so that
  *                   `order` is a permutation of 0..L-1 that later stages can walk uniformly.
+ * inv (optional)  = its inverse: inv[order[t]] = t, the slot of every sequence position (what the
+ *                   plan kernel reads to classify positions without walking the whole order).
  * stats[FF_STAT_NV], stats[FF_STAT_FTN] are written.  patch_num <= 32768; patch_type, order and ws
  * 16-byte aligned, ws >= ff_workspace_bytes(L, patch_num) (two launches: per-slice facts, then the
  * closed form of the frame-major layout on every workgroup or the counting sort on one). */
 int ff_build_order(const int64_t* patch_type, int64_t L, int64_t patch_num,
-                   int32_t* order, int64_t* stats, void* ws, size_t ws_bytes, ff_stream_t stream);
+                   int32_t* order, int32_t* inv, int64_t* stats, void* ws, size_t ws_bytes, ff_stream_t stream);
 
 /* ---- K1: adjacent-pair cosine similarity ----------------------------------------------------
  * Replaces the two [Nv-1, d] gathers + cosine_similarity + boundary fill (main.py:216-238,
@@ -109,7 +117,11 @@ int ff_pair_similarity(const void* hidden, int dtype, int64_t L, int64_t d,
  *   dst     [L] int32 : for each SEQUENCE position i: its row in the compacted output, or -1;
  *   keep    [L] uint8 : the keep mask of main.py:278-279 by sequence position;
  *   stats             : FF_STAT_COUNT .. FF_STAT_TIES_TAKEN, FF_STAT_LOUT, FF_STAT_MERGED.
- * dst, keep and ws must be 16-byte aligned; ws >= ff_workspace_bytes(). */
+ * sim, order, dst, keep and ws must be 16-byte aligned (member 8); ws >= ff_workspace_bytes().
+ * L < 983 040 (one workgroup per 4096 tokens, all resident: each publishes its kept count as one
+ * 8-byte {tag, count} word and sums its predecessors' - no other inter-workgroup traffic).
+ * Stand-alone form: builds the select tables and the inverse order itself (extra launches); the fused
+ * step gets both from its producers. */
 int ff_plan_merge(const void* sim, int dtype, const int32_t* order, int64_t L,
                   double threshold, double sub, double ratio_lb,
                   uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
@@ -227,22 +239,24 @@ int ff_patch_type_from_mask(const uint8_t* mask, int64_t n, int64_t patch_num, i
  * device-visible pinned host pointer that receives a copy of the stats block, its FF_STAT_SEQ
  * word written last with `seq`, so the host can poll instead of synchronising the stream.
  * Workspace protocol, layout hint, identity calls and order_next as for ff_merge_begin /
- * ff_merge_finish below.  One host call = five launches issued back to back: the form to use when
+ * ff_merge_finish below.  One host call = three launches issued back to back: the form to use when
  * the sequence is short enough that the host, not the similarity pass, would set the pace. */
 int ff_merge_step(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
                   const int64_t* patch_type, int64_t patch_num, int order_valid,
                   double threshold, double sub, double ratio_lb,
-                  int32_t* order, void* sim, uint8_t* member, int32_t* dst, uint8_t* keep,
+                  int32_t* order, int32_t* inv, void* sim, uint8_t* member, int32_t* dst, uint8_t* keep,
                   int64_t* stats, int64_t* stats_host_mapped, int64_t seq,
                   const ff_aux_t* aux_host, int n_aux,
-                  int64_t hint_pre, int64_t hint_frames, int32_t* order_next,
+                  int64_t hint_pre, int64_t hint_frames, int32_t* order_next, int32_t* inv_next,
                   void* ws, size_t ws_bytes, ff_stream_t stream);
 
 /* The same step in two halves, so the host can allocate the output tensors while the first
  * streaming pass runs: begin = K0 (unless order_valid) + K1, finish = K2+K3 + K4.  `ws` must be the
- * SAME zero-initialised workspace for every call of a sequence and `seq` must increase by one per
- * call: the similarity kernel accumulates the select's level-0 statistics into the table of parity
- * (seq & 1) and the scan kernel of the call clears the other table for the next call.
+ * SAME zero-initialised workspace for every call of a sequence (see ff_workspace_bytes) and `seq` a
+ * number that differs from call to call (it is echoed in the published result block): the similarity
+ * kernel accumulates the select tables of the call, the plan kernel consumes them and the merge
+ * kernel clears them for the next call.  `inv` is the inverse of `order` (both [L] int32, both written
+ * by begin unless order_valid).
  * Layout hint (hint_frames > 0, only looked at when order_valid == 0): the caller expects the
  * frame-major layout the reference's packers produce - hint_frames frames of patch_num visual
  * tokens typed 0..patch_num-1 behind hint_pre other tokens, TEXT (-1) everywhere else
@@ -255,19 +269,20 @@ int ff_merge_step(const void* hidden, void* hidden_out, int dtype, int64_t L, in
  * threshold set, main.py:264-266) the reduced sequence IS the input: the merge kernel exits without
  * writing hidden_out, the aux outputs or order_next, and stats[NV]/[FTN] stay as they are - the
  * caller keeps using its input tensors and its current `order`.
- * order_next (optional, [L] int32): receives the by-patch order of the COMPACTED sequence and
- * stats[NV]/stats[FTN] are advanced to it, so the next merge call on the reduced sequence can pass
- * it as `order` with order_valid = 1 and skip K0 (surviving tokens keep their relative order). */
+ * order_next / inv_next (optional, both or neither, [L] int32): receive the by-patch order of the
+ * COMPACTED sequence and its inverse, and stats[NV]/stats[FTN] are advanced to it, so the next merge
+ * call on the reduced sequence can pass them as `order` / `inv` with order_valid = 1 and skip K0
+ * (surviving tokens keep their relative order). */
 int ff_merge_begin(const void* hidden, int dtype, int64_t L, int64_t d,
                    const int64_t* patch_type, int64_t patch_num, int order_valid, double threshold,
-                   int32_t* order, void* sim, int64_t* stats, int64_t seq,
+                   int32_t* order, int32_t* inv, void* sim, int64_t* stats, int64_t seq,
                    int64_t hint_pre, int64_t hint_frames, void* ws, size_t ws_bytes,
                    ff_stream_t stream);
 int ff_merge_finish(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
                     double threshold, double sub, double ratio_lb,
-                    const int32_t* order, const void* sim, uint8_t* member, int32_t* dst, uint8_t* keep,
-                    int64_t* stats, int64_t* stats_host_mapped, int64_t seq,
-                    const ff_aux_t* aux_host, int n_aux, int32_t* order_next,
+                    const int32_t* order, const int32_t* inv, const void* sim, uint8_t* member, int32_t* dst,
+                    uint8_t* keep, int64_t* stats, int64_t* stats_host_mapped, int64_t seq,
+                    const ff_aux_t* aux_host, int n_aux, int32_t* order_next, int32_t* inv_next,
                     void* ws, size_t ws_bytes, ff_stream_t stream);
 
 /* ff_merge_finish for the fixed-sparsity baseline: top-k with the caller's k instead of the
@@ -275,9 +290,9 @@ int ff_merge_finish(const void* hidden, void* hidden_out, int dtype, int64_t L, 
  * each run with .mean(dim=1), modeling_qwen2_baseline.py:1034-1048).  Same workspace protocol. */
 int ff_merge_finish_topk(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
                          int64_t k, int fold,
-                         const int32_t* order, const void* sim, uint8_t* member, int32_t* dst, uint8_t* keep,
-                         int64_t* stats, int64_t* stats_host_mapped, int64_t seq,
-                         const ff_aux_t* aux_host, int n_aux, int32_t* order_next,
+                         const int32_t* order, const int32_t* inv, const void* sim, uint8_t* member, int32_t* dst,
+                         uint8_t* keep, int64_t* stats, int64_t* stats_host_mapped, int64_t seq,
+                         const ff_aux_t* aux_host, int n_aux, int32_t* order_next, int32_t* inv_next,
                          void* ws, size_t ws_bytes, ff_stream_t stream);
 
 /* One FrameFusion.forward prune call (main.py:61-101) from a single host call: head mean of the

@@ -48,10 +48,10 @@ int main(int argc, char** argv) {
         }
         if (vis) pt[i] = (i - pre) % P;
     }
-    void *dh, *dout, *dpt, *dorder, *dsim, *dmember, *ddst, *dkeep, *dstats, *dws, *dpt_out;
+    void *dh, *dout, *dpt, *dorder, *dinv, *dsim, *dmember, *ddst, *dkeep, *dstats, *dws, *dpt_out;
     const size_t wsb = ff_workspace_bytes(L, P);
     CK(hipMalloc(&dh, h.size() * 2)); CK(hipMalloc(&dout, h.size() * 2)); CK(hipMalloc(&dpt, L * 8)); CK(hipMalloc(&dpt_out, L * 8));
-    CK(hipMalloc(&dorder, L * 4)); CK(hipMalloc(&dsim, L * 4)); CK(hipMalloc(&dmember, L)); CK(hipMalloc(&ddst, L * 4));
+    CK(hipMalloc(&dorder, L * 4)); CK(hipMalloc(&dinv, L * 4)); CK(hipMalloc(&dsim, L * 4)); CK(hipMalloc(&dmember, L)); CK(hipMalloc(&ddst, L * 4));
     CK(hipMalloc(&dkeep, L)); CK(hipMalloc(&dstats, FF_STAT_WORDS * 8)); CK(hipMalloc(&dws, wsb));
     CK(hipMemcpy(dh, h.data(), h.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(dpt, pt.data(), L * 8, hipMemcpyHostToDevice));
@@ -61,8 +61,8 @@ int main(int argc, char** argv) {
     ff_aux_t aux[1] = {{dpt, dpt_out, 8, 1}};
     const double thr = 0.6015625;                                        // bf16(0.6), main.py:113
     FF(ff_merge_step(dh, dout, FF_BF16, L, d, L, (const int64_t*)dpt, P, /*order_valid=*/0, thr, /*sub=*/0.7, /*ratio_lb=*/0.1,
-                     (int32_t*)dorder, dsim, (uint8_t*)dmember, (int32_t*)ddst, (uint8_t*)dkeep, (int64_t*)dstats, nullptr,
-                     /*seq=*/1, aux, 1, /*hint_pre=*/0, /*hint_frames=*/0, /*order_next=*/nullptr, dws, wsb, st));
+                     (int32_t*)dorder, (int32_t*)dinv, dsim, (uint8_t*)dmember, (int32_t*)ddst, (uint8_t*)dkeep, (int64_t*)dstats, nullptr,
+                     /*seq=*/1, aux, 1, /*hint_pre=*/0, /*hint_frames=*/0, /*order_next=*/nullptr, /*inv_next=*/nullptr, dws, wsb, st));
     CK(hipStreamSynchronize(st));
     std::vector<int64_t> stats(FF_STAT_WORDS);
     std::vector<uint8_t> keep(L);

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(_lib.LIB_PATH)
     for name in declared_functions():
         assert hasattr(lib, name), name
-    assert _lib.load().ff_abi_version() == _lib.ABI_VERSION == 3
+    assert _lib.load().ff_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_stat_enum_matches_binding():
@@ -54,7 +54,7 @@ def test_error_strings_and_workspace():
 def test_argument_validation_without_gpu():
     lib = _lib.load()
     # null pointers / bad sizes are rejected before anything is enqueued
-    assert lib.ff_build_order(None, 10, 4, None, None, None, 0, None) == -1
+    assert lib.ff_build_order(None, 10, 4, None, None, None, None, 0, None) == -1
     assert lib.ff_pair_similarity(None, 1, 10, 64, None, None, None, None, None) == -1
     assert lib.ff_pair_similarity(16, 7, 10, 64, 16, 16, 16, 16, None) == -1          # unknown dtype
     assert lib.ff_pair_similarity(16, 1, 10, 3, 16, 16, 16, 16, None) == -2           # 6-byte rows: alignment
@@ -66,7 +66,7 @@ def test_argument_validation_without_gpu():
     assert lib.ff_head_mean(None, 1, 4, 1, 10, None, None) == -1
     assert lib.ff_last_query_attention(16, 16, 1, 6, 4, 1, 10, 64, 0.1, 1, 16, None, 16, 1 << 20, None) == -1  # H % H_kv
     # empty problems are a no-op
-    assert lib.ff_build_order(16, 0, 4, 16, 16, 16, 1 << 20, None) == 0
+    assert lib.ff_build_order(16, 0, 4, 16, None, 16, 16, 1 << 24, None) == 0
     assert lib.ff_pair_similarity(16, 1, 0, 64, 16, 16, 16, 16, None) == 0
 
 

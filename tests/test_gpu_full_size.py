@@ -162,8 +162,10 @@ def test_128_frames_cascade_and_large_ragged_order():
             stats = torch.zeros(_lib.STAT_WORDS, dtype=torch.int64, device=DEV)
             wsb = int(lib.ff_workspace_bytes(n, P))
             ws = torch.zeros(wsb, dtype=torch.uint8, device=DEV)
-            _lib.check(lib.ff_build_order(f.patch_type.data_ptr(), n, P, order.data_ptr(), stats.data_ptr(),
-                                          ws.data_ptr(), wsb, _lib.stream_ptr()), "ff_build_order")
+            inv = torch.empty(n, dtype=torch.int32, device=DEV)
+            _lib.check(lib.ff_build_order(f.patch_type.data_ptr(), n, P, order.data_ptr(), inv.data_ptr(),
+                                          stats.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr()), "ff_build_order")
+            assert torch.equal(inv[order.long()].cpu(), torch.arange(n, dtype=torch.int32))    # inv is the inverse permutation
             want, _ = orc.by_patch_order(o.patch_type, P)
             nv = want.numel()
             assert int(stats[_lib.STAT_NV]) == nv

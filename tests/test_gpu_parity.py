@@ -37,9 +37,11 @@ def hip_order(pt, P):
     stats = torch.zeros(_lib.STAT_WORDS, dtype=torch.int64, device=DEV)
     wsb = int(lib.ff_workspace_bytes(L, P))
     ws = torch.zeros(wsb, dtype=torch.uint8, device=DEV)
-    _lib.check(lib.ff_build_order(ptd.data_ptr(), L, P, order.data_ptr(), stats.data_ptr(), ws.data_ptr(), wsb,
-                                  _lib.stream_ptr()), "ff_build_order")
+    inv = torch.full((L,), -7, dtype=torch.int32, device=DEV)
+    _lib.check(lib.ff_build_order(ptd.data_ptr(), L, P, order.data_ptr(), inv.data_ptr(), stats.data_ptr(), ws.data_ptr(),
+                                  wsb, _lib.stream_ptr()), "ff_build_order")
     torch.cuda.synchronize()
+    assert torch.equal(inv[order.long()].cpu(), torch.arange(L, dtype=torch.int32))        # the inverse permutation
     return order.cpu().long(), stats.cpu()
 
 

@@ -62,7 +62,7 @@ def main():
     thr = float(torch.tensor(0.6, dtype=dtype))
     sub = float(ff._compute_pruning_ratio([], 0.3))
     stages = {
-        "order": (lambda: lib.ff_build_order(ptype.data_ptr(), L, P, order_buf.data_ptr(), sc.stats.data_ptr(), sc.ws.data_ptr(), sc.ws_bytes, stream),
+        "order": (lambda: lib.ff_build_order(ptype.data_ptr(), L, P, order_buf.data_ptr(), None, sc.stats.data_ptr(), sc.ws.data_ptr(), sc.ws_bytes, stream),
                   8 * L + 4 * L),
         "similarity": (lambda: lib.ff_pair_similarity(hidden.data_ptr(), code, L, d, ptype.data_ptr(), order_buf.data_ptr(),
                                                       sc.stats.data_ptr(), sim.data_ptr(), stream), nv * d * elt),
