@@ -13,6 +13,7 @@ namespace ff {
 constexpr int kWave = 64;  // gfx950 wavefront
 
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // ---- raw buffer access (SRSRC): a wave-uniform base + byte count; lanes past the end read 0 and
@@ -75,6 +76,26 @@ template <> struct Act<FF_BF16> {
     __device__ static inline float load1(const void* p, int64_t idx) {
         return __uint_as_float((uint32_t)((const uint16_t*)p)[idx] << 16);
     }
+    // acc + a.lo*b.lo + a.hi*b.hi on packed pairs (v_dot2c_f32_bf16: products of two bf16 are exact in fp32)
+    __device__ static inline float dot2(uint32_t a, uint32_t b, float acc) {
+        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), acc, false);
+    }
+    // acc + sum of squares of the 8 values of a 16-byte word: no unpacking
+    __device__ static inline float sumsq(const uint4& v, float acc) {
+        acc = dot2(v.x, v.x, acc); acc = dot2(v.y, v.y, acc); acc = dot2(v.z, v.z, acc); return dot2(v.w, v.w, acc);
+    }
+    // acc + sum_i T(prev_i * x_i): fp32 products rounded pairwise to bf16 (v_cvt_pk_bf16_f32), summed by
+    // one dot2 with (1, 1) per pair instead of two unpacks + two adds
+    __device__ static inline float dot_rounded(const float* prev, const float* x, float acc) {
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            bf16x2_t pr;
+            pr.x = (__bf16)(prev[e] * x[e]);
+            pr.y = (__bf16)(prev[e + 1] * x[e + 1]);
+            acc = __builtin_amdgcn_fdot2_f32_bf16(pr, __builtin_bit_cast(bf16x2_t, 0x3f803f80u), acc, false);
+        }
+        return acc;
+    }
     __device__ static inline void store1(void* p, int64_t idx, float x) {
         ((uint16_t*)p)[idx] = (uint16_t)(__float_as_uint(rnd(x)) >> 16);
     }
@@ -102,6 +123,23 @@ template <> struct Act<FF_F16> {
     }
     __device__ static inline float load1(const void* p, int64_t idx) { return (float)((const _Float16*)p)[idx]; }
     __device__ static inline void store1(void* p, int64_t idx, float x) { ((_Float16*)p)[idx] = (_Float16)x; }
+    __device__ static inline float dot2(uint32_t a, uint32_t b, float acc) {
+        return __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, a), __builtin_bit_cast(half2_t, b), acc, false);
+    }
+    __device__ static inline float sumsq(const uint4& v, float acc) {
+        acc = dot2(v.x, v.x, acc); acc = dot2(v.y, v.y, acc); acc = dot2(v.z, v.z, acc); return dot2(v.w, v.w, acc);
+    }
+    // acc + sum_i T(a_i * b_i) on raw words: the packed fp16 multiply rounds each (exact) product once,
+    // exactly T(a*b); a dot2 with (1, 1) adds the pair
+    __device__ static inline float dot_rounded_raw(const uint4& a, const uint4& b, float acc) {
+        const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const half2_t pr = __builtin_bit_cast(half2_t, aw[e]) * __builtin_bit_cast(half2_t, bw[e]);
+            acc = __builtin_amdgcn_fdot2(pr, __builtin_bit_cast(half2_t, 0x3c003c00u), acc, false);
+        }
+        return acc;
+    }
     __device__ static inline uint32_t bits1(const void* p, int64_t idx) { return ((const uint16_t*)p)[idx]; }
 };
 

@@ -10,7 +10,7 @@ rows = [r for r in rows if "ff::" in r["Kernel_Name"]]     # (memset / fill kern
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 def short(n):
     n = n.replace("void ", "")
-    return n.split("<")[0].split("(")[0].replace("ff::", "").replace("k_plan_fast", "k_plan")
+    return n.split("<")[0].split("(")[0].replace("ff::", "").replace("k_plan_fast", "k_plan").replace("k_pair_similarity_tile", "k_pair_similarity")
 # a call = a maximal run of kernels ending with k_merge_compact; the product's merge call is either
 # K0 (two launches) + similarity + hist + flags + scan + merge, or - with a layout hint - starts at
 # the similarity kernel
