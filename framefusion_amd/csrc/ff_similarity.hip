@@ -13,8 +13,6 @@
 // Rounding recipe, T = activation dtype:
 //     dot = T(sum_fp32 T(a_i*b_i));  na = T(sqrt_fp32(sum_fp32 a_i^2));  sim = T(dot / T(na*nb))
 // sqrt and divide are the correctly rounded fp32 forms (hipcc default).
-#include <stdlib.h>
-
 #include "ff_common.h"
 
 namespace ff {
@@ -210,184 +208,6 @@ __global__ __launch_bounds__(kSimThreads) void k_pair_similarity(
     }
 }
 
-// ---- tile variant ---------------------------------------------------------------------------------------
-// One ROW per wave (the access pattern this chip reads fastest: tools/membench "rows R=1", 6.05 TB/s
-// against 5.4 for five rows side by side), the pair partner through LDS: a workgroup of 16 waves owns 16
-// consecutive by-patch slots; wave w streams row order[j0 + w] with up to 8 KiB in flight, and for every
-// 1 KiB tile drops its 16 bytes per lane into an LDS ring slot that wave w + 1 reads back (double
-// buffered: one barrier per tile).  Wave 0 also streams the row before the group (the only re-read: 1 row
-// in 17).  Norms travel the same way at the end; the group's 16 similarities feed the select tables from
-// ONE wave (16 values folded per atomic instead of 4).
-constexpr int kTileWaves = 16;
-constexpr int kTileThreads = kTileWaves * kWave;
-constexpr int kTileDepth = 8;                     // 16-byte words per lane in flight per row (8 KiB)
-
-template <int DT>
-__device__ inline void pair_tile(const uint4& pv, const uint4& v, float& nrm, float& dot) {
-    using A = Act<DT>;
-    if constexpr (DT == FF_BF16) {
-        float a[8], b[8];
-        nrm = A::sumsq(v, nrm);
-        A::unpack(pv, a);
-        A::unpack(v, b);
-        dot = A::dot_rounded(a, b, dot);
-    } else if constexpr (DT == FF_F16) {
-        nrm = A::sumsq(v, nrm);
-        dot = A::dot_rounded_raw(pv, v, dot);
-    } else {
-        float a[4], b[4];
-        A::unpack(pv, a);
-        A::unpack(v, b);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            nrm = __builtin_fmaf(b[e], b[e], nrm);
-            dot += a[e] * b[e];
-        }
-    }
-}
-
-template <int DT>
-__device__ inline float sumsq_tile(const uint4& v, float nrm) {
-    using A = Act<DT>;
-    if constexpr (DT == FF_F32) {
-        float b[4];
-        A::unpack(v, b);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) nrm = __builtin_fmaf(b[e], b[e], nrm);
-        return nrm;
-    } else {
-        return A::sumsq(v, nrm);
-    }
-}
-
-template <int DT, bool kHint>
-__global__ __launch_bounds__(kTileThreads) void k_pair_similarity_tile(
-    const char* __restrict__ hidden, uint32_t row_bytes, const int64_t* __restrict__ ptype,
-    const int32_t* __restrict__ order, const int64_t* __restrict__ stats, void* __restrict__ sim,
-    int* __restrict__ l0, int* t16_end, float thr, const LayoutHint hint, int32_t* __restrict__ order_out,
-    int32_t* __restrict__ inv_out, int64_t* __restrict__ stats_out) {
-    using A = Act<DT>;
-    __shared__ uint4 ring[2][kTileWaves + 1][kWave];          // 34 KiB
-    __shared__ float nrm_sh[kTileWaves + 1];
-    __shared__ float sim_sh[kTileWaves];
-    const int lane = lane_id(), w = wave_id();
-    int nv;
-    if constexpr (kHint) {
-        nv = hint.patches * hint.frames;
-        // the non-visual tail of `order` (positions in sequence order) + their type check
-        const int n_tail = hint.L - nv;
-        const int gtid = blockIdx.x * kTileThreads + threadIdx.x;
-        for (int q = gtid; q < n_tail; q += (int)gridDim.x * kTileThreads) {
-            const int i = q < hint.pre ? q : q + nv;
-            if (ptype[i] != -1) atomicOr((unsigned long long*)(stats_out + FF_STAT_ERROR), (unsigned long long)FF_ERR_BIT_LAYOUT);
-            order_out[nv + q] = i;
-            if (inv_out) inv_out[i] = nv + q;
-        }
-        if (gtid == 0) {
-            stats_out[FF_STAT_NV] = nv;
-            stats_out[FF_STAT_FTN] = nv;
-        }
-    } else {
-        nv = (int)stats[FF_STAT_NV];
-    }
-    const int j0 = blockIdx.x * kTileWaves;
-    if (j0 >= nv) return;                                   // (whole workgroup)
-    const int j = min(j0 + w, nv - 1);                      // idle waves of the last group shadow the last slot
-    const bool active = j0 + w < nv;
-    // my row (and, for wave 0, the row before the group)
-    int row_i, halo_i, my_p = 0, my_f = 0;
-    if constexpr (kHint) {
-        const int F = hint.frames, P = hint.patches;
-        my_p = j / F; my_f = j - my_p * F;
-        row_i = hint.pre + my_f * P + my_p;
-        const int jh = max(j0 - 1, 0), ph = jh / F, fh = jh - ph * F;
-        halo_i = hint.pre + fh * P + ph;
-    } else {
-        row_i = uniform(order[j]);
-        halo_i = uniform(order[max(j0 - 1, 0)]);
-    }
-    const __amdgpu_buffer_rsrc_t mine = make_rsrc(hidden + (int64_t)row_i * row_bytes, row_bytes);
-    const __amdgpu_buffer_rsrc_t halo = make_rsrc(hidden + (int64_t)halo_i * row_bytes, w == 0 ? row_bytes : 0u);
-    int64_t my_type = 0, prev_type = 0;
-    if (lane == 0) {
-        if constexpr (kHint) my_type = ptype[row_i];
-        else { my_type = ptype[row_i]; prev_type = j > 0 ? ptype[order[j - 1]] : -1; }
-    }
-    float nrm = 0.f, dot = 0.f, nrm_halo = 0.f;
-    const uint32_t lane_off = (uint32_t)lane * 16;
-    const int tiles = (int)((row_bytes + 1023u) >> 10);
-    for (int c0 = 0; c0 < tiles; c0 += kTileDepth) {
-        uint4 v[kTileDepth], hv[kTileDepth];
-#pragma unroll
-        for (int u = 0; u < kTileDepth; ++u) v[u] = buf_load16(mine, lane_off + (uint32_t)(c0 + u) * 1024u);     // past the end: zeros
-#pragma unroll
-        for (int u = 0; u < kTileDepth; ++u) hv[u] = buf_load16(halo, lane_off + (uint32_t)(c0 + u) * 1024u);    // (empty resource unless wave 0)
-#pragma unroll
-        for (int u = 0; u < kTileDepth; ++u) {
-            if (c0 + u < tiles) {                                   // (uniform)
-                const int b = (c0 + u) & 1;
-                ring[b][w + 1][lane] = v[u];
-                if (w == 0) ring[b][0][lane] = hv[u];
-                __syncthreads();
-                const uint4 pv = ring[b][w][lane];
-                pair_tile<DT>(pv, v[u], nrm, dot);
-                if (w == 0) nrm_halo = sumsq_tile<DT>(hv[u], nrm_halo);
-            }
-        }
-    }
-    nrm = wave_sum(nrm);
-    dot = wave_sum(dot);
-    if (w == 0) nrm_halo = wave_sum(nrm_halo);
-    if (lane == 0) {
-        nrm_sh[w + 1] = nrm;
-        if (w == 0) nrm_sh[0] = nrm_halo;
-    }
-    __syncthreads();
-    if (lane == 0) {
-        float s = -2.0f;   // IGNORE_TOKEN (main.py:225-238)
-        if (active) {
-            bool same_type;
-            if constexpr (kHint) {
-                if (my_type != (int64_t)my_p)
-                    atomicOr((unsigned long long*)(stats_out + FF_STAT_ERROR), (unsigned long long)FF_ERR_BIT_LAYOUT);
-                order_out[j] = row_i;
-                if (inv_out) inv_out[row_i] = j;
-                same_type = my_f != 0;                    // the previous slot is the same patch one frame earlier
-            } else {
-                same_type = j > 0 && prev_type == my_type;
-            }
-            if (same_type) {
-                const float d = A::rnd(dot);
-                const float na = A::rnd(sqrtf(nrm_sh[w]));
-                const float nb = A::rnd(sqrtf(nrm_sh[w + 1]));
-                const float den = A::rnd(na * nb);
-                s = A::rnd(d / den);
-            }
-            A::store1(sim, j, s);
-        }
-        sim_sh[w] = s;
-    }
-    if (l0) {
-        __syncthreads();
-        if (w == 0) {
-            // select statistics of the plan kernel that follows (ff_plan.hip), one wave for the group's 16 values
-            const bool have = lane < kTileWaves && j0 + lane < nv;
-            const float mine_s = have ? sim_sh[lane] : -2.0f;
-            uint32_t bits;
-            if constexpr (DT == FF_F32) bits = __float_as_uint(mine_s);
-            else if constexpr (DT == FF_BF16) bits = __float_as_uint(mine_s) >> 16;
-            else { _Float16 hh = (_Float16)mine_s; bits = (uint32_t)__builtin_bit_cast(uint16_t, hh); }
-            const uint32_t key = order_key<DT>(bits);
-            int* tab = l0 + (blockIdx.x & (kL0Copies - 1)) * kL0Stride;
-            const int n_ge = __popcll(__ballot(have && mine_s >= thr));
-            if (lane == 0 && n_ge) atomicAdd(&tab[256], n_ge);
-            wave_agg_add<4>(tab, key >> (A::kKeyBits - 8), have);
-            int* t16 = t16_slice(t16_end, j0 / kSelSlice) + (blockIdx.x & (kT16Copies - 1)) * 65536;
-            wave_agg_add<6>(t16, t16_bin(key >> (A::kKeyBits - 16)), have);
-        }
-    }
-}
-
 struct SimArgs {
     const void* hidden;
     int64_t L, d;
@@ -407,20 +227,6 @@ struct SimArgs {
 template <int DT, int kPairs, int kSimThreads>
 static int launch_similarity_pt(const SimArgs& a, hipStream_t st) {
     const int64_t row_bytes = a.d * Act<DT>::kBytes;
-    static int use_tile = -1;
-    if (use_tile < 0) { const char* e = getenv("FF_K1_TILE"); use_tile = e ? atoi(e) : 0; }
-    if (use_tile) {
-        const int64_t groups = (a.L + kTileWaves - 1) / kTileWaves;
-        if (a.hint.frames > 0)
-            hipLaunchKernelGGL((k_pair_similarity_tile<DT, true>), dim3((unsigned)groups), dim3(kTileThreads), 0, st,
-                               (const char*)a.hidden, (uint32_t)row_bytes, a.ptype, a.order, a.stats, a.sim, a.l0, a.t16_end, a.thr,
-                               a.hint, a.order_out, a.inv_out, a.stats_out);
-        else
-            hipLaunchKernelGGL((k_pair_similarity_tile<DT, false>), dim3((unsigned)groups), dim3(kTileThreads), 0, st,
-                               (const char*)a.hidden, (uint32_t)row_bytes, a.ptype, a.order, a.stats, a.sim, a.l0, a.t16_end, a.thr,
-                               a.hint, (int32_t*)nullptr, (int32_t*)nullptr, (int64_t*)nullptr);
-        return (int)hipGetLastError();
-    }
     const int64_t per_block = (int64_t)(kSimThreads / kWave) * kPairs;
     const int64_t blocks = (a.L + per_block - 1) / per_block;
     if (a.hint.frames > 0)
@@ -435,18 +241,7 @@ static int launch_similarity_pt(const SimArgs& a, hipStream_t st) {
 }
 
 template <int DT>
-static int launch_similarity(const SimArgs& a, hipStream_t st) {
-    static int pairs = -1;
-    if (pairs < 0) { const char* e = getenv("FF_K1_PAIRS"); pairs = e ? atoi(e) : 4; }      // (experiment)
-    switch (pairs) {
-        case 1: return launch_similarity_pt<DT, 1, 256>(a, st);
-        case 2: return launch_similarity_pt<DT, 2, 256>(a, st);
-        case 3: return launch_similarity_pt<DT, 3, 256>(a, st);
-        case 12: return launch_similarity_pt<DT, 2, 512>(a, st);
-        case 11: return launch_similarity_pt<DT, 1, 512>(a, st);
-        default: return launch_similarity_pt<DT, 4, 256>(a, st);
-    }
-}
+static int launch_similarity(const SimArgs& a, hipStream_t st) { return launch_similarity_pt<DT, 4, 256>(a, st); }
 
 // hint_frames > 0: frame-major closed form (see LayoutHint); `order` and `stats` are then outputs.
 int launch_similarity_any(const void* hidden, int dtype, int64_t L, int64_t d, const int64_t* ptype,
