@@ -28,7 +28,7 @@ STAT_ERROR = 11
 ERR_BIT_BARRIER, ERR_BIT_LAYOUT = 1, 2
 STAT_WORDS = 32
 MAX_AUX = 4
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class FFAux(C.Structure):
@@ -61,11 +61,11 @@ PROTOTYPES = {
     "ff_head_mean": (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _vp]),
     "ff_last_query_attention": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _i64, _i64, _f64, _i32, _vp, _vp, _vp,
                                        _sz, _vp]),
-    "ff_merge_begin": (_i32, [_vp, _i32, _i64, _i64, _vp, _i64, _i32, _f64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _sz,
+    "ff_merge_begin": (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _i64, _i32, _f64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _sz,
                               _vp]),
-    "ff_merge_finish": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+    "ff_merge_finish": (_i32, [_vp, _vp, _vp, _i32, _i64, _i64, _i64, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                _i64, C.POINTER(FFAux), _i32, _vp, _vp, _vp, _sz, _vp]),
-    "ff_prune_step": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _i32, _i64, _i64, _vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp,
+    "ff_prune_step": (_i32, [_vp, _vp, _vp, _i32, _i64, _i64, _i64, _vp, _i32, _i64, _i64, _vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp,
                              _vp, C.POINTER(FFAux), _i32, _vp, _sz, _vp]),
     "ff_plan_topk": (_i32, [_vp, _i32, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ff_merge_finish_topk": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -73,7 +73,7 @@ PROTOTYPES = {
     "ff_token_span": (_i32, [_vp, _i64, _i64, _vp, _vp]),
     "ff_fill_patch_type": (_i32, [_vp, _i64, C.POINTER(FFSegment), _i64, _vp]),
     "ff_patch_type_from_mask": (_i32, [_vp, _i64, _i64, _vp, _vp, _vp]),
-    "ff_merge_step": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _i64, _i32, _f64, _f64, _f64, _vp, _vp, _vp, _vp,
+    "ff_merge_step": (_i32, [_vp, _vp, _vp, _i32, _i64, _i64, _i64, _vp, _i64, _i32, _f64, _f64, _f64, _vp, _vp, _vp, _vp,
                              _vp, _vp, _vp, _vp, _i64, C.POINTER(FFAux), _i32, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
 }
 

@@ -124,7 +124,7 @@ class FixedSparsityMerging:
         sc.seq += 1
         seq = sc.seq
         sc.dirty = True
-        _lib.check(lib.ff_merge_begin(hidden.data_ptr(), code, L, d, ptype.data_ptr(), int(self.patch_num), order_valid,
+        _lib.check(lib.ff_merge_begin(hidden.data_ptr(), None, code, L, d, ptype.data_ptr(), int(self.patch_num), order_valid,
                                       0.0, sc.order.data_ptr(), sc.inv.data_ptr(), sc.sim32.data_ptr(), sc.stats.data_ptr(),
                                       seq, 0, 0,
                                       sc.ws.data_ptr(), sc.ws_bytes, stream), "ff_merge_begin")

@@ -17,12 +17,12 @@ int* ws_l0(void* ws);
 int* ws_t16_end(void* ws, size_t ws_bytes);
 void table_regions(void* ws, size_t ws_bytes, int64_t L, void** a, size_t* a_bytes, void** b, size_t* b_bytes);
 int zero_tables(void* ws, size_t ws_bytes, int64_t L, hipStream_t st);
-int launch_merge_compact(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
+int launch_merge_compact(const void* hidden, const void* addend, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
                          const int32_t* order, const uint8_t* member, int fold, const int32_t* dst,
                          const uint8_t* keep, const ff_aux_t* aux_host, int n_aux, int32_t* order_next,
                          int32_t* inv_next, int64_t* stats, hipStream_t st, bool skip_identity, void* zero_a,
                          size_t zero_a_bytes, const void* zero_keys, int64_t zero_n, int zero_key_dt, int* t16_end);
-int launch_similarity_any(const void* hidden, int dtype, int64_t L, int64_t d, const int64_t* ptype,
+int launch_similarity_any(const void* hidden, const void* addend, int dtype, int64_t L, int64_t d, const int64_t* ptype,
                           int32_t* order, int32_t* inv, int64_t* stats, void* sim, int* l0, int* t16_end, double thr,
                           int64_t hint_pre, int64_t hint_patches, int64_t hint_frames, hipStream_t st);
 int launch_head_mean(const void* attn_w, int dtype, int64_t H, int64_t num, int64_t S, void* importance,
@@ -50,7 +50,7 @@ extern "C" size_t ff_workspace_bytes(int64_t L, int64_t patch_num) {
     return ff::plan_ws_front_bytes(L) + ((size_t)(L / 4096) + 1) * 64 + 256 + ff::plan_ws_tail_bytes(L);
 }
 
-extern "C" int ff_merge_begin(const void* hidden, int dtype, int64_t L, int64_t d, const int64_t* patch_type,
+extern "C" int ff_merge_begin(const void* hidden, const void* addend, int dtype, int64_t L, int64_t d, const int64_t* patch_type,
                               int64_t patch_num, int order_valid, double threshold, int32_t* order, int32_t* inv,
                               void* sim, int64_t* stats, int64_t seq, int64_t hint_pre, int64_t hint_frames, void* ws,
                               size_t ws_bytes, ff_stream_t stream) {
@@ -58,7 +58,7 @@ extern "C" int ff_merge_begin(const void* hidden, int dtype, int64_t L, int64_t 
     if (ws_bytes < ff_workspace_bytes(L, patch_num)) return FF_ERR_WORKSPACE;
     if (dtype != FF_F32 && dtype != FF_BF16 && dtype != FF_F16) return FF_ERR_ARG;
     const int64_t esz = dtype == FF_F32 ? 4 : 2;
-    if (((uintptr_t)hidden & 15) || ((d * esz) & 15) || ((uintptr_t)ws & 15)) return FF_ERR_ALIGN;
+    if (((uintptr_t)hidden & 15) || ((uintptr_t)addend & 15) || ((d * esz) & 15) || ((uintptr_t)ws & 15)) return FF_ERR_ALIGN;
     if (L >= (1ll << 31) || d * esz >= (1ll << 31)) return FF_ERR_UNSUPPORTED;
     // frame-major hint: the similarity kernel derives (and verifies) the order itself, K0 is skipped
     const bool hinted = !order_valid && hint_frames > 0 && hint_pre >= 0 && patch_num >= 1 &&
@@ -71,14 +71,14 @@ extern "C" int ff_merge_begin(const void* hidden, int dtype, int64_t L, int64_t 
     // the similarity kernel also accumulates the select tables of this call (zero on entry: cleared by
     // the previous call's merge kernel)
     (void)seq;
-    return ff::launch_similarity_any(hidden, dtype, L, d, patch_type, order, inv, stats, sim, ff::ws_l0(ws),
+    return ff::launch_similarity_any(hidden, addend, dtype, L, d, patch_type, order, inv, stats, sim, ff::ws_l0(ws),
                                      ff::ws_t16_end(ws, ws_bytes), threshold, hint_pre, patch_num,
                                      hinted ? hint_frames : 0, (hipStream_t)stream);
 }
 
 // second half of a merge call: select (policy or forced k) + run merge (fold 1: main.py's sequential
 // rounding, 2: the baseline's fp32 mean) + compaction
-static int merge_finish(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
+static int merge_finish(const void* hidden, const void* addend, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
                         double threshold, double sub, double ratio_lb, long long force_k, int fold,
                         const int32_t* order, const int32_t* inv, const void* sim, uint8_t* member, int32_t* dst,
                         uint8_t* keep, int64_t* stats, int64_t* stats_host_mapped, int64_t seq, const ff_aux_t* aux_host,
@@ -91,7 +91,7 @@ static int merge_finish(const void* hidden, void* hidden_out, int dtype, int64_t
     if (dtype != FF_F32 && dtype != FF_BF16 && dtype != FF_F16) return FF_ERR_ARG;
     if (n_aux < 0 || n_aux > FF_MAX_AUX || (n_aux > 0 && !aux_host)) return FF_ERR_ARG;
     const int64_t esz = dtype == FF_F32 ? 4 : 2;
-    if (((uintptr_t)hidden & 15) || ((uintptr_t)hidden_out & 15) || ((d * esz) & 15)) return FF_ERR_ALIGN;
+    if (((uintptr_t)hidden & 15) || ((uintptr_t)addend & 15) || ((uintptr_t)hidden_out & 15) || ((d * esz) & 15)) return FF_ERR_ALIGN;
     if (order_next && ((uintptr_t)member & 15)) return FF_ERR_ALIGN;
     if (L == 0) return FF_OK;
     if (((uintptr_t)member & 7) || ((uintptr_t)dst & 15) || ((uintptr_t)keep & 15) || ((uintptr_t)order & 15) ||
@@ -105,17 +105,17 @@ static int merge_finish(const void* hidden, void* hidden_out, int dtype, int64_t
     void *za, *zb;
     size_t zab, zbb;
     ff::table_regions(ws, ws_bytes, L, &za, &zab, &zb, &zbb);
-    return ff::launch_merge_compact(hidden, hidden_out, dtype, L, d, L_cap, order, member, fold, dst, keep, aux_host,
+    return ff::launch_merge_compact(hidden, addend, hidden_out, dtype, L, d, L_cap, order, member, fold, dst, keep, aux_host,
                                     n_aux, order_next, inv_next, stats, (hipStream_t)stream, true, za, zab, sim, L, dtype,
                                     ff::ws_t16_end(ws, ws_bytes));
 }
 
-extern "C" int ff_merge_finish(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
+extern "C" int ff_merge_finish(const void* hidden, const void* addend, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
                                double threshold, double sub, double ratio_lb, const int32_t* order, const int32_t* inv,
                                const void* sim, uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
                                int64_t* stats_host_mapped, int64_t seq, const ff_aux_t* aux_host, int n_aux,
                                int32_t* order_next, int32_t* inv_next, void* ws, size_t ws_bytes, ff_stream_t stream) {
-    return merge_finish(hidden, hidden_out, dtype, L, d, L_cap, threshold, sub, ratio_lb, -1, FF_FOLD_SEQUENTIAL, order, inv,
+    return merge_finish(hidden, addend, hidden_out, dtype, L, d, L_cap, threshold, sub, ratio_lb, -1, FF_FOLD_SEQUENTIAL, order, inv,
                         sim, member, dst, keep, stats, stats_host_mapped, seq, aux_host, n_aux, order_next, inv_next, ws,
                         ws_bytes, stream);
 }
@@ -127,25 +127,25 @@ extern "C" int ff_merge_finish_topk(const void* hidden, void* hidden_out, int dt
                                     int32_t* order_next, int32_t* inv_next, void* ws, size_t ws_bytes,
                                     ff_stream_t stream) {
     if (k < 0 || (fold != FF_FOLD_SEQUENTIAL && fold != FF_FOLD_MEAN)) return FF_ERR_ARG;
-    return merge_finish(hidden, hidden_out, dtype, L, d, L_cap, 0.0, 0.0, 0.0, k, fold, order, inv, sim, member, dst, keep,
+    return merge_finish(hidden, nullptr, hidden_out, dtype, L, d, L_cap, 0.0, 0.0, 0.0, k, fold, order, inv, sim, member, dst, keep,
                         stats, stats_host_mapped, seq, aux_host, n_aux, order_next, inv_next, ws, ws_bytes, stream);
 }
 
-extern "C" int ff_merge_step(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
+extern "C" int ff_merge_step(const void* hidden, const void* addend, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
                              const int64_t* patch_type, int64_t patch_num, int order_valid, double threshold,
                              double sub, double ratio_lb, int32_t* order, int32_t* inv, void* sim, uint8_t* member,
                              int32_t* dst, uint8_t* keep, int64_t* stats, int64_t* stats_host_mapped,
                              int64_t seq, const ff_aux_t* aux_host, int n_aux, int64_t hint_pre,
                              int64_t hint_frames, int32_t* order_next, int32_t* inv_next, void* ws, size_t ws_bytes,
                              ff_stream_t stream) {
-    int rc = ff_merge_begin(hidden, dtype, L, d, patch_type, patch_num, order_valid, threshold, order, inv, sim, stats,
+    int rc = ff_merge_begin(hidden, addend, dtype, L, d, patch_type, patch_num, order_valid, threshold, order, inv, sim, stats,
                             seq, hint_pre, hint_frames, ws, ws_bytes, stream);
     if (rc) return rc;
-    return ff_merge_finish(hidden, hidden_out, dtype, L, d, L_cap, threshold, sub, ratio_lb, order, inv, sim, member, dst,
+    return ff_merge_finish(hidden, addend, hidden_out, dtype, L, d, L_cap, threshold, sub, ratio_lb, order, inv, sim, member, dst,
                            keep, stats, stats_host_mapped, seq, aux_host, n_aux, order_next, inv_next, ws, ws_bytes, stream);
 }
 
-extern "C" int ff_prune_step(const void* hidden, void* hidden_out, int dtype, int64_t S, int64_t d, int64_t L_cap,
+extern "C" int ff_prune_step(const void* hidden, const void* addend, void* hidden_out, int dtype, int64_t S, int64_t d, int64_t L_cap,
                              const void* attn_w, int w_dtype, int64_t H, int64_t num, void* importance,
                              int tables_ready,
                              int64_t start, int64_t n_img, int64_t k, uint8_t* member, int32_t* dst, uint8_t* keep,
@@ -179,8 +179,8 @@ extern "C" int ff_prune_step(const void* hidden, void* hidden_out, int dtype, in
     if (have_tables) ff::table_regions(ws, ws_bytes, S, &za, &zab, &zb, &zbb);
     (void)zb; (void)zbb;
     const int64_t esz = dtype == FF_F32 ? 4 : 2;
-    if (((uintptr_t)hidden & 15) || ((uintptr_t)hidden_out & 15) || ((d * esz) & 15)) return FF_ERR_ALIGN;
-    return ff::launch_merge_compact(hidden, hidden_out, dtype, S, d, L_cap, nullptr, member, FF_FOLD_DROP, dst, keep,
+    if (((uintptr_t)hidden & 15) || ((uintptr_t)addend & 15) || ((uintptr_t)hidden_out & 15) || ((d * esz) & 15)) return FF_ERR_ALIGN;
+    return ff::launch_merge_compact(hidden, addend, hidden_out, dtype, S, d, L_cap, nullptr, member, FF_FOLD_DROP, dst, keep,
                                     aux_host, n_aux, nullptr, nullptr, nullptr, st, false, za, zab, have_tables ? imp : nullptr,
                                     S, w_dtype, ff::ws_t16_end(ws, ws_bytes));
 }

@@ -143,6 +143,20 @@ template <> struct Act<FF_F16> {
     __device__ static inline uint32_t bits1(const void* p, int64_t idx) { return ((const uint16_t*)p)[idx]; }
 };
 
+// 16 bytes of T(a_i + b_i): the residual add the decoder performs before a reduction call
+// (framefusion/models/qwen2/modeling_qwen2.py:64-67), formed in registers: fp32 add, one rounding to T
+// (what torch's bf16 / fp16 add does).
+template <int DT>
+__device__ inline uint4 add16(const uint4& a, const uint4& b) {
+    using A = Act<DT>;
+    float x[A::kPer16], y[A::kPer16];
+    A::unpack(a, x);
+    A::unpack(b, y);
+#pragma unroll
+    for (int e = 0; e < A::kPer16; ++e) x[e] = A::rnd(x[e] + y[e]);
+    return A::pack(x);
+}
+
 // Order-preserving unsigned key of a T value given its raw bits: larger value <=> larger key;
 // every NaN maps to the maximum (torch.topk ranks NaN highest).
 template <int DT> __device__ inline uint32_t order_key(uint32_t bits);

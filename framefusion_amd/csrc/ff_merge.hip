@@ -60,9 +60,10 @@ __device__ inline void copy_row(const char* __restrict__ src, char* __restrict__
 // needed by the stores).  The additions stay sequential - a rounding after each - but the loads
 // do not wait for them.  Row pieces move as raw buffer loads/stores (lanes past the row end read
 // 0 / are dropped).
-template <int kDepth>
+template <int kDepth, bool kAdd>
 struct Batch {
     uint4 buf[kDepth];
+    uint4 buf2[kAdd ? kDepth : 1];   // the addend's pieces (kAdd: rows are T(hidden + addend))
     int idx[kDepth];       // sequence index of each row (wave-uniform)
     int pos, take;
     unsigned mem_bits;
@@ -91,9 +92,9 @@ __device__ inline void zero_by_key(const ZeroJob& z, int t) {
     for (int x = 0; x < kT16Copies; ++x) tab[x * 65536] = 0;
 }
 
-template <int DT>
+template <int DT, bool kAdd>
 __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
-    const char* __restrict__ hidden, char* __restrict__ out, uint32_t row_bytes, int L, int64_t L_cap,
+    const char* __restrict__ hidden, const char* __restrict__ addend, char* __restrict__ out, uint32_t row_bytes, int L, int64_t L_cap,
     const int32_t* __restrict__ order, const uint8_t* __restrict__ member, int fold,
     const int32_t* __restrict__ dst, const uint8_t* __restrict__ keep, AuxPack aux, int n_main,
     int n_aux_blocks, int n_next_blocks, int32_t* __restrict__ order_next, int32_t* __restrict__ inv_next,
@@ -200,9 +201,10 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
     if (starts == 0ull) return;                             // every slot here belongs to an earlier anchor
 
     auto piece = [&](int i) { return make_rsrc(hidden + (int64_t)i * row_bytes + col, blk_bytes); };
+    auto piece2 = [&](int i) { return make_rsrc((kAdd ? addend : hidden) + (int64_t)i * row_bytes + col, blk_bytes); };
 
     // request the next (up to) kDepth rows of the stream
-    auto issue = [&](Batch<kDepth>& b, int pos) {
+    auto issue = [&](Batch<kDepth, kAdd>& b, int pos) {
         if (pos - win > kWave - kDepth) {                   // keep kDepth slots of lookahead in the window
             win = pos;
             ordw = (pos + lane < L) ? (order ? order[pos + lane] : pos + lane) : 0;
@@ -223,7 +225,10 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
 #pragma unroll
         for (int u = 0; u < kDepth; ++u) {
             const bool is_mem = (mem_bits >> u) & 1u;
-            if (u < take && (fold || !is_mem)) b.buf[u] = buf_load16<2>(piece(b.idx[u]), voff);
+            if (u < take && (fold || !is_mem)) {
+                b.buf[u] = buf_load16<2>(piece(b.idx[u]), voff);
+                if constexpr (kAdd) b.buf2[u] = buf_load16<2>(piece2(b.idx[u]), voff);
+            }
         }
     };
 
@@ -246,7 +251,18 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
         }
         buf_store16<2>(make_rsrc(out + (int64_t)open_r * row_bytes + col, blk_bytes), voff, A::pack(o));
     };
-    auto fold_batch = [&](Batch<kDepth>& b) {
+    auto row_of = [&](const Batch<kDepth, kAdd>& b, int u, float* f) {          // the (summed) row piece as T-valued floats
+        if constexpr (kAdd) {
+            float y[E];
+            A::unpack(b.buf[u], f);
+            A::unpack(b.buf2[u], y);
+#pragma unroll
+            for (int e = 0; e < E; ++e) f[e] = A::rnd(f[e] + y[e]);
+        } else {
+            A::unpack(b.buf[u], f);
+        }
+    };
+    auto fold_batch = [&](Batch<kDepth, kAdd>& b) {
 #pragma unroll
         for (int u = 0; u < kDepth; ++u) {
             if (u < b.take) {
@@ -255,16 +271,16 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
                     if (open_r >= 0) flush();
                     open_r = __builtin_amdgcn_readlane(dv, b.pos + u - t0);
                     open_n = 0;
-                    A::unpack(b.buf[u], acc);
+                    row_of(b, u, acc);
                 } else if (fold == FF_FOLD_MEAN) {
                     float x[E];
-                    A::unpack(b.buf[u], x);
+                    row_of(b, u, x);
 #pragma unroll
                     for (int e = 0; e < E; ++e) acc[e] = acc[e] + x[e];
                     ++open_n;
                 } else if (fold) {
                     float x[E];
-                    A::unpack(b.buf[u], x);
+                    row_of(b, u, x);
 #pragma unroll
                     for (int e = 0; e < E; ++e) acc[e] = A::rnd(acc[e] + x[e]);
                     ++open_n;
@@ -273,7 +289,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
         }
     };
 
-    Batch<kDepth> b0, b1;
+    Batch<kDepth, kAdd> b0, b1;
     int pos = t0 + __ffsll((long long)starts) - 1;
     issue(b0, pos);
     pos += b0.take;
@@ -307,7 +323,7 @@ __global__ __launch_bounds__(256) void k_gather_mask(const char* __restrict__ ma
     }
 }
 
-int launch_merge_compact(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
+int launch_merge_compact(const void* hidden, const void* addend, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
                          const int32_t* order, const uint8_t* member, int fold, const int32_t* dst,
                          const uint8_t* keep, const ff_aux_t* aux_host, int n_aux, int32_t* order_next,
                          int32_t* inv_next, int64_t* stats, hipStream_t st, bool skip_identity, void* zero_a,
@@ -329,14 +345,14 @@ int launch_merge_compact(const void* hidden, void* hidden_out, int dtype, int64_
     const char* h = (const char*)hidden;
     char* o = (char*)hidden_out;
     const int64_t* ident = (skip_identity && stats) ? stats : nullptr;
-#define FF_MC_LAUNCH(DT)                                                                                               \
-    hipLaunchKernelGGL((k_merge_compact<DT>), grid, dim3(kMergeThreads), 0, st, h, o, (uint32_t)row_bytes, (int)L, L_cap, \
-                       order, member, fold, dst, keep, pack, n_main, n_aux_blocks, n_next_blocks, order_next, inv_next, stats, \
-                       ident, zero)
+#define FF_MC_LAUNCH(DT, ADD)                                                                                          \
+    hipLaunchKernelGGL((k_merge_compact<DT, ADD>), grid, dim3(kMergeThreads), 0, st, h, (const char*)addend, o,          \
+                       (uint32_t)row_bytes, (int)L, L_cap, order, member, fold, dst, keep, pack, n_main, n_aux_blocks,  \
+                       n_next_blocks, order_next, inv_next, stats, ident, zero)
     switch (dtype) {
-        case FF_F32: FF_MC_LAUNCH(FF_F32); break;
-        case FF_BF16: FF_MC_LAUNCH(FF_BF16); break;
-        default: FF_MC_LAUNCH(FF_F16);
+        case FF_F32: if (addend) FF_MC_LAUNCH(FF_F32, true); else FF_MC_LAUNCH(FF_F32, false); break;
+        case FF_BF16: if (addend) FF_MC_LAUNCH(FF_BF16, true); else FF_MC_LAUNCH(FF_BF16, false); break;
+        default: if (addend) FF_MC_LAUNCH(FF_F16, true); else FF_MC_LAUNCH(FF_F16, false);
     }
 #undef FF_MC_LAUNCH
     return (int)hipGetLastError();
@@ -360,7 +376,7 @@ extern "C" int ff_merge_compact(const void* hidden, void* hidden_out, int dtype,
     if (((uintptr_t)hidden & 15) || ((uintptr_t)hidden_out & 15) || ((d * esz) & 15)) return FF_ERR_ALIGN;
     if (L >= (1ll << 29) || d * esz >= (1ll << 31)) return FF_ERR_UNSUPPORTED;
     if (L == 0) return FF_OK;
-    return ff::launch_merge_compact(hidden, hidden_out, dtype, L, d, L_cap, order, member, fold, dst, keep, aux_host, n_aux,
+    return ff::launch_merge_compact(hidden, nullptr, hidden_out, dtype, L, d, L_cap, order, member, fold, dst, keep, aux_host, n_aux,
                                     nullptr, nullptr, nullptr,
                                     (hipStream_t)stream, false, nullptr, 0, nullptr, 0, 0, nullptr);
 }

@@ -28,9 +28,11 @@ struct LayoutHint {
     int pre, patches, frames, L;
 };
 
-template <int DT, int kPairs, int kSimThreads, bool kHint>
+// kAdd: the rows are T(hidden[i] + addend[i]) - the decoder's residual add fused into the pass (both
+// operands read once here and once by the merge kernel, the sum never touches memory).
+template <int DT, int kPairs, int kSimThreads, bool kHint, bool kAdd>
 __global__ __launch_bounds__(kSimThreads) void k_pair_similarity(
-    const char* __restrict__ hidden, uint32_t row_bytes, const int64_t* __restrict__ ptype,
+    const char* __restrict__ hidden, const char* __restrict__ addend, uint32_t row_bytes, const int64_t* __restrict__ ptype,
     const int32_t* __restrict__ order, const int64_t* __restrict__ stats, void* __restrict__ sim,
     int* __restrict__ l0, int* t16_end, float thr, const LayoutHint hint, int32_t* __restrict__ order_out,
     int32_t* __restrict__ inv_out, int64_t* __restrict__ stats_out) {
@@ -61,7 +63,11 @@ __global__ __launch_bounds__(kSimThreads) void k_pair_similarity(
     const int j0 = uniform((blockIdx.x * kSimWaves + wave_id()) * kPairs);
     if (j0 >= nv) return;
 
-    __amdgpu_buffer_rsrc_t row[R];
+    __amdgpu_buffer_rsrc_t row[R], row2[R];
+    auto set_row = [&](int r, int64_t i) {
+        row[r] = make_rsrc(hidden + i * row_bytes, row_bytes);
+        row2[r] = make_rsrc((kAdd ? addend : hidden) + i * row_bytes, row_bytes);
+    };
     int slot_i[kPairs], slot_p[kPairs], slot_f[kPairs];       // kHint: position / type / frame of slot j0+r
     int64_t my_type = 0;
     if constexpr (kHint) {
@@ -71,7 +77,7 @@ __global__ __launch_bounds__(kSimThreads) void k_pair_similarity(
             int pm = p0, fm = f0 - 1;
             if (fm < 0) { fm = F - 1; pm = p0 - 1; }
             if (j0 == 0) { pm = 0; fm = 0; }
-            row[0] = make_rsrc(hidden + (int64_t)(hint.pre + fm * P + pm) * row_bytes, row_bytes);
+            set_row(0, (int64_t)(hint.pre + fm * P + pm));
         }
         int p = p0, f = f0, last_i = hint.pre + f0 * P + p0;
 #pragma unroll
@@ -80,7 +86,7 @@ __global__ __launch_bounds__(kSimThreads) void k_pair_similarity(
             const int i = in ? hint.pre + f * P + p : last_i;
             slot_i[r] = i; slot_p[r] = p; slot_f[r] = f;
             last_i = i;
-            row[r + 1] = make_rsrc(hidden + (int64_t)i * row_bytes, row_bytes);
+            set_row(r + 1, (int64_t)i);
             if (++f == F) { f = 0; ++p; }
         }
         // type of my slot, requested now so that the check at the end finds it in a register
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(kSimThreads) void k_pair_similarity(
         for (int r = 0; r < R; ++r) {
             int j = j0 - 1 + r;
             j = j < 0 ? 0 : (j >= nv ? nv - 1 : j);
-            row[r] = make_rsrc(hidden + (int64_t)uniform(order[j]) * row_bytes, row_bytes);
+            set_row(r, (int64_t)uniform(order[j]));
         }
     }
 
@@ -106,13 +112,19 @@ __global__ __launch_bounds__(kSimThreads) void k_pair_similarity(
     // 1 KiB tiles; tile t+1 is in flight while tile t is reduced
     const uint32_t lane_off = (uint32_t)lane * 16;
     const uint32_t tiles = (row_bytes + 1023u) >> 10;
-    uint4 cur[R], nxt[R];
+    uint4 cur[R], nxt[R], nxt2[kAdd ? R : 1];
 #pragma unroll
-    for (int r = 0; r < R; ++r) cur[r] = buf_load16(row[r], lane_off);
+    for (int r = 0; r < R; ++r) {
+        cur[r] = buf_load16(row[r], lane_off);
+        if constexpr (kAdd) cur[r] = add16<DT>(cur[r], buf_load16(row2[r], lane_off));
+    }
     for (uint32_t t = 0; t < tiles; ++t) {
         const uint32_t noff = lane_off + (t + 1) * 1024u;      // past-the-end lanes read zeros
 #pragma unroll
-        for (int r = 0; r < R; ++r) nxt[r] = buf_load16(row[r], noff);
+        for (int r = 0; r < R; ++r) {
+            nxt[r] = buf_load16(row[r], noff);
+            if constexpr (kAdd) nxt2[r] = buf_load16(row2[r], noff);
+        }
 
         if constexpr (DT == FF_BF16) {
             // |x|^2 straight from the packed words; the T-rounded products from the unpacked rows
@@ -149,7 +161,10 @@ __global__ __launch_bounds__(kSimThreads) void k_pair_similarity(
             }
         }
 #pragma unroll
-        for (int r = 0; r < R; ++r) cur[r] = nxt[r];
+        for (int r = 0; r < R; ++r) {
+            if constexpr (kAdd) cur[r] = add16<DT>(nxt[r], nxt2[r]);
+            else cur[r] = nxt[r];
+        }
     }
 
 #pragma unroll
@@ -210,6 +225,7 @@ __global__ __launch_bounds__(kSimThreads) void k_pair_similarity(
 
 struct SimArgs {
     const void* hidden;
+    const void* addend;       // NULL: the rows are hidden's
     int64_t L, d;
     const int64_t* ptype;
     const int32_t* order;
@@ -229,14 +245,18 @@ static int launch_similarity_pt(const SimArgs& a, hipStream_t st) {
     const int64_t row_bytes = a.d * Act<DT>::kBytes;
     const int64_t per_block = (int64_t)(kSimThreads / kWave) * kPairs;
     const int64_t blocks = (a.L + per_block - 1) / per_block;
-    if (a.hint.frames > 0)
-        hipLaunchKernelGGL((k_pair_similarity<DT, kPairs, kSimThreads, true>), dim3((unsigned)blocks), dim3(kSimThreads), 0,
-                           st, (const char*)a.hidden, (uint32_t)row_bytes, a.ptype, a.order, a.stats, a.sim, a.l0, a.t16_end, a.thr,
-                           a.hint, a.order_out, a.inv_out, a.stats_out);
-    else
-        hipLaunchKernelGGL((k_pair_similarity<DT, kPairs, kSimThreads, false>), dim3((unsigned)blocks), dim3(kSimThreads), 0,
-                           st, (const char*)a.hidden, (uint32_t)row_bytes, a.ptype, a.order, a.stats, a.sim, a.l0, a.t16_end, a.thr,
-                           a.hint, (int32_t*)nullptr, (int32_t*)nullptr, (int64_t*)nullptr);
+#define FF_SIM_LAUNCH(HINT, ADD, OO, IO, SO)                                                                              \
+    hipLaunchKernelGGL((k_pair_similarity<DT, kPairs, kSimThreads, HINT, ADD>), dim3((unsigned)blocks), dim3(kSimThreads), 0, \
+                       st, (const char*)a.hidden, (const char*)a.addend, (uint32_t)row_bytes, a.ptype, a.order, a.stats,    \
+                       a.sim, a.l0, a.t16_end, a.thr, a.hint, OO, IO, SO)
+    if (a.hint.frames > 0) {
+        if (a.addend) FF_SIM_LAUNCH(true, true, a.order_out, a.inv_out, a.stats_out);
+        else FF_SIM_LAUNCH(true, false, a.order_out, a.inv_out, a.stats_out);
+    } else {
+        if (a.addend) FF_SIM_LAUNCH(false, true, (int32_t*)nullptr, (int32_t*)nullptr, (int64_t*)nullptr);
+        else FF_SIM_LAUNCH(false, false, (int32_t*)nullptr, (int32_t*)nullptr, (int64_t*)nullptr);
+    }
+#undef FF_SIM_LAUNCH
     return (int)hipGetLastError();
 }
 
@@ -244,10 +264,10 @@ template <int DT>
 static int launch_similarity(const SimArgs& a, hipStream_t st) { return launch_similarity_pt<DT, 4, 256>(a, st); }
 
 // hint_frames > 0: frame-major closed form (see LayoutHint); `order` and `stats` are then outputs.
-int launch_similarity_any(const void* hidden, int dtype, int64_t L, int64_t d, const int64_t* ptype,
+int launch_similarity_any(const void* hidden, const void* addend, int dtype, int64_t L, int64_t d, const int64_t* ptype,
                           int32_t* order, int32_t* inv, int64_t* stats, void* sim, int* l0, int* t16_end, double thr,
                           int64_t hint_pre, int64_t hint_patches, int64_t hint_frames, hipStream_t st) {
-    SimArgs a{hidden, L, d, ptype, order, stats, sim, l0, t16_end, (float)thr,
+    SimArgs a{hidden, addend, L, d, ptype, order, stats, sim, l0, t16_end, (float)thr,
               LayoutHint{(int)hint_pre, (int)hint_patches, (int)hint_frames, (int)L}, order, inv, stats};
     switch (dtype) {
         case FF_F32: return launch_similarity<FF_F32>(a, st);
@@ -267,6 +287,6 @@ extern "C" int ff_pair_similarity(const void* hidden, int dtype, int64_t L, int6
     if (((uintptr_t)hidden & 15) || ((d * esz) & 15)) return FF_ERR_ALIGN;
     if (L >= (1ll << 31) || d * esz >= (1ll << 31)) return FF_ERR_UNSUPPORTED;
     if (L == 0) return FF_OK;
-    return ff::launch_similarity_any(hidden, dtype, L, d, patch_type, const_cast<int32_t*>(order), nullptr,
+    return ff::launch_similarity_any(hidden, nullptr, dtype, L, d, patch_type, const_cast<int32_t*>(order), nullptr,
                                      const_cast<int64_t*>(stats), sim, nullptr, nullptr, 0.0, 0, 0, 0, (hipStream_t)stream);
 }

@@ -175,23 +175,38 @@ class FrameFusion(nn.Module):
         return pre, n // P
 
     # ---- reference main.py:40-140 ------------------------------------------------------------
-    def forward(self, hidden_states, position_embeddings, attention_mask, self_attn_weights=None):
+    def forward(self, hidden_states, position_embeddings, attention_mask, self_attn_weights=None, residual=None):
+        """Reference signature (main.py:40-42) plus `residual`: when given, the sequence that is reduced
+        is ``residual + hidden_states`` - the add the decoder performs right before call B
+        (models/qwen2/modeling_qwen2.py:64-67) - formed inside the two streaming passes instead of by an
+        eager add whose result would be written once and read twice."""
         dev = hidden_states.device
         if dev.type == "cuda" and dev.index != torch.cuda.current_device():
             # the kernels are launched through ctypes on the CURRENT device's stream: follow the
             # tensors (several replicas on several GPUs in one process, as in the reference's demo)
             with torch.cuda.device(dev):
-                return self.forward(hidden_states, position_embeddings, attention_mask, self_attn_weights)
+                return self.forward(hidden_states, position_embeddings, attention_mask, self_attn_weights, residual)
         bsz, q_len, hidden_size = hidden_states.size()
         prune_now = q_len > 1 and self.finish_merging == True and self.finish_pruning == False
         merge_now = q_len > 1 and (not self.finish_merging)
+        if residual is not None:
+            if residual.shape != hidden_states.shape or residual.dtype != hidden_states.dtype or residual.device != dev:
+                raise FrameFusionHipError("residual must have the shape, dtype and device of hidden_states")
+            if not (prune_now or merge_now):
+                return residual + hidden_states, position_embeddings, attention_mask
         if prune_now:
             hidden_states, position_embeddings, attention_mask = self._prune(
-                hidden_states, position_embeddings, attention_mask, self_attn_weights)
+                hidden_states, position_embeddings, attention_mask, self_attn_weights, residual)
+            residual = None                      # (folded into the pruned rows)
         if merge_now:
             hidden_states, position_embeddings, attention_mask = self._merge(
-                hidden_states, position_embeddings, attention_mask)
+                hidden_states, position_embeddings, attention_mask, residual)
         return hidden_states, position_embeddings, attention_mask
+
+    def forward_residual(self, residual, hidden_states, position_embeddings, attention_mask, self_attn_weights=None):
+        """Call B of the decoder layer with its residual add fused in:
+        ``forward(residual + hidden_states, ...)`` without materialising the sum."""
+        return self.forward(hidden_states, position_embeddings, attention_mask, self_attn_weights, residual=residual)
 
     # ---- helpers -------------------------------------------------------------------------------
     def _threshold_for(self, dtype) -> float:
@@ -270,10 +285,10 @@ class FrameFusion(nn.Module):
         return out
 
     # ---- merge call: main.py:104-138 -------------------------------------------------------------
-    def _merge(self, hidden_states, position_embeddings, attention_mask):
-        return self._merge_complete(self._merge_launch(hidden_states, position_embeddings, attention_mask))
+    def _merge(self, hidden_states, position_embeddings, attention_mask, residual=None):
+        return self._merge_complete(self._merge_launch(hidden_states, position_embeddings, attention_mask, residual=residual))
 
-    def _merge_launch(self, hidden_states, position_embeddings, attention_mask, use_hint=True):
+    def _merge_launch(self, hidden_states, position_embeddings, attention_mask, use_hint=True, residual=None):
         """Enqueue the whole merge call on the current stream and return without waiting: the
         state machine is advanced by _merge_complete."""
         _lib.require_gpu(hidden_states, "FrameFusion.forward")
@@ -284,6 +299,10 @@ class FrameFusion(nn.Module):
         dtype = hidden_states.dtype
         code = _dtype_code(hidden_states)
         hidden = hidden_states if hidden_states.is_contiguous() else hidden_states.contiguous()
+        addend = None
+        if residual is not None:
+            addend = residual if residual.is_contiguous() else residual.contiguous()
+        addend_ptr = addend.data_ptr() if addend is not None else None
 
         ptype = self.patch_type
         if ptype.device != device or ptype.dtype != torch.int64 or not ptype.is_contiguous():
@@ -314,7 +333,7 @@ class FrameFusion(nn.Module):
         if hint is not None and hint[0] + hint[1] * int(self.patch_num) > L:
             hint = None
         hint_pre, hint_frames = hint if hint is not None else (0, 0)
-        rc = lib.ff_merge_begin(hidden.data_ptr(), code, L, d, ptype.data_ptr(), int(self.patch_num), order_valid,
+        rc = lib.ff_merge_begin(hidden.data_ptr(), addend_ptr, code, L, d, ptype.data_ptr(), int(self.patch_num), order_valid,
                                 thr, sc.order.data_ptr(), sc.inv.data_ptr(), sim_ptr, sc.stats.data_ptr(), seq, hint_pre,
                                 hint_frames,
                                 sc.ws.data_ptr(), sc.ws_bytes, stream)
@@ -327,7 +346,7 @@ class FrameFusion(nn.Module):
         aux = (FFAux * _lib.MAX_AUX)()
         n_aux = self._fill_aux(aux, 0, [ptype.view(1, L)], [ptype_out], L)
         n_aux = self._fill_aux(aux, n_aux, srcs, outs, L)
-        rc = lib.ff_merge_finish(hidden.data_ptr(), out.data_ptr(), code, L, d, L_cap,
+        rc = lib.ff_merge_finish(hidden.data_ptr(), addend_ptr, out.data_ptr(), code, L, d, L_cap,
                                  float(thr), float(sub), float(self.ratio_lower_bound),
                                  sc.order.data_ptr(), sc.inv.data_ptr(), sim_ptr, sc.member.data_ptr(),
                                  sc.dst.data_ptr(), sc.keep.data_ptr(), sc.stats.data_ptr(), sc.stats_host_ptr, seq,
@@ -340,7 +359,7 @@ class FrameFusion(nn.Module):
             mask_out = self._gather_mask(attention_mask, L, L_cap, sc.dst, stream)
 
         return dict(sc=sc, seq=seq, L=L, dtype=dtype, out=out, ptype_out=ptype_out, rebuild=rebuild,
-                    mask_out=mask_out, hinted=hint is not None,
+                    mask_out=mask_out, hinted=hint is not None, residual=residual,
                     inputs=(hidden_states, position_embeddings, attention_mask))
 
     def _merge_complete(self, pending):
@@ -364,7 +383,7 @@ class FrameFusion(nn.Module):
             self._layout_hint = None
             sc.dirty = True
             sc.order_valid_for = None
-            return self._merge_complete(self._merge_launch(*pending["inputs"], use_hint=False))
+            return self._merge_complete(self._merge_launch(*pending["inputs"], use_hint=False, residual=pending["residual"]))
         nv, ftn, count = int(st[_lib.STAT_NV]), int(st[_lib.STAT_FTN]), int(st[_lib.STAT_COUNT])
         L_out = int(st[_lib.STAT_LOUT])
         branch = int(st[_lib.STAT_BRANCH])
@@ -386,6 +405,9 @@ class FrameFusion(nn.Module):
             self.last_call = dict(kind="merge", L_in=L, L_out=L, nv=nv, ftn=ftn, count=count, branch=branch,
                                   k=int(st[_lib.STAT_K]), scratch=sc, dtype=dtype, order=sc.order)
             sc.order_valid_for = (self._ptype_gen, L)
+            if pending["residual"] is not None:          # nothing folded, but the caller is owed the sum
+                h_in, pe_in, mask_in = pending["inputs"]
+                return pending["residual"] + h_in, pe_in, mask_in
             return pending["inputs"]
 
         self.patch_type = ptype_out[:, :L_out]                                      # main.py:132
@@ -413,7 +435,7 @@ class FrameFusion(nn.Module):
         return out
 
     # ---- prune call: main.py:61-101 ----------------------------------------------------------------
-    def _prune(self, hidden_states, position_embeddings, attention_mask, self_attn_weights):
+    def _prune(self, hidden_states, position_embeddings, attention_mask, self_attn_weights, residual=None):
         _lib.require_gpu(hidden_states, "FrameFusion.forward")
         lib = _lib.load()
         bsz, q_len, d = hidden_states.size()
@@ -454,7 +476,9 @@ class FrameFusion(nn.Module):
         n_aux = self._fill_aux(aux, 0, srcs, outs, q_len)
         imp = sc.sim32[:q_len]       # fp32-sized slots: room for any weight dtype
         sc.dirty = True
-        _lib.check(lib.ff_prune_step(hidden.data_ptr(), out.data_ptr(), code, q_len, d, L_out,
+        addend = residual.contiguous() if residual is not None else None
+        _lib.check(lib.ff_prune_step(hidden.data_ptr(), addend.data_ptr() if addend is not None else None,
+                                     out.data_ptr(), code, q_len, d, L_out,
                                      w.data_ptr(), w_code, w.shape[1], w.shape[2], imp.data_ptr(), 0,
                                      start, n_img, k, sc.member.data_ptr(), sc.dst.data_ptr(), sc.keep.data_ptr(),
                                      sc.stats.data_ptr(), aux, n_aux, sc.ws.data_ptr(), sc.ws_bytes, stream),

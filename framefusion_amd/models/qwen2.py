@@ -58,9 +58,10 @@ def qwen2_decoder_forward(self, hidden_states, attention_mask=None, position_ids
     hidden_states, importance = self.self_attn(hidden_states=hidden_states, attention_mask=attention_mask,
                                                position_ids=position_ids, past_key_values=past_key_values,
                                                use_cache=use_cache, position_embeddings=position_embeddings, **kwargs)
-    hidden_states = residual + hidden_states
-    hidden_states, position_embeddings, attention_mask = self.framefusion(    # modeling_qwen2.py:67
-        hidden_states, position_embeddings, attention_mask, importance)
+    # modeling_qwen2.py:64-67: hidden = residual + attention output, then call B - here the add is formed
+    # inside the reduction's two streaming passes (a plain add when no reduction is due)
+    hidden_states, position_embeddings, attention_mask = self.framefusion.forward_residual(
+        residual, hidden_states, position_embeddings, attention_mask, importance)
     residual = hidden_states
     hidden_states = self.mlp(self.post_attention_layernorm(hidden_states))
     hidden_states = residual + hidden_states

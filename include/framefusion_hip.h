@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FF_ABI_VERSION 4
+#define FF_ABI_VERSION 5
 
 enum { FF_F32 = 0, FF_BF16 = 1, FF_F16 = 2 };
 
@@ -241,7 +241,7 @@ int ff_patch_type_from_mask(const uint8_t* mask, int64_t n, int64_t patch_num, i
  * Workspace protocol, layout hint, identity calls and order_next as for ff_merge_begin /
  * ff_merge_finish below.  One host call = three launches issued back to back: the form to use when
  * the sequence is short enough that the host, not the similarity pass, would set the pace. */
-int ff_merge_step(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
+int ff_merge_step(const void* hidden, const void* addend, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
                   const int64_t* patch_type, int64_t patch_num, int order_valid,
                   double threshold, double sub, double ratio_lb,
                   int32_t* order, int32_t* inv, void* sim, uint8_t* member, int32_t* dst, uint8_t* keep,
@@ -249,6 +249,12 @@ int ff_merge_step(const void* hidden, void* hidden_out, int dtype, int64_t L, in
                   const ff_aux_t* aux_host, int n_aux,
                   int64_t hint_pre, int64_t hint_frames, int32_t* order_next, int32_t* inv_next,
                   void* ws, size_t ws_bytes, ff_stream_t stream);
+
+/* `addend` (optional, [L, d] like hidden; ff_merge_step / begin / finish / ff_prune_step): the rows that are
+ * reduced are T(hidden[i] + addend[i]) - the residual add the decoder performs right before the call
+ * (framefusion/models/qwen2/modeling_qwen2.py:64-67: hidden = residual + attention output) formed in
+ * registers by both streaming passes: neither the eager add's write nor its re-read reach memory.
+ * Pass the same pointer to begin and finish. */
 
 /* The same step in two halves, so the host can allocate the output tensors while the first
  * streaming pass runs: begin = K0 (unless order_valid) + K1, finish = K2+K3 + K4.  `ws` must be the
@@ -273,12 +279,12 @@ int ff_merge_step(const void* hidden, void* hidden_out, int dtype, int64_t L, in
  * COMPACTED sequence and its inverse, and stats[NV]/stats[FTN] are advanced to it, so the next merge
  * call on the reduced sequence can pass them as `order` / `inv` with order_valid = 1 and skip K0
  * (surviving tokens keep their relative order). */
-int ff_merge_begin(const void* hidden, int dtype, int64_t L, int64_t d,
+int ff_merge_begin(const void* hidden, const void* addend, int dtype, int64_t L, int64_t d,
                    const int64_t* patch_type, int64_t patch_num, int order_valid, double threshold,
                    int32_t* order, int32_t* inv, void* sim, int64_t* stats, int64_t seq,
                    int64_t hint_pre, int64_t hint_frames, void* ws, size_t ws_bytes,
                    ff_stream_t stream);
-int ff_merge_finish(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
+int ff_merge_finish(const void* hidden, const void* addend, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
                     double threshold, double sub, double ratio_lb,
                     const int32_t* order, const int32_t* inv, const void* sim, uint8_t* member, int32_t* dst,
                     uint8_t* keep, int64_t* stats, int64_t* stats_host_mapped, int64_t seq,
@@ -303,7 +309,7 @@ int ff_merge_finish_topk(const void* hidden, void* hidden_out, int dtype, int64_
  * accumulated the select tables in `ws`.  `importance` is scratch for S values of w_dtype.  The output
  * length S - n_img + k is known to the host, so nothing is read back.  `ws` follows the workspace
  * protocol of ff_merge_begin (zero on entry, left zero). */
-int ff_prune_step(const void* hidden, void* hidden_out, int dtype, int64_t S, int64_t d, int64_t L_cap,
+int ff_prune_step(const void* hidden, const void* addend, void* hidden_out, int dtype, int64_t S, int64_t d, int64_t L_cap,
                   const void* attn_w, int w_dtype, int64_t H, int64_t num, void* importance, int tables_ready,
                   int64_t start, int64_t n_img, int64_t k,
                   uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,

@@ -60,7 +60,7 @@ int main(int argc, char** argv) {
     if (ff_abi_version() != FF_ABI_VERSION) { fprintf(stderr, "ABI mismatch\n"); return 4; }
     ff_aux_t aux[1] = {{dpt, dpt_out, 8, 1}};
     const double thr = 0.6015625;                                        // bf16(0.6), main.py:113
-    FF(ff_merge_step(dh, dout, FF_BF16, L, d, L, (const int64_t*)dpt, P, /*order_valid=*/0, thr, /*sub=*/0.7, /*ratio_lb=*/0.1,
+    FF(ff_merge_step(dh, /*addend=*/nullptr, dout, FF_BF16, L, d, L, (const int64_t*)dpt, P, /*order_valid=*/0, thr, /*sub=*/0.7, /*ratio_lb=*/0.1,
                      (int32_t*)dorder, (int32_t*)dinv, dsim, (uint8_t*)dmember, (int32_t*)ddst, (uint8_t*)dkeep, (int64_t*)dstats, nullptr,
                      /*seq=*/1, aux, 1, /*hint_pre=*/0, /*hint_frames=*/0, /*order_next=*/nullptr, /*inv_next=*/nullptr, dws, wsb, st));
     CK(hipStreamSynchronize(st));

@@ -21,17 +21,20 @@ class Shadow:
     def __init__(self, ff):
         self.ff, self.inner, self.log = ff, ff.forward, []
 
-    def __call__(self, hidden, pos, mask, attn_w=None):
+    def __call__(self, hidden, pos, mask, attn_w=None, residual=None):
         ff = self.ff
         if hidden.shape[1] <= 1:
-            return self.inner(hidden, pos, mask, attn_w)
+            return self.inner(hidden, pos, mask, attn_w, residual)
+        fused_in = hidden
+        if residual is not None:                # the oracle sees what the reference would: the eager sum
+            hidden = residual + hidden
         o = orc.OracleFrameFusion(ff.cost, ff.similarity_lower_bound, ff.ratio_lower_bound)
         o.prepare(ff.patch_type.cpu(), ff.patch_num, ff.image_token_start_index, ff.image_token_end_index,
                   ff.image_token_length, ff.original_length, ff.finish_merging, ff.finish_pruning, list(ff.sparsity_list))
         L = hidden.shape[1]
         ho, po, _ = o.forward(hidden.cpu(), torch.arange(L)[None], None, None if attn_w is None else attn_w.cpu())
         was_active = (not ff.finish_merging) or (not ff.finish_pruning)
-        out = self.inner(hidden, pos, mask, attn_w)
+        out = self.inner(fused_in, pos, mask, attn_w, residual)
         if was_active and (ff.last_call is not None):
             kind = ff.last_call["kind"]
             keep_g = torch.nonzero(ff.last_plan()["keep"][:L].bool()).reshape(-1).cpu().numpy()
