@@ -28,7 +28,7 @@ STAT_ERROR = 11
 ERR_BIT_BARRIER, ERR_BIT_LAYOUT = 1, 2
 STAT_WORDS = 32
 MAX_AUX = 4
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class FFAux(C.Structure):
@@ -59,8 +59,9 @@ PROTOTYPES = {
                                 _vp]),
     "ff_gather_mask": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "ff_head_mean": (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _vp]),
-    "ff_last_query_attention": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _i64, _i64, _f64, _i32, _vp, _vp, _vp,
-                                       _sz, _vp]),
+    "ff_last_query_attention": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _i64, _i64, _f64, _i32, _vp, _vp, _i64, _i64,
+                                       _vp, _sz, _vp, _sz, _vp]),
+    "ff_last_query_workspace_bytes": (_sz, [_i32, _i64, _i64, _i64, _i64]),
     "ff_merge_begin": (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _i64, _i32, _f64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _sz,
                               _vp]),
     "ff_merge_finish": (_i32, [_vp, _vp, _vp, _i32, _i64, _i64, _i64, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,

@@ -150,18 +150,210 @@ int launch_head_mean(const void* attn_w, int dtype, int64_t H, int64_t num, int6
 
 template <int DT>
 __global__ __launch_bounds__(256) void k_lq_mean(const float* __restrict__ probs_f, int rows, int S,
-                                                 void* __restrict__ imp) {
+                                                 void* __restrict__ imp, int lo, int hi, int* __restrict__ l0, int* t16_end) {
     using A = Act<DT>;
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= S) return;
-    float acc = 0.f;
-    for (int r = 0; r < rows; ++r) acc += probs_f[(int64_t)r * S + s];
-    A::store1(imp, s, acc / (float)rows);
+    float v = 0.f;
+    if (s < S) {
+        float acc = 0.f;
+        for (int r = 0; r < rows; ++r) acc += probs_f[(int64_t)r * S + s];
+        v = A::rnd(acc / (float)rows);
+        A::store1(imp, s, v);
+    }
+    if (l0) importance_tables<DT>(v, s, s >= lo && s < hi, l0, t16_end);
+}
+
+// ---- tiled path (lanes-per-key a power of two: every real head size) -------------------------------------
+// k_lq_tile: workgroup = 256 keys of one kv head x up to 16 query rows of its GQA group.  A key row is
+// read by LPK = dh * sizeof(T) / 16 consecutive lanes, 16 bytes each: a wave-load covers 1 KiB of
+// CONTIGUOUS keys (the old lane-per-key layout strode 256 B between lanes).  The query rows sit in LDS
+// as packed T; q . k runs on v_dot2c (products of two bf16 / fp16 are exact in fp32), the LPK partial
+// sums meet through xor shuffles.  Scores leave as T in a key-major [S][H*num] workspace (2 bytes per
+// score instead of the 8 of the old fp32 scores + probs), together with per-(row, tile) softmax
+// statistics (max, sum of exp relative to it).
+// k_lq_finish: one thread per key: p = T(exp(x - M) / Sum) with the row's global (M, Sum) folded from the
+// tile statistics, fp32 head/query mean -> importance, optional [H, num, S] weights, and the select
+// tables of the prune's plan kernel on the way.
+constexpr int kLqKeys = 256;
+constexpr int kLqRows = 16;
+
+template <int DT>
+__device__ inline float dot16(const uint4& a, const uint4& b, float acc) {
+    using A = Act<DT>;
+    if constexpr (DT == FF_F32) {
+        float x[4], y[4];
+        A::unpack(a, x);
+        A::unpack(b, y);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_fmaf(x[e], y[e], acc);
+        return acc;
+    } else {
+        acc = A::dot2(a.x, b.x, acc); acc = A::dot2(a.y, b.y, acc); acc = A::dot2(a.z, b.z, acc);
+        return A::dot2(a.w, b.w, acc);
+    }
+}
+
+// sum over the LPK consecutive lanes that share a key (every lane gets it): DPP permutations inside a
+// row of 16 lanes (VALU rate), LDS shuffles only beyond
+template <int LPK>
+__device__ inline float group_sum(float v) {
+    auto dpp = [](float x, int ctrl_id) {
+        const int i = __float_as_int(x);
+        int r;
+        switch (ctrl_id) {
+            case 0: r = __builtin_amdgcn_update_dpp(0, i, 0xB1, 0xf, 0xf, false); break;      // quad_perm [1,0,3,2]
+            case 1: r = __builtin_amdgcn_update_dpp(0, i, 0x4E, 0xf, 0xf, false); break;      // quad_perm [2,3,0,1]
+            case 2: r = __builtin_amdgcn_update_dpp(0, i, 0x141, 0xf, 0xf, false); break;     // row_half_mirror
+            default: r = __builtin_amdgcn_update_dpp(0, i, 0x140, 0xf, 0xf, false); break;    // row_mirror
+        }
+        return __int_as_float(r);
+    };
+    if constexpr (LPK >= 2) v += dpp(v, 0);
+    if constexpr (LPK >= 4) v += dpp(v, 1);
+    if constexpr (LPK >= 8) v += dpp(v, 2);
+    if constexpr (LPK >= 16) v += dpp(v, 3);
+    if constexpr (LPK >= 32) v += __shfl_xor(v, 16, kWave);
+    if constexpr (LPK >= 64) v += __shfl_xor(v, 32, kWave);
+    return v;
+}
+
+template <int DT, int LPK>
+__global__ __launch_bounds__(256) void k_lq_tile(const void* __restrict__ q, const void* __restrict__ k, int H, int H_kv,
+                                                 int num, int S, float scale, int causal, int pitch,
+                                                 void* __restrict__ scores, float2* __restrict__ tstats, int tiles) {
+    using A = Act<DT>;
+    constexpr int KPW = kWave / LPK;                 // keys per wave-load
+    __shared__ uint4 q_lds[kLqRows][LPK];
+    __shared__ float sc[kLqKeys][kLqRows + 1];
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const int hk = blockIdx.y, group = H / H_kv, rows = group * num;
+    const int r0 = blockIdx.z * kLqRows, rows_here = min(kLqRows, rows - r0);
+    const int tile = blockIdx.x;
+    for (int x = tid; x < kLqRows * LPK; x += 256) {
+        const int row = x / LPK, part = x - row * LPK;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row < rows_here) v = ((const uint4*)q)[(size_t)(hk * rows + r0 + row) * LPK + part];
+        q_lds[row][part] = v;
+    }
+    __syncthreads();
+    const uint32_t row_bytes = (uint32_t)LPK * 16u;
+    const __amdgpu_buffer_rsrc_t krs = make_rsrc((const char*)k + (size_t)hk * S * row_bytes, (uint32_t)S * row_bytes);
+    const int part = lane & (LPK - 1), slot = lane / LPK;
+#pragma unroll 2
+    for (int it = 0; it < kWave / KPW; ++it) {
+        const int key_local = w * kWave + it * KPW + slot;
+        const int s_key = tile * kLqKeys + key_local;
+        const uint4 kv = buf_load16(krs, (uint32_t)s_key * row_bytes + (uint32_t)part * 16u);      // past S: zeros
+#pragma unroll
+        for (int r = 0; r < kLqRows; ++r) {
+            const float acc = group_sum<LPK>(dot16<DT>(kv, q_lds[r][part], 0.f));
+            if (part == (r & (LPK - 1))) sc[key_local][r] = acc;
+        }
+    }
+    __syncthreads();
+    {   // staged rounding + the causal bias, scores out as T, key-major
+        const int s_key = tile * kLqKeys + tid;
+        if (s_key < S) {
+            for (int r = 0; r < rows_here; ++r) {
+                const int n = (r0 + r) % num;
+                float v = A::rnd(sc[tid][r]);
+                v = A::rnd(v * scale);
+                if (causal && s_key > S - num + n) v = A::rnd(v + (-INFINITY));
+                sc[tid][r] = v;
+                A::store1(scores, (int64_t)s_key * pitch + hk * rows + r0 + r, v);
+            }
+        } else {
+            for (int r = 0; r < rows_here; ++r) sc[tid][r] = -INFINITY;
+        }
+    }
+    __syncthreads();
+    {   // tile statistics: 16 threads per row
+        const int r = tid >> 4, sub = tid & 15;
+        float m = -INFINITY;
+        for (int x = sub; x < kLqKeys; x += 16) m = fmaxf(m, sc[x][r]);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, kWave));
+        float e = 0.f;
+        if (m > -INFINITY)
+            for (int x = sub; x < kLqKeys; x += 16) e += expf(sc[x][r] - m);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) e += __shfl_xor(e, o, kWave);
+        if (sub == 0 && r < rows_here) tstats[(size_t)(hk * rows + r0 + r) * tiles + tile] = make_float2(m, e);
+    }
 }
 
 template <int DT>
-static int launch_lq(const void* q, const void* k, int64_t H, int64_t H_kv, int64_t num, int64_t S, int64_t dh,
-                     double scale, int causal, void* weights, void* importance, void* ws, hipStream_t st) {
+__global__ __launch_bounds__(256) void k_lq_finish(const void* __restrict__ scores, const float2* __restrict__ tstats,
+                                                   int rows_total, int pitch, int tiles, int S, void* __restrict__ weights,
+                                                   void* __restrict__ imp, int lo, int hi, int* __restrict__ l0,
+                                                   int* t16_end) {
+    using A = Act<DT>;
+    constexpr int E = A::kPer16;
+    extern __shared__ __attribute__((aligned(16))) float row_ms[];       // [rows_total][2]: the row's max and sum of exp
+    const int tid = threadIdx.x;
+    {   // global (max, sum) of every row from the tile statistics: a group of G lanes per row
+        int G = 1;
+        while (G < 64 && G * 2 * rows_total <= 256) G *= 2;
+        const int per_pass = 256 / G, sub = tid & (G - 1);
+        for (int row0 = 0; row0 < rows_total; row0 += per_pass) {
+            const int row = row0 + tid / G;
+            const bool live = row < rows_total;
+            const float2* ts = tstats + (size_t)(live ? row : 0) * tiles;
+            // one pass, 8 tiles in flight per lane: running max with the sum rescaled to it
+            float M = -INFINITY, sum = 0.f;
+            for (int t0 = sub; t0 < tiles; t0 += 8 * G) {
+                float2 ms[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) ms[u] = t0 + u * G < tiles ? ts[t0 + u * G] : make_float2(-INFINITY, 0.f);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (ms[u].y > 0.f) {
+                        const float Mn = fmaxf(M, ms[u].x);
+                        sum = sum * expf(M - Mn) + ms[u].y * expf(ms[u].x - Mn);      // (exp(-inf) = 0 on the first)
+                        M = Mn;
+                    }
+                }
+            }
+            for (int o = G >> 1; o > 0; o >>= 1) {
+                const float Mo = __shfl_xor(M, o, kWave), so = __shfl_xor(sum, o, kWave);
+                const float Mn = fmaxf(M, Mo);
+                sum = (M > -INFINITY ? sum * expf(M - Mn) : 0.f) + (Mo > -INFINITY ? so * expf(Mo - Mn) : 0.f);
+                M = Mn;
+            }
+            if (live && sub == 0) { row_ms[2 * row] = M; row_ms[2 * row + 1] = sum; }
+        }
+    }
+    __syncthreads();
+    const int s = blockIdx.x * 256 + tid;
+    float v = 0.f;
+    if (s < S) {
+        float acc = 0.f;
+        const uint4* src = (const uint4*)((const char*)scores + (size_t)s * pitch * A::kBytes);
+        for (int row0 = 0; row0 < rows_total; row0 += E) {
+            float x[E];
+            A::unpack(src[row0 / E], x);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int row = row0 + e;
+                if (row < rows_total) {
+                    const float p = A::rnd(expf(x[e] - row_ms[2 * row]) / row_ms[2 * row + 1]);
+                    acc += p;
+                    if (weights) A::store1(weights, (int64_t)row * S + s, p);
+                }
+            }
+        }
+        if (imp) {
+            v = A::rnd(acc / (float)rows_total);
+            A::store1(imp, s, v);
+        }
+    }
+    if (l0) importance_tables<DT>(v, s, s >= lo && s < hi, l0, t16_end);
+}
+
+template <int DT>
+static int launch_lq_general(const void* q, const void* k, int64_t H, int64_t H_kv, int64_t num, int64_t S, int64_t dh,
+                             double scale, int causal, void* weights, void* importance, void* ws, int64_t lo, int64_t hi,
+                             int* l0, int* t16_end, hipStream_t st) {
     float* scores = (float*)ws;
     float* probs = scores + H * num * S;
     const int rows = (int)((H / H_kv) * num);
@@ -173,7 +365,51 @@ static int launch_lq(const void* q, const void* k, int64_t H, int64_t H_kv, int6
     hipLaunchKernelGGL(k_lq_softmax<DT>, dim3((unsigned)(H * num)), dim3(256), 0, st, scores, (int)S, probs, weights);
     if (importance)
         hipLaunchKernelGGL(k_lq_mean<DT>, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, probs, (int)(H * num),
-                           (int)S, importance);
+                           (int)S, importance, (int)lo, (int)hi, l0, t16_end);
+    return (int)hipGetLastError();
+}
+
+size_t lq_ws_bytes(int dtype, int64_t H, int64_t num, int64_t S, int64_t dh) {
+    const int64_t esz = dtype == FF_F32 ? 4 : 2;
+    const int64_t lpk = dh * esz / 16;
+    const bool tiled = (dh * esz) % 16 == 0 && lpk >= 1 && lpk <= 64 && (lpk & (lpk - 1)) == 0;
+    if (!tiled) return (size_t)(2 * H * num * S) * sizeof(float);
+    const int64_t tiles = (S + kLqKeys - 1) / kLqKeys;
+    const int64_t pitch_bytes = (H * num * esz + 15) & ~(int64_t)15;           // one key's scores: whole 16-byte words
+    return (size_t)(S * pitch_bytes + H * num * tiles * 8 + 16);
+}
+
+template <int DT>
+static int launch_lq(const void* q, const void* k, int64_t H, int64_t H_kv, int64_t num, int64_t S, int64_t dh,
+                     double scale, int causal, void* weights, void* importance, void* ws, int64_t lo, int64_t hi,
+                     int* l0, int* t16_end, hipStream_t st) {
+    constexpr int kB = Act<DT>::kBytes;
+    const int64_t lpk = dh * kB / 16;
+    const bool tiled = (dh * kB) % 16 == 0 && lpk >= 1 && lpk <= 64 && (lpk & (lpk - 1)) == 0 && H * num <= 4096;
+    if (!tiled) return launch_lq_general<DT>(q, k, H, H_kv, num, S, dh, scale, causal, weights, importance, ws, lo, hi, l0, t16_end, st);
+    const int rows = (int)((H / H_kv) * num), rows_total = (int)(H * num);
+    const int tiles = (int)((S + kLqKeys - 1) / kLqKeys);
+    void* scores = ws;
+    const int64_t pitch_bytes = ((int64_t)rows_total * kB + 15) & ~(int64_t)15;
+    const int pitch = (int)(pitch_bytes / kB);
+    float2* tstats = (float2*)((char*)ws + S * pitch_bytes);
+    const dim3 grid((unsigned)tiles, (unsigned)H_kv, (unsigned)((rows + kLqRows - 1) / kLqRows));
+#define FF_LQ_TILE(LPK)                                                                                                   \
+    hipLaunchKernelGGL((k_lq_tile<DT, LPK>), grid, dim3(256), 0, st, q, k, (int)H, (int)H_kv, (int)num, (int)S, (float)scale, \
+                       causal, pitch, scores, tstats, tiles)
+    switch ((int)lpk) {
+        case 1: FF_LQ_TILE(1); break;
+        case 2: FF_LQ_TILE(2); break;
+        case 4: FF_LQ_TILE(4); break;
+        case 8: FF_LQ_TILE(8); break;
+        case 16: FF_LQ_TILE(16); break;
+        case 32: FF_LQ_TILE(32); break;
+        default: FF_LQ_TILE(64);
+    }
+#undef FF_LQ_TILE
+    hipLaunchKernelGGL(k_lq_finish<DT>, dim3((unsigned)((S + 255) / 256)), dim3(256), (size_t)rows_total * 2 * sizeof(float), st,
+                       (const void*)scores, (const float2*)tstats, rows_total, pitch, tiles, (int)S, weights, importance, (int)lo,
+                       (int)hi, l0, t16_end);
     return (int)hipGetLastError();
 }
 
@@ -187,23 +423,41 @@ extern "C" int ff_head_mean(const void* attn_w, int dtype, int64_t H, int64_t nu
     return ff::launch_head_mean(attn_w, dtype, H, num, S, importance, 0, 0, nullptr, nullptr, (hipStream_t)stream);
 }
 
+namespace ff {
+int* ws_l0(void* ws);
+int* ws_t16_end(void* ws, size_t ws_bytes);
+}  // namespace ff
+
+extern "C" size_t ff_last_query_workspace_bytes(int dtype, int64_t H, int64_t num, int64_t S, int64_t dh) {
+    if (H < 1 || num < 1 || S < 1 || dh < 1) return 0;
+    return ff::lq_ws_bytes(dtype, H, num, S, dh);
+}
+
 extern "C" int ff_last_query_attention(const void* q_last, const void* k, int dtype, int64_t H, int64_t H_kv,
                                        int64_t num, int64_t S, int64_t dh, double scale, int causal,
-                                       void* weights, void* importance, void* ws, size_t ws_bytes,
-                                       ff_stream_t stream) {
+                                       void* weights, void* importance, int64_t sel_lo, int64_t sel_hi, void* sel_ws,
+                                       size_t sel_ws_bytes, void* ws, size_t ws_bytes, ff_stream_t stream) {
     if (!q_last || !k || !ws || H < 1 || H_kv < 1 || num < 1 || S < 1 || dh < 1) return FF_ERR_ARG;
     if (H % H_kv) return FF_ERR_ARG;
     if (!weights && !importance) return FF_ERR_ARG;
+    if (dtype != FF_F32 && dtype != FF_BF16 && dtype != FF_F16) return FF_ERR_ARG;
     if (S >= (1ll << 31) || H * num * S >= (1ll << 40)) return FF_ERR_UNSUPPORTED;
     if ((size_t)ff::kRowsPerBlock * dh * sizeof(float) > 64 * 1024) return FF_ERR_UNSUPPORTED;
     const int64_t esz = dtype == FF_F32 ? 4 : 2;
-    if (((dh * esz) & 15) || ((uintptr_t)k & 15)) return FF_ERR_ALIGN;
-    if (ws_bytes < (size_t)(2 * H * num * S) * sizeof(float)) return FF_ERR_WORKSPACE;
+    if (((dh * esz) & 15) || ((uintptr_t)k & 15) || ((uintptr_t)q_last & 15) || ((uintptr_t)ws & 15)) return FF_ERR_ALIGN;
+    if (ws_bytes < ff::lq_ws_bytes(dtype, H, num, S, dh)) return FF_ERR_WORKSPACE;
+    int *l0 = nullptr, *t16_end = nullptr;
+    if (sel_ws) {                                   // accumulate the select tables of importance[sel_lo, sel_hi)
+        if (!importance || sel_lo < 0 || sel_hi > S || sel_lo > sel_hi) return FF_ERR_ARG;
+        if (sel_ws_bytes < ff_workspace_bytes(S, 1)) return FF_ERR_WORKSPACE;
+        if ((uintptr_t)sel_ws & 15) return FF_ERR_ALIGN;
+        l0 = ff::ws_l0(sel_ws);
+        t16_end = ff::ws_t16_end(sel_ws, sel_ws_bytes);
+    }
     hipStream_t st = (hipStream_t)stream;
     switch (dtype) {
-        case FF_F32: return ff::launch_lq<FF_F32>(q_last, k, H, H_kv, num, S, dh, scale, causal, weights, importance, ws, st);
-        case FF_BF16: return ff::launch_lq<FF_BF16>(q_last, k, H, H_kv, num, S, dh, scale, causal, weights, importance, ws, st);
-        case FF_F16: return ff::launch_lq<FF_F16>(q_last, k, H, H_kv, num, S, dh, scale, causal, weights, importance, ws, st);
-        default: return FF_ERR_ARG;
+        case FF_F32: return ff::launch_lq<FF_F32>(q_last, k, H, H_kv, num, S, dh, scale, causal, weights, importance, ws, sel_lo, sel_hi, l0, t16_end, st);
+        case FF_BF16: return ff::launch_lq<FF_BF16>(q_last, k, H, H_kv, num, S, dh, scale, causal, weights, importance, ws, sel_lo, sel_hi, l0, t16_end, st);
+        default: return ff::launch_lq<FF_F16>(q_last, k, H, H_kv, num, S, dh, scale, causal, weights, importance, ws, sel_lo, sel_hi, l0, t16_end, st);
     }
 }

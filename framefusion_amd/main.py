@@ -434,6 +434,24 @@ class FrameFusion(nn.Module):
             out.update(sim=sc.sim(c["dtype"], nv), order=c["order"][:nv])
         return out
 
+    def _expect_importance(self, S: int, dtype, device):
+        """The attention hook is about to compute the importance of a prune call over S tokens: hand out the
+        workspace (as the `select` argument of utils._launch_last_query) in which the importance kernel
+        accumulates the select tables, and a token _prune recognises the tensor by."""
+        with torch.cuda.device(device):
+            sc = self._scratch_for(device, S, dtype)
+            start = _to_int(self.image_token_start_index)
+            n_img = _to_int(self.image_token_length - (self.original_length - S))
+            if n_img < 0 or start < 0 or start + n_img > S:
+                return None, None
+            if sc.dirty:
+                sc.ws.zero_()
+                sc.stats.zero_()
+            sc.dirty = True                       # until the prune call has consumed (and cleared) the tables
+            token = (id(sc), sc.seq, S, start, n_img, dtype)
+            sc.tables_token = token
+            return (start, start + n_img, sc.ws.data_ptr(), sc.ws_bytes), token
+
     # ---- prune call: main.py:61-101 ----------------------------------------------------------------
     def _prune(self, hidden_states, position_embeddings, attention_mask, self_attn_weights, residual=None):
         _lib.require_gpu(hidden_states, "FrameFusion.forward")
@@ -465,7 +483,13 @@ class FrameFusion(nn.Module):
         if k < 0 or k > n_img:
             raise RuntimeError("selected index k out of range")                     # torch.topk's error
         L_out = q_len - n_img + k
-        if sc.dirty:                 # a merge call died half-way: the select tables must start from zero
+        # importance from last_query_importance(..., framefusion=self): its kernel has already filled the
+        # select tables of exactly this call in the workspace
+        token = getattr(w, "_ff_tables", None)
+        tables_ready = int(token is not None and token == getattr(sc, "tables_token", None) and
+                           token == (id(sc), sc.seq, q_len, start, n_img, w.dtype) and w.shape[1] * w.shape[2] == 1)
+        sc.tables_token = None
+        if sc.dirty and not tables_ready:   # a call died half-way: the select tables must start from zero
             sc.ws.zero_()
             sc.stats.zero_()
             sc.dirty = False
@@ -479,7 +503,7 @@ class FrameFusion(nn.Module):
         addend = residual.contiguous() if residual is not None else None
         _lib.check(lib.ff_prune_step(hidden.data_ptr(), addend.data_ptr() if addend is not None else None,
                                      out.data_ptr(), code, q_len, d, L_out,
-                                     w.data_ptr(), w_code, w.shape[1], w.shape[2], imp.data_ptr(), 0,
+                                     w.data_ptr(), w_code, w.shape[1], w.shape[2], imp.data_ptr(), tables_ready,
                                      start, n_img, k, sc.member.data_ptr(), sc.dst.data_ptr(), sc.keep.data_ptr(),
                                      sc.stats.data_ptr(), aux, n_aux, sc.ws.data_ptr(), sc.ws_bytes, stream),
                    "ff_prune_step")

@@ -38,7 +38,7 @@ def qwen2_attention_forward(self, hidden_states, position_embeddings, attention_
     ff = self.framefusion
     if q_len > 1 and ff.finish_merging and not ff.finish_pruning:            # modeling_qwen2.py:168
         importance = last_query_importance(query_states, key_states, num=1, is_causal=attention_mask is None,
-                                           scale=self.scaling)
+                                           scale=self.scaling, framefusion=ff)
 
     attention_interface = ALL_ATTENTION_FUNCTIONS.get_interface(self.config._attn_implementation, eager_attention_forward)
     attn_output, _ = attention_interface(self, query_states, key_states, value_states, attention_mask,

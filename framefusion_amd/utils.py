@@ -27,7 +27,7 @@ def get_attr_by_name(obj: Any, name: str) -> Any:
     return node
 
 
-def _launch_last_query(query, key, num, is_causal, scale, want_weights, want_importance):
+def _launch_last_query(query, key, num, is_causal, scale, want_weights, want_importance, select=None):
     _lib.require_gpu(query, "scaled_dot_product_attention")
     if query.ndim != 4 or key.ndim != 4 or query.shape[0] != 1 or key.shape[0] != 1:
         raise FrameFusionHipError("expected query [1, H, L, dh] and key [1, H_kv, S, dh]")
@@ -46,12 +46,14 @@ def _launch_last_query(query, key, num, is_causal, scale, want_weights, want_imp
     dev = query.device
     weights = torch.empty(1, H, num, S, dtype=query.dtype, device=dev) if want_weights else None
     importance = torch.empty(S, dtype=query.dtype, device=dev) if want_importance else None
-    ws_bytes = 2 * H * num * S * 4
+    ws_bytes = int(lib.ff_last_query_workspace_bytes(code, H, num, S, dh))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    sel_lo, sel_hi, sel_ws, sel_bytes = select if select is not None else (0, 0, None, 0)
     rc = lib.ff_last_query_attention(q_last.data_ptr(), k.data_ptr(), code, H, H_kv, num, S, dh, float(factor),
                                      1 if is_causal else 0,
                                      weights.data_ptr() if want_weights else None,
                                      importance.data_ptr() if want_importance else None,
+                                     sel_lo, sel_hi, sel_ws, sel_bytes,
                                      ws.data_ptr(), ws_bytes, _lib.stream_ptr())
     _lib.check(rc, "ff_last_query_attention")
     return weights, importance
@@ -71,8 +73,17 @@ def scaled_dot_product_attention(query, key, value, num=1, attn_mask=None, dropo
     return weights
 
 
-def last_query_importance(query, key, num=1, is_causal=True, scale=None) -> torch.Tensor:
+def last_query_importance(query, key, num=1, is_causal=True, scale=None, framefusion=None) -> torch.Tensor:
     """Fused form for the attention hook: the head/query mean of the weights
-    above, shaped [1, 1, 1, S] so that FrameFusion.forward's own mean (main.py:70) is the identity."""
-    _, imp = _launch_last_query(query, key, num, is_causal, scale, False, True)
-    return imp[None, None, None, :]
+    above, shaped [1, 1, 1, S] so that FrameFusion.forward's own mean (main.py:70) is the identity.
+    With `framefusion` (the instance whose prune call will consume the result) the importance kernel
+    also accumulates the select tables of that call in the instance's workspace: the prune is then
+    plan + gather, nothing else."""
+    select, token = None, None
+    if framefusion is not None and query.is_cuda:
+        select, token = framefusion._expect_importance(key.shape[2], query.dtype, query.device)
+    _, imp = _launch_last_query(query, key, num, is_causal, scale, False, True, select)
+    out = imp[None, None, None, :]
+    if token is not None:
+        out._ff_tables = token
+    return out

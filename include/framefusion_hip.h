@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FF_ABI_VERSION 5
+#define FF_ABI_VERSION 6
 
 enum { FF_F32 = 0, FF_BF16 = 1, FF_F16 = 2 };
 
@@ -195,11 +195,18 @@ int ff_head_mean(const void* attn_w, int dtype, int64_t H, int64_t num, int64_t 
 /* Last-`num`-query attention probabilities with the reference's staged rounding:
  * p = T(softmax_fp32(T(T(q K^T) * scale) + causal_bias)).  q_last [H, num, dh], k [H_kv, S, dh]
  * (GQA: head h reads kv head h / (H/H_kv), the repeat_kv of modeling_qwen2.py:147 folded in),
- * weights [H, num, S] (may be NULL), importance [S] (may be NULL) = head_mean(weights). */
+ * weights [H, num, S] (may be NULL), importance [S] (may be NULL) = head_mean(weights).
+ * sel_ws (optional, with importance): the workspace of the prune call that will consume the
+ * importance - the select tables of importance[sel_lo, sel_hi) are accumulated on the way, and
+ * ff_prune_step is then called with H = num = 1, attn_w = importance, tables_ready = 1.
+ * ws: ff_last_query_workspace_bytes() bytes, 16-byte aligned (scores as T, key-major, + tile statistics).
+ * Two launches when dh * sizeof(T) / 16 is a power of two (every real head size), else three. */
+size_t ff_last_query_workspace_bytes(int dtype, int64_t H, int64_t num, int64_t S, int64_t dh);
 int ff_last_query_attention(const void* q_last, const void* k, int dtype, int64_t H, int64_t H_kv,
                             int64_t num, int64_t S, int64_t dh, double scale, int causal,
-                            void* weights, void* importance, void* ws, size_t ws_bytes,
-                            ff_stream_t stream);
+                            void* weights, void* importance,
+                            int64_t sel_lo, int64_t sel_hi, void* sel_ws, size_t sel_ws_bytes,
+                            void* ws, size_t ws_bytes, ff_stream_t stream);
 
 /* ---- token layout (the patch_type builders of the reference's multimodal packers) -------------
  * The packers find the visual span in the prompt ids with torch.where and build patch_type as a

@@ -251,6 +251,16 @@ def test_hip_matches_reference_full_size_prune(name):
     check_prune(g, name, imp.reshape(-1).cpu(), kept, "hip",
                 torch.stack((w[0, 0, 0], w[0, H - 1, num - 1])).cpu())
     assert torch.equal(hg, hd[:, pg[0]])
+    # importance computed WITH the instance: the kernel also fills the select tables of the prune call
+    f3 = ffa.FrameFusion(0.3, 0.6, 0.1)
+    f3.prepare(torch.zeros(1, S, dtype=torch.long, device=DEV), 1, start, start + n_img, img_len, orig_len,
+               finish_merging=True, sparsity_list=list(g[f"{name}/sparsity"]))
+    imp3 = ffa.last_query_importance(qd, kd, num=num, is_causal=True, framefusion=f3)
+    assert torch.equal(imp3, imp) and getattr(imp3, "_ff_tables", None) is not None
+    hg3, pg3, _ = f3(hd, torch.arange(S, device=DEV)[None], None, imp3)
+    assert torch.equal(pg3, pg) and torch.equal(hg3, hg)
+    # ... and the workspace is clean again: a merge call on the same instance behaves
+    assert not f3._scratch[("cuda", 0)].dirty
     # the unfused form (weights [1, H, num, S] -> head mean inside the prune call) keeps the same tokens
     f2 = ffa.FrameFusion(0.3, 0.6, 0.1)
     f2.prepare(torch.zeros(1, S, dtype=torch.long, device=DEV), 1, start, start + n_img, img_len, orig_len,

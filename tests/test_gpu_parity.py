@@ -318,6 +318,20 @@ def test_importance_golden(golden, name):
                           rtol=tol, atol=1e-30)
 
 
+def test_importance_odd_head_size_general_path():
+    """dh * sizeof(T) / 16 not a power of two (dh = 24 bf16 -> 3 lanes per key): the general kernels"""
+    g = torch.Generator().manual_seed(5)
+    q = harness.snap(torch.randn(1, 6, 5, 24, generator=g), torch.bfloat16)
+    k = harness.snap(torch.randn(1, 2, 300, 24, generator=g), torch.bfloat16)
+    for num in (1, 4):
+        want = orc.last_query_attention(q, k, num=num, is_causal=True, enable_gqa=True)
+        got = ffa.scaled_dot_product_attention(dev(q), dev(k), None, num=num, is_causal=True, enable_gqa=True)
+        assert torch.allclose(got.cpu().float(), want.float(), rtol=2 ** -7, atol=1e-30)
+        assert float((got.cpu().float() != want.float()).float().mean()) <= 5e-3
+        imp = ffa.last_query_importance(dev(q), dev(k), num=num, is_causal=True)
+        assert torch.allclose(imp.reshape(-1).cpu().float(), torch.mean(want, dim=(1, 2))[0].float(), rtol=2 ** -7, atol=1e-30)
+
+
 def test_head_mean_exact():
     w = harness.attention_stub(28, 4, 5000, torch.bfloat16)
     want = torch.mean(w, dim=(1, 2))[0]

@@ -47,11 +47,19 @@ def main():
         ff.prepare(pt, 576, start, start + n_img, n_img, a.S, finish_merging=True, sparsity_list=[0.5])
         return ff(h, [cos, sin], None, weights)
 
+    def fused():
+        ff.prepare(pt, 576, start, start + n_img, n_img, a.S, finish_merging=True, sparsity_list=[0.5])
+        return ff(h, [cos, sin], None, ffa.last_query_importance(q, k, num=a.num, is_causal=True, framefusion=ff))
+
     t_p = timeit(lambda: prune(w))
     t_pi = timeit(lambda: prune(imp))
+    t_f = timeit(fused)
     out = prune(w)[0]
-    print(f"S={a.S} H={a.H}/{a.Hkv} dh={a.dh} num={a.num}: weights {t_w:.1f} us, fused importance {t_i:.1f} us, "
-          f"prune call (weights) {t_p:.1f} us, prune call (importance) {t_pi:.1f} us, {a.S} -> {out.shape[1]}")
+    print(f"S={a.S} H={a.H}/{a.Hkv} dh={a.dh} num={a.num} d={a.dim}: weights {t_w:.1f} us, importance {t_i:.1f} us, "
+          f"prune call (weights) {t_p:.1f} us, prune call (importance) {t_pi:.1f} us, importance(+tables) + prune {t_f:.1f} us, "
+          f"{a.S} -> {out.shape[1]}")
+    kb = a.Hkv * a.S * a.dh * 2
+    print(f"importance kernels: K traffic {kb/1e6:.0f} MB -> {kb/t_i/1e3:.0f} GB/s")
     bytes_prune = (a.S + out.shape[1]) * a.dim * 2
     print(f"prune gather algorithmic {bytes_prune/1e6:.0f} MB -> {bytes_prune/t_pi/1e3:.0f} GB/s")
 
