@@ -3,21 +3,27 @@
 synthetic [1, 64 frames x 576 tokens, 4096] bf16 activations (BASELINE.json configs[1], "C2").
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = prepare() + one FrameFusion.forward call (by-patch order - derived inside the similarity
-kernel from prepare()'s layout scalars and verified there -, K1 similarity, K2/K3 plan, K4
-merge+compaction, one 256-byte result block) on one video sample resident in HBM.  With N ranks each
-rank reduces its own independent sample (seed + rank): weak scaling, no data-path collective.
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (live hipEvent timing on the
-launch stream, algorithmic bytes from DESIGN.md); `cpu_baseline` times the CPU oracle
-(oracle/ff_oracle.py, a torch-CPU port of the reference path) on the same input.
+`--gpus N` (N > 1) starts its own N ranks, one per GPU (framefusion_amd/dp.py: torch.distributed.run on
+127.0.0.1, RCCL); it also runs unchanged under an external `python -m torch.distributed.run`.
+
+A step = prepare() + one FrameFusion.forward call - three launches: K1 similarity (derives and verifies
+the by-patch order from prepare()'s layout scalars, accumulates the select tables), the plan kernel, K4
+merge + compaction - and one 256-byte result block, on one video sample resident in HBM.  With N ranks
+each rank reduces its own independent sample (seed + rank): weak scaling, no data-path collective; rank
+0's workload description is broadcast and the per-rank records are all_gathered.  Rank 0 prints ONE JSON
+line.  `roofline` prices the dominant kernel (live hipEvent timing on the launch stream, algorithmic bytes
+from DESIGN.md); `cpu_baseline` times the CPU oracle (oracle/ff_oracle.py, a torch-CPU port of the reference
+path) on the same input; `eager_gpu_baseline` runs the same torch port on the MI355X (what the reference costs
+through PyTorch-ROCm eager: the denominator of the >= 5x target); `extra.configs` times BASELINE.json's
+other single-GPU configurations (C3, C5) and the real LLaVA-Video-7B shape.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -31,7 +37,7 @@ FRAMES, PATCHES, DIM, HEAD_DIM = 64, 576, 4096, 128
 COST, THRESHOLD, RATIO_LB = 0.3, 0.6, 0.1          # reference operating point (README.md:123)
 P_CHANGE, SIGMA = 0.2, 0.3                         # top-k regime 36864 -> 11060
 HBM_PEAK_GBS = 8000.0                              # MI355X_MICROARCH.md: 8 TB/s spec
-BASELINE_METRIC = "vision tokens reduced/sec (64 frames\u00d7576 tok, d=4096 bf16), 1\u21928 MI355X"   # BASELINE.json
+BASELINE_METRIC = "vision tokens reduced/sec (64 frames×576 tok, d=4096 bf16), 1→8 MI355X"   # BASELINE.json
 
 
 def parse():
@@ -49,20 +55,20 @@ def parse():
     ap.add_argument("--oversubscribe", action="store_true",
                     help="allow more ranks than GPUs (rank r -> GPU r %% device_count; gloo only: RCCL refuses two ranks "
                          "on one device) - exercises the N > 1 path on a 1-GPU box")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip cpu_baseline and eager_gpu_baseline")
+    ap.add_argument("--no-extra", action="store_true", help="skip extra.configs (C3 / C5 / 7B shape)")
     ap.add_argument("--cpu-calls", type=int, default=5)
     return ap.parse_args()
 
 
+def merge_bytes(L_in, L_out, d, elt, head_dim, pe_outer=1, pe_tables=2):
+    """DESIGN.md §3 / SURVEY.md §8d: compulsory HBM traffic of one merge (or prune) call."""
+    return L_in * d * elt + L_out * d * elt + pe_tables * (L_in + L_out) * head_dim * elt * pe_outer + 8 * (L_in + L_out)
+
+
 def algorithmic_bytes(L_in, L_out, nv, d, elt, head_dim, pe_outer=1):
-    """DESIGN.md §Roofline / SURVEY.md §8d: compulsory HBM traffic of one merge call."""
-    hidden_in = L_in * d * elt
-    hidden_out = L_out * d * elt
-    pos = 2 * (L_in + L_out) * head_dim * elt * pe_outer
-    ints = 8 * (L_in + L_out)
-    return dict(step=hidden_in + hidden_out + pos + ints,
-                similarity=nv * d * elt + nv * elt,
-                merge_compact=hidden_in + hidden_out + pos + ints)
+    step = merge_bytes(L_in, L_out, d, elt, head_dim, pe_outer)
+    return dict(step=step, similarity=nv * d * elt + nv * elt, merge_compact=step)
 
 
 def main():
@@ -120,85 +126,15 @@ def main():
     # whole-job numbers: tokens summed over ranks; one record per rank all_gathered for the report
     _, tok_all = dp.aggregate(dist, elapsed, float(reduced * args.steps), dev)
     per_rank = dp.gather_records(dist, (rank, dev.index, L, L_out, elapsed / args.steps * 1e3), dev)
-    B = 1
 
     result = None
     if rank == 0:
-        # ---- per-kernel timing with events on the launch stream (stage entry points) -------------
-        lib = _lib.load()
-        sc = ff._scratch[(dev.type, dev.index)]
-        order_buf = info["order"]
-        stream = _lib.stream_ptr()
-        elt = hidden.element_size()
-        nv = info["nv"]
-        sim = sc.sim(hidden.dtype, L)
-        out_buf = torch.empty(1, L, d, dtype=hidden.dtype, device=dev)
-        ptype_out = torch.empty(1, L, dtype=torch.int64, device=dev)
-        cos_o, sin_o = torch.empty_like(cos), torch.empty_like(sin)
-        aux = (_lib.FFAux * _lib.MAX_AUX)()
-        aux[0] = _lib.FFAux(ptype.data_ptr(), ptype_out.data_ptr(), 8, 1)
-        aux[1] = _lib.FFAux(cos.data_ptr(), cos_o.data_ptr(), HEAD_DIM * elt, 1)
-        aux[2] = _lib.FFAux(sin.data_ptr(), sin_o.data_ptr(), HEAD_DIM * elt, 1)
-        thr = float(torch.tensor(THRESHOLD, dtype=hidden.dtype))
-        sub = float(ff._compute_pruning_ratio([], COST))
-        rep_no = [0]
-
-        def cur_hidden():           # same alternation as the timed loop (set per repetition below)
-            return hidden_alt if rep_no[0] & 1 else hidden
-        stages = {
-            "order": lambda: lib.ff_build_order(ptype.data_ptr(), L, P, order_buf.data_ptr(), None, sc.stats.data_ptr(),
-                                                sc.ws.data_ptr(), sc.ws_bytes, stream),
-            "similarity": lambda: lib.ff_pair_similarity(cur_hidden().data_ptr(), _lib.FF_BF16, L, d, ptype.data_ptr(),
-                                                         order_buf.data_ptr(), sc.stats.data_ptr(), sim.data_ptr(), stream),
-            "plan": lambda: lib.ff_plan_merge(sim.data_ptr(), _lib.FF_BF16, order_buf.data_ptr(), L, thr, sub, RATIO_LB,
-                                              sc.member.data_ptr(), sc.dst.data_ptr(), sc.keep.data_ptr(),
-                                              sc.stats.data_ptr(), sc.ws.data_ptr(), sc.ws_bytes, stream),
-            "merge_compact": lambda: lib.ff_merge_compact(cur_hidden().data_ptr(), out_buf.data_ptr(), _lib.FF_BF16, L, d, L,
-                                                          order_buf.data_ptr(), sc.member.data_ptr(), 1, sc.dst.data_ptr(),
-                                                          sc.keep.data_ptr(), aux, 3, stream),
-        }
-        # per-kernel durations: the four stages in the order of a real step (each kernel sees the
-        # cache state its predecessor leaves behind), hipEvents between the stages on the launch
-        # stream, launches queued ahead so host latency is not billed to a kernel
-        reps = max(10, min(args.steps, 30))
-        names = list(stages)
-        for name in names:
-            _lib.check(stages[name](), name)
-        torch.cuda.synchronize()
-        marks = [[torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)] for _ in range(reps)]
-        for r in range(reps):
-            rep_no[0] = r
-            marks[r][0].record()
-            for q, name in enumerate(names):
-                _lib.check(stages[name](), name)
-                marks[r][q + 1].record()
-        torch.cuda.synchronize()
-        kernel_us = {name: sum(marks[r][q].elapsed_time(marks[r][q + 1]) for r in range(reps)) / reps * 1e3
-                     for q, name in enumerate(names)}
-        alg = algorithmic_bytes(L, L_out, nv, d, elt, HEAD_DIM)
-        dominant = max(("similarity", "merge_compact"), key=lambda k: kernel_us[k])
-        # An event pair around ONE launch also times two command-processor round trips (~7 us here;
-        # the rocprofv3 kernel trace does not see them).  For the roofline figure the dominant
-        # kernel is therefore timed differentially, still in pipeline order and with the same cache
-        # state: second pass with no event between it and its predecessor,
-        #   t(kernel) = t(predecessor + kernel, one event pair) - t(predecessor, one event pair),
-        # so the event overhead cancels and what remains is the launch duration plus the ~0.2 us
-        # dependency gap between the two kernels.
-        q_dom = names.index(dominant)
-        pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-        for r in range(reps):
-            rep_no[0] = r
-            for q, name in enumerate(names):
-                if q == q_dom - 1:
-                    pairs[r][0].record()
-                _lib.check(stages[name](), name)
-                if q == q_dom:
-                    pairs[r][1].record()
-        torch.cuda.synchronize()
-        both_us = sum(a.elapsed_time(b) for a, b in pairs) / reps * 1e3
-        dense_us = both_us - kernel_us[names[q_dom - 1]]
+        spread = step_spread(step, max(20, min(args.steps, 100)))
+        kernel_us, dominant, dense_us = stage_times(ff, _lib, hidden, hidden_alt, ptype, cos, sin, P, L, d, info, dev, args.steps)
+        alg = algorithmic_bytes(L, L_out, info["nv"], d, hidden.element_size(), HEAD_DIM)
         achieved = alg[dominant] / (dense_us * 1e-6) / 1e9
         ms_per_step = t_max / args.steps * 1e3
+        headline = (F, P, d) == (FRAMES, PATCHES, DIM)
         result = {
             "metric": BASELINE_METRIC,
             "value": tok_all / t_max,
@@ -211,6 +147,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
+            "step_us": spread,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -219,27 +156,118 @@ def main():
             "config": {"workload": f"C2: one FrameFusion.forward merge call on [1, {F}x{P}, {d}] bf16, "
                                    f"cost={COST} thr={THRESHOLD} lb={RATIO_LB}, p_change={args.p_change} "
                                    f"({'top-k' if info['branch'] else 'threshold'} branch), one sample per GPU",
-                       "tokens_in": L, "tokens_out": L_out, "samples_per_gpu_per_step": B,
-                       "tokens_processed_per_s": world * B * L * args.steps / t_max,
+                       "tokens_in": L, "tokens_out": L_out, "samples_per_gpu_per_step": 1,
+                       "tokens_processed_per_s": world * L * args.steps / t_max,
                        "parallelism": f"dp{world} (independent samples)"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": profiled_traffic(dominant) if (F, P, d) == (FRAMES, PATCHES, DIM) else None,
+                         "traffic": profiled_traffic(dominant) if headline else None,
                          "algorithmic_bytes": alg[dominant], "kernel_us": dense_us,
                          "kernel_us_own_event_pair": kernel_us[dominant]},
             "kernels_us": kernel_us,
             "step_roofline": {"algorithmic_bytes": alg["step"], "achieved": alg["step"] / (ms_per_step * 1e-3) / 1e9,
                               "frac": alg["step"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
-        if world == 1 and (F, P, d) == (FRAMES, PATCHES, DIM):
-            result["cascade"] = prefill_cascade(dev)
+        if world == 1 and headline and not args.no_extra:
+            result["extra"] = {"configs": extra_configs(dev)}
         if not args.no_cpu_baseline and world == 1:         # reported at N = 1 only (other ranks would wait)
-            result["cpu_baseline"] = cpu_baseline(hidden, ptype, cos, sin, P, L, args.cpu_calls)
+            result["cpu_baseline"], result["eager_gpu_baseline"] = baselines(hidden, ptype, cos, sin, P, L, L_out,
+                                                                              args.cpu_calls, ms_per_step)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))
+
+
+def step_spread(step, n):
+    """min / median / max of the step on the GPU clock: events between consecutive steps of a second, untimed
+    run of the same loop (host and device in the same lock-step as the timed region)."""
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+    for _ in range(3):
+        step()
+    marks[0].record()
+    for i in range(n):
+        step()
+        marks[i + 1].record()
+    torch.cuda.synchronize()
+    us = sorted(marks[i].elapsed_time(marks[i + 1]) * 1e3 for i in range(n))
+    return {"min": us[0], "median": statistics.median(us), "max": us[-1], "p90": us[int(0.9 * (n - 1))], "samples": n}
+
+
+def stage_times(ff, _lib, hidden, hidden_alt, ptype, cos, sin, P, L, d, info, dev, steps):
+    """Per-kernel durations through the stage entry points of the C ABI, in the order of a real step (each
+    kernel sees the cache state its predecessor leaves behind), hipEvents on the launch stream, launches
+    queued ahead so host latency is not billed to a kernel.  The stand-alone plan stage also builds the
+    select tables and the inverse order itself (the fused step gets both from the similarity kernel): its
+    number is an upper bound of the in-step plan kernel (profiles/ has the in-step timeline)."""
+    lib = _lib.load()
+    sc = ff._scratch[(dev.type, dev.index)]
+    order_buf = info["order"]
+    stream = _lib.stream_ptr()
+    elt = hidden.element_size()
+    sim = sc.sim(hidden.dtype, L)
+    out_buf = torch.empty(1, L, d, dtype=hidden.dtype, device=dev)
+    ptype_out = torch.empty(1, L, dtype=torch.int64, device=dev)
+    cos_o, sin_o = torch.empty_like(cos), torch.empty_like(sin)
+    aux = (_lib.FFAux * _lib.MAX_AUX)()
+    aux[0] = _lib.FFAux(ptype.data_ptr(), ptype_out.data_ptr(), 8, 1)
+    aux[1] = _lib.FFAux(cos.data_ptr(), cos_o.data_ptr(), HEAD_DIM * elt, 1)
+    aux[2] = _lib.FFAux(sin.data_ptr(), sin_o.data_ptr(), HEAD_DIM * elt, 1)
+    thr = float(torch.tensor(THRESHOLD, dtype=hidden.dtype))
+    sub = float(ff._compute_pruning_ratio([], COST))
+    rep_no = [0]
+
+    def cur_hidden():           # same alternation as the timed loop (set per repetition below)
+        return hidden_alt if rep_no[0] & 1 else hidden
+    stages = {
+        "order": lambda: lib.ff_build_order(ptype.data_ptr(), L, P, order_buf.data_ptr(), None, sc.stats.data_ptr(),
+                                            sc.ws.data_ptr(), sc.ws_bytes, stream),
+        "similarity": lambda: lib.ff_pair_similarity(cur_hidden().data_ptr(), _lib.FF_BF16, L, d, ptype.data_ptr(),
+                                                     order_buf.data_ptr(), sc.stats.data_ptr(), sim.data_ptr(), stream),
+        "plan": lambda: lib.ff_plan_merge(sim.data_ptr(), _lib.FF_BF16, order_buf.data_ptr(), L, thr, sub, RATIO_LB,
+                                          sc.member.data_ptr(), sc.dst.data_ptr(), sc.keep.data_ptr(),
+                                          sc.stats.data_ptr(), sc.ws.data_ptr(), sc.ws_bytes, stream),
+        "merge_compact": lambda: lib.ff_merge_compact(cur_hidden().data_ptr(), out_buf.data_ptr(), _lib.FF_BF16, L, d, L,
+                                                      order_buf.data_ptr(), sc.member.data_ptr(), 1, sc.dst.data_ptr(),
+                                                      sc.keep.data_ptr(), aux, 3, stream),
+    }
+    reps = max(10, min(steps, 30))
+    names = list(stages)
+    for name in names:
+        _lib.check(stages[name](), name)
+    torch.cuda.synchronize()
+    marks = [[torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)] for _ in range(reps)]
+    for r in range(reps):
+        rep_no[0] = r
+        marks[r][0].record()
+        for q, name in enumerate(names):
+            _lib.check(stages[name](), name)
+            marks[r][q + 1].record()
+    torch.cuda.synchronize()
+    kernel_us = {name: sum(marks[r][q].elapsed_time(marks[r][q + 1]) for r in range(reps)) / reps * 1e3
+                 for q, name in enumerate(names)}
+    dominant = max(("similarity", "merge_compact"), key=lambda k: kernel_us[k])
+    # An event pair around ONE launch also times two command-processor round trips (~7 us here;
+    # the rocprofv3 kernel trace does not see them).  For the roofline figure the dominant
+    # kernel is therefore timed differentially, still in pipeline order and with the same cache
+    # state: second pass with no event between it and its predecessor,
+    #   t(kernel) = t(predecessor + kernel, one event pair) - t(predecessor, one event pair),
+    # so the event overhead cancels and what remains is the launch duration plus the ~0.2 us
+    # dependency gap between the two kernels.
+    q_dom = names.index(dominant)
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for r in range(reps):
+        rep_no[0] = r
+        for q, name in enumerate(names):
+            if q == q_dom - 1:
+                pairs[r][0].record()
+            _lib.check(stages[name](), name)
+            if q == q_dom:
+                pairs[r][1].record()
+    torch.cuda.synchronize()
+    both_us = sum(a.elapsed_time(b) for a, b in pairs) / reps * 1e3
+    return kernel_us, dominant, both_us - kernel_us[names[q_dom - 1]]
 
 
 def profiled_traffic(kernel):
@@ -263,64 +291,115 @@ def profiled_traffic(kernel):
     return total
 
 
-def prefill_cascade(dev, reps=8):
-    """Extra (SURVEY.md §8d "the full cascade per sample"): every FrameFusion.forward call of ONE
-    prefill in the threshold regime (p_change 0.5, 14 + 20 text tokens): call A merges, call B of
-    layer 0 finds nothing left (identity), call B of layer 1 prunes with last-query importance.
-    Host wall per call after a device synchronise, mean over `reps` prefills."""
-    import framefusion_amd as ffa
+def cascade(ffa, dev, F, P, d, p_change, thr, pre, post, heads, kv_heads, num, mrope, sigma_hi=1.6, reps=6, seed=1234):
+    """Every FrameFusion.forward call of ONE prefill (call A, then call B per layer until merging and pruning are
+    finished), the importance of the prune call computed by the HIP attention-hook kernel from synthetic q / K
+    (un-repeated GQA heads).  GPU time of the whole cascade (one synchronise at the end), mean over `reps`."""
     from framefusion_amd.synth import video_tokens, rotary_tables
-    h0, pt = video_tokens(FRAMES, PATCHES, DIM, p_change=0.5, sigma=SIGMA, sigma_hi=1.6, seed=1234, pre=14, post=20,
+    h0, pt = video_tokens(F, P, d, p_change=p_change, sigma=SIGMA, sigma_hi=sigma_hi, seed=seed, pre=pre, post=post,
                           dtype=torch.bfloat16, device=str(dev))
     L = h0.shape[1]
-    cos, sin = rotary_tables(L, HEAD_DIM, torch.bfloat16, device=str(dev))
-    ff = ffa.FrameFusion(COST, THRESHOLD, RATIO_LB)
+    pe0 = rotary_tables(L, HEAD_DIM, torch.bfloat16, device=str(dev), mrope=mrope)
     gen = torch.Generator(device=dev).manual_seed(7)
-    acc = []
+    q = torch.randn(1, heads, num, HEAD_DIM, generator=gen, device=dev).to(torch.bfloat16)
+    k_full = torch.randn(1, kv_heads, L, HEAD_DIM, generator=gen, device=dev).to(torch.bfloat16)
+    ff = ffa.FrameFusion(COST, thr, RATIO_LB)
+    elt, pe_outer = 2, (3 if mrope else 1)
+    times, calls, bytes_alg = [], [], 0
+    k_of = {L: k_full}                              # the layer's keys at the current sequence length
     for rep in range(reps + 2):
-        ff.prepare(pt, PATCHES, 14, 14 + FRAMES * PATCHES - 1, FRAMES * PATCHES, L)
-        h, pe, calls = h0, [cos, sin], []
+        ff.prepare(pt, P, pre, pre + F * P - 1, F * P, L)
+        h, pe = h0, [t for t in pe0]
+        calls, bytes_alg = [], 0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         while not (ff.finish_merging and ff.finish_pruning) and len(calls) < 30:
+            n_in = h.shape[1]
             w = None
             if ff.finish_merging and not ff.finish_pruning:            # what the attention hook hands over
-                w = torch.rand(1, 1, 1, h.shape[1], generator=gen, device=dev).to(torch.bfloat16)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            n_in = h.shape[1]
+                if n_in not in k_of:
+                    k_of[n_in] = k_full[:, :, :n_in].contiguous()
+                w = ffa.last_query_importance(q, k_of[n_in], num=num, is_causal=True, framefusion=ff)
+                bytes_alg += kv_heads * n_in * HEAD_DIM * elt
             h, pe, _ = ff(h, pe, None, w)
-            torch.cuda.synchronize()
-            calls.append((ff.last_call["kind"], n_in, h.shape[1], (time.perf_counter() - t0) * 1e6))
+            calls.append((ff.last_call["kind"], n_in, h.shape[1]))
+            bytes_alg += merge_bytes(n_in, h.shape[1], d, elt, HEAD_DIM, pe_outer)
+        torch.cuda.synchronize()
         if rep >= 2:
-            acc.append(calls)
-    n_calls = len(acc[0])
-    per_call = [{"kind": acc[0][i][0], "tokens_in": acc[0][i][1], "tokens_out": acc[0][i][2],
-                 "us": sum(c[i][3] for c in acc) / len(acc)} for i in range(n_calls)]
-    total = sum(c["us"] for c in per_call)
-    return {"workload": f"one prefill, [1, {L}, {DIM}] bf16, p_change=0.5 (threshold branch), importance = random [1,1,1,S]",
-            "calls": per_call, "total_us": total, "tokens_reduced_per_s": (L - per_call[-1]["tokens_out"]) / (total * 1e-6)}
+            times.append((time.perf_counter() - t0) * 1e6)
+    us = statistics.median(times)
+    L_final = calls[-1][2]
+    return {"tokens_in": L, "tokens_out": L_final, "calls": [f"{k}:{a}->{b}" for k, a, b in calls], "us": us,
+            "tokens_reduced_per_s": (L - L_final) / (us * 1e-6), "algorithmic_bytes": bytes_alg,
+            "hbm_frac": bytes_alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
 
 
-def cpu_baseline(hidden, ptype, cos, sin, P, L, calls):
-    """The reference's torch-CPU path, as restated in oracle/ff_oracle.py ("port"), on this box's
-    host cores: `calls` merge calls on the same sample (bounded: ~0.5-1 s each)."""
+def extra_configs(dev):
+    """BASELINE.json's other single-GPU configurations, each as a whole prefill cascade (host included: the
+    calls are issued back to back, one synchronise at the end)."""
+    import framefusion_amd as ffa
+    out = []
+    # C2 in the threshold regime (merge, identity, prune)
+    r = cascade(ffa, dev, FRAMES, PATCHES, DIM, 0.5, THRESHOLD, 14, 20, 32, 8, 1, False)
+    out.append({"workload": "C2 cascade: [1, 14+64x576+20, 4096] bf16, p_change=0.5 (threshold branch), thr=0.6", **r})
+    # C3: Qwen2-VL-7B, 128 frames = 64 temporal grids x 195 tokens, M-RoPE containers, num = 4 importance, threshold sweep
+    sweep = []
+    for thr in (0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9):
+        r = cascade(ffa, dev, 64, 195, 3584, 0.5, thr, 15, 12, 28, 4, 4, True, sigma_hi=1.8, reps=4, seed=77)
+        sweep.append({"similarity_lower_bound": thr, **r})
+    tot_us = sum(s["us"] for s in sweep)
+    out.append({"workload": "C3: Qwen2-VL-7B shape [1, 15+64x195+12, 3584] bf16, M-RoPE [3,1,L,128], num=4, "
+                            "similarity_lower_bound sweep 0.3..0.9 (one prefill cascade each)",
+                "sweep": sweep, "us": tot_us,
+                "tokens_reduced_per_s": sum(s["tokens_in"] - s["tokens_out"] for s in sweep) / (tot_us * 1e-6),
+                "hbm_frac": sum(s["algorithmic_bytes"] for s in sweep) / (tot_us * 1e-6) / 1e9 / HBM_PEAK_GBS})
+    # C5: LLaVA-Video-72B, d = 8192, H = 64 / H_kv = 8: merge, then importance inside the attention hook + prune
+    r = cascade(ffa, dev, 64, 576, 8192, 0.95, THRESHOLD, 14, 20, 64, 8, 1, False, sigma_hi=None)
+    out.append({"workload": "C5: LLaVA-Video-72B shape [1, 14+64x576+20, 8192] bf16, H=64/H_kv=8: merge call, fused "
+                            "attention importance + prune", **r})
+    r = cascade(ffa, dev, 64, 576, 8192, 0.2, THRESHOLD, 14, 20, 64, 8, 1, False, sigma_hi=None)
+    out.append({"workload": "C5 top-k regime: [1, 14+64x576+20, 8192] bf16, one merge call", **r})
+    # the real LLaVA-Video-7B token layout (14 x 15 per frame, d = 3584): the host, not HBM, sets the pace here
+    r = cascade(ffa, dev, 64, 210, 3584, 0.2, THRESHOLD, 14, 20, 28, 4, 1, False, sigma_hi=None)
+    out.append({"workload": "LLaVA-Video-7B real shape [1, 14+64x210+20, 3584] bf16, one merge call (top-k)", **r})
+    return out
+
+
+def baselines(hidden, ptype, cos, sin, P, L, L_out, calls, hip_ms):
+    """(cpu_baseline, eager_gpu_baseline): the reference's torch path, as restated in oracle/ff_oracle.py
+    ("port"), timed on this box's host cores and - the same code on GPU tensors - on the MI355X: what the
+    reference costs through PyTorch-ROCm eager (~450 aten dispatches, 17 host syncs per call)."""
     from oracle import ff_oracle as orc
     h, pt, c, s = hidden.cpu(), ptype.cpu(), cos.cpu(), sin.cpu()
     threads = torch.get_num_threads()
 
-    def one():
+    def one(hh, pp, cc, ss):
         f = orc.OracleFrameFusion(COST, THRESHOLD, RATIO_LB)
-        f.prepare(pt, P, 0, L, L, L)
-        o, _, _ = f.forward(h, [c, s], None)
+        f.prepare(pp, P, 0, L, L, L)
+        o, _, _ = f.forward(hh, [cc, ss], None)
         return o.shape[1]
 
-    one()
+    one(h, pt, c, s)
     t0 = time.perf_counter()
     for _ in range(calls):
-        lo = one()
+        lo = one(h, pt, c, s)
     dt = time.perf_counter() - t0
-    return {"value": (L - lo) * calls / dt, "unit": "tokens/s", "cores": threads, "kind": "port",
-            "sample": f"{calls} merge calls of the CPU oracle on the same [1, {L}, {hidden.shape[2]}] bf16 sample "
-                      f"({dt / calls * 1e3:.0f} ms per call, torch {torch.__version__} CPU, {os.cpu_count()} logical cores)"}
+    cpu = {"value": (L - lo) * calls / dt, "unit": "tokens/s", "cores": threads, "kind": "port",
+           "sample": f"{calls} merge calls of the CPU oracle on the same [1, {L}, {hidden.shape[2]}] bf16 sample "
+                     f"({dt / calls * 1e3:.0f} ms per call, torch {torch.__version__} CPU, {os.cpu_count()} logical cores)"}
+    n = 5
+    for _ in range(2):
+        one(hidden, ptype, cos, sin)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        lg = one(hidden, ptype, cos, sin)
+    torch.cuda.synchronize()
+    eager_ms = (time.perf_counter() - t0) / n * 1e3
+    eager = {"value": (L - lg) / (eager_ms * 1e-3), "unit": "tokens/s", "ms_per_call": eager_ms, "tokens_out": lg,
+             "kind": "torch port of the reference path, eager on the MI355X (same sample, same tie rule)",
+             "speedup_of_this_build": eager_ms / hip_ms}
+    return cpu, eager
 
 
 if __name__ == "__main__":
