@@ -76,10 +76,12 @@ def test_c2_gaussian_within_tolerance():
     assert float((rel > 1e-3).float().mean()) <= 1e-3                    # bf16 hidden within 1e-3 rel
 
 
-@pytest.mark.parametrize("thr", [0.3, 0.5, 0.7, 0.9])
-def test_c3_qwen2vl_shape_threshold_sweep(thr):
-    """Qwen2-VL-7B shape: 64 temporal grids x 180 tokens, d=3584, M-RoPE containers, num=4 importance."""
-    F, P, d, pre, post = 64, 180, 3584, 15, 12
+@pytest.mark.parametrize("P", [180, 195])
+@pytest.mark.parametrize("thr", [0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9])
+def test_c3_qwen2vl_shape_threshold_sweep(thr, P):
+    """Qwen2-VL-7B shape (BASELINE.json configs[2]): 128 frames = 64 temporal grids x {180, 195} tokens, d=3584,
+    M-RoPE containers, num=4 importance, the whole similarity_lower_bound sweep of SURVEY.md §8d."""
+    F, d, pre, post = 64, 3584, 15, 12
     h, pt = video_tokens(F, P, d, p_change=0.5, sigma=0.3, sigma_hi=1.8, seed=77, pre=pre, post=post, grid=0.125)
     L = h.shape[1]
     want, _ = harness.run_cascade(orc.OracleFrameFusion(0.3, thr, 0.1), h.clone(), pt.clone(), P,
@@ -97,7 +99,7 @@ def test_c3_qwen2vl_shape_threshold_sweep(thr):
 def test_c5_72b_shape_fused_importance_and_prune():
     """LLaVA-Video-72B shape (d=8192, H=64, H_kv=8, dh=128): merge, then importance from q/k inside the
     attention hook, then the prune call."""
-    F, P, d, pre, post = 32, 576, 8192, 14, 20
+    F, P, d, pre, post = 64, 576, 8192, 14, 20          # BASELINE.json configs[4]: 64 frames
     H, Hk, dh = 64, 8, 128
     h, pt = video_tokens(F, P, d, p_change=0.95, sigma=0.3, seed=5, pre=pre, post=post, grid=0.125)
     L = h.shape[1]
@@ -115,8 +117,8 @@ def test_c5_72b_shape_fused_importance_and_prune():
     k = harness.snap(torch.randn(1, Hk, S, dh, generator=g), torch.bfloat16)
     w_o = orc.last_query_attention(q, k, num=1, is_causal=True, enable_gqa=True)
     w_g = ffa.scaled_dot_product_attention(q.to(DEV), k.to(DEV), None, num=1, is_causal=True, enable_gqa=True)
-    assert torch.allclose(w_g.cpu().float(), w_o.float(), rtol=2 ** -7, atol=1e-30)
-    assert float((w_g.cpu().float() != w_o.float()).float().mean()) <= 0.02
+    assert torch.allclose(w_g.cpu().float(), w_o.float(), rtol=2 ** -7, atol=1e-30)          # never more than one ulp
+    assert float((w_g.cpu().float() != w_o.float()).float().mean()) <= 1e-3                  # measured: ~2e-5
     # feed both sides the SAME weights so the prune itself is compared exactly
     h2 = harness.layer_stub(ho, 0)
     ho2, po2, _ = o.forward(h2, po, None, w_o)
@@ -124,13 +126,24 @@ def test_c5_72b_shape_fused_importance_and_prune():
     assert o.finish_pruning and f.finish_pruning
     assert torch.equal(pg2.cpu(), po2) and same_bits(hg2.cpu(), ho2)
     # and the fused [1, 1, 1, S] importance is accepted in place of the weights (a11)
-    imp = ffa.last_query_importance(q.to(DEV), k.to(DEV), num=1, is_causal=True)
     f2 = ffa.FrameFusion(0.3, 0.6, 0.1)
     f2.prepare(f.patch_type, P, pre, pre + F * P, F * P, L, finish_merging=True, sparsity_list=list(o.sparsity_list[:1]))
+    imp = ffa.last_query_importance(q.to(DEV), k.to(DEV), num=1, is_causal=True, framefusion=f2)   # + the prune's select tables
     hg3, pg3, _ = f2(h2.to(DEV), pg, None, imp)
     assert hg3.shape == hg2.shape
-    same = float((pg3.cpu() == po2).float().mean())
-    assert same >= 0.99          # ranking from HIP-computed weights: only ulp-level ties may differ
+    # ranking from HIP-computed importances: the kept set may differ from the oracle's only at positions whose
+    # importance differs by an ulp or sits in the tie class of the cut
+    imp_g, imp_o = imp.reshape(-1).cpu().float(), torch.mean(w_o, dim=(1, 2))[0].float()
+    differ = imp_g != imp_o
+    assert float(differ.float().mean()) <= 1e-3
+    pos_in = pg[0].cpu()                                   # original positions of the S tokens that entered the prune
+    in_g = torch.isin(pos_in, pg3[0].cpu()); in_o = torch.isin(pos_in, po2[0])
+    k_cut = int(in_o.sum()) - (S - (F * P - (L - S)))      # visual tokens kept
+    vis = slice(pre, pre + F * P - (L - S))
+    kth = torch.sort(imp_o[vis], descending=True).values[k_cut - 1]
+    unsure = differ | (imp_o == kth) | (imp_g == torch.sort(imp_g[vis], descending=True).values[k_cut - 1])
+    assert torch.equal(in_g[~unsure], in_o[~unsure])
+    assert int(in_g.sum()) == int(in_o.sum())
 
 
 def test_128_frames_cascade_and_large_ragged_order():
