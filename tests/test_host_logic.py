@@ -163,3 +163,43 @@ def test_synthetic_generator_is_deterministic_and_on_grid():
     assert pa.tolist()[0][:3] == [-1, -1, 0] and pa.shape == (1, 2 + 35 + 1)
     x = a.float() * 8
     assert torch.equal(x, x.round()) and float(a.float().abs().max()) <= 4.0
+
+
+def test_patch_type_assignment_invalidates_the_cached_order():
+    """The by-patch order kept in the scratch is keyed on a generation counter that ANY assignment of
+    patch_type bumps (prepare(), the compaction of a merge call, a caller writing the attribute)."""
+    ff = ffa.FrameFusion()
+    g0 = ff._ptype_gen
+    ff.prepare(torch.zeros(1, 4, dtype=torch.long), 2, 0, 3, 4, 4)
+    g1 = ff._ptype_gen
+    ff.patch_type = ff.patch_type                         # even the same tensor object: a new generation
+    assert g0 < g1 < ff._ptype_gen
+    b = ffa.baseline.FixedSparsityMerging([0.1])
+    h0 = b._ptype_gen
+    b.prepare(torch.zeros(1, 4, dtype=torch.long), 2)
+    assert b._ptype_gen > h0 and b.patch_type is not None
+
+
+def test_copies_do_not_share_the_device_scratch():
+    """copy.deepcopy / pickle of a used instance must not alias the pinned result block the device publishes into."""
+    import copy
+    import pickle
+    ff = ffa.FrameFusion(0.25, 0.7, 0.2)
+    ff.prepare(torch.zeros(1, 4, dtype=torch.long), 2, 0, 3, 4, 4)
+    ff._scratch[("cuda", 0)] = object()                   # stands for a live _Scratch
+    ff.last_call = dict(scratch=ff._scratch[("cuda", 0)])
+    for clone in (copy.deepcopy(ff), pickle.loads(pickle.dumps(ff))):
+        assert clone._scratch == {} and clone.last_call is None
+        assert (clone.cost, clone.similarity_lower_bound, clone.ratio_lower_bound) == (0.25, 0.7, 0.2)
+        assert clone.finish_merging is False and clone.sparsity_list == [] and torch.equal(clone.patch_type, ff.patch_type)
+    assert ff._scratch and ff.last_call is not None       # the original keeps its own
+
+
+def test_forward_residual_signature_and_errors():
+    ff = ffa.FrameFusion()
+    ff.prepare(torch.zeros(1, 4, dtype=torch.long), 2, 0, 3, 4, 4, finish_merging=True, finish_pruning=True)
+    a, b = torch.ones(1, 4, 8), torch.full((1, 4, 8), 2.0)
+    out, pe, m = ff.forward_residual(a, b, "pos", None)          # nothing due: a plain add, on any device
+    assert torch.equal(out, a + b) and pe == "pos" and m is None
+    with pytest.raises(ffa.FrameFusionHipError):
+        ff.forward(b, "pos", None, residual=torch.ones(1, 3, 8))
