@@ -282,6 +282,106 @@ __global__ __launch_bounds__(256) void k_lq_tile(const void* __restrict__ q, con
     }
 }
 
+// ---- scores on the matrix cores (16-bit T, dh = 64 / 128 / 256) --------------------------------------------
+// q . K^T of the last queries IS a small dense GEMM: [keys x dh] . [dh x rows] with the GQA group's rows
+// padded to 32.  The dot2 kernel above is ALU-bound (16 rows x (dot + group sum) per 16 bytes of K); one
+// v_mfma_f32_32x32x16 does a 32-key x 32-row x 16-dim block, which leaves the kernel waiting for K.
+// Products of two bf16 / fp16 values are exact in fp32 and the accumulation is fp32: the same numbers as
+// the reference's matmul up to summation order.  Wave = 64 keys (two 32-key blocks), workgroup = 256 keys.
+//   A operand: lane l holds K[key = l & 31][16 kk + 8 (l >> 5) .. + 8]    (16 bytes straight from memory)
+//   B operand: lane l holds Q[row = l & 31][16 kk + 8 (l >> 5) .. + 8]    (all kk kept in registers)
+//   C/D      : lane l, register r: row(key) = (r & 3) + 8 (r >> 2) + 4 (l >> 5), column(query row) = l & 31
+typedef short mfma_ab_t __attribute__((ext_vector_type(8)));
+typedef float mfma_cd_t __attribute__((ext_vector_type(16)));
+
+template <int DT, int NK>
+__global__ __launch_bounds__(256) void k_lq_mfma(const void* __restrict__ q, const void* __restrict__ k, int H, int H_kv,
+                                                 int num, int S, float scale, int causal, int pitch,
+                                                 void* __restrict__ scores, float2* __restrict__ tstats, int tiles) {
+    using A = Act<DT>;
+    static_assert(A::kBytes == 2, "16-bit activations");
+    constexpr int kRowsPad = 32;
+    __shared__ float2 wstat[4][kRowsPad];
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const int hk = blockIdx.y, group = H / H_kv, rows = group * num;
+    const int r0 = blockIdx.z * kRowsPad, rows_here = min(kRowsPad, rows - r0);
+    const int tile = blockIdx.x;
+    const int col = lane & 31, half = lane >> 5;
+    constexpr uint32_t row_bytes = NK * 32u;                           // dh * 2
+    // B fragments: my query row's 8 values of every 16-dim step (zeros for the padding rows)
+    mfma_ab_t bfrag[NK];
+    {
+        const __amdgpu_buffer_rsrc_t qrs = make_rsrc((const char*)q + (size_t)(hk * rows + r0) * row_bytes,
+                                                     (uint32_t)rows_here * row_bytes);
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+            const uint4 v = buf_load16(qrs, (uint32_t)col * row_bytes + (uint32_t)kk * 32u + (uint32_t)half * 16u);   // rows past the group: zeros
+            bfrag[kk] = __builtin_bit_cast(mfma_ab_t, v);
+        }
+    }
+    const __amdgpu_buffer_rsrc_t krs = make_rsrc((const char*)k + (size_t)hk * S * row_bytes, (uint32_t)S * row_bytes);
+    const int key0 = tile * kLqKeys + w * 64;
+    mfma_cd_t acc[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        uint4 a[NK];
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk)
+            a[kk] = buf_load16(krs, (uint32_t)(key0 + b * 32 + col) * row_bytes + (uint32_t)kk * 32u + (uint32_t)half * 16u);   // keys past S: zeros
+#pragma unroll
+        for (int x = 0; x < 16; ++x) acc[b][x] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+            if constexpr (DT == FF_BF16)
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_ab_t, a[kk]), bfrag[kk], acc[b], 0, 0, 0);
+            else
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(__attribute__((ext_vector_type(8))) _Float16, a[kk]),
+                                                               __builtin_bit_cast(__attribute__((ext_vector_type(8))) _Float16, bfrag[kk]),
+                                                               acc[b], 0, 0, 0);
+        }
+    }
+    // staged rounding + the causal bias; scores out as T, key-major; statistics of my row
+    const int n = (r0 + col) % num;
+    float m = -INFINITY;
+    float v[2][16];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int s_key = key0 + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float x = A::rnd(acc[b][r]);
+            x = A::rnd(x * scale);
+            if (causal && s_key > S - num + n) x = A::rnd(x + (-INFINITY));
+            if (s_key >= S || col >= rows_here) x = -INFINITY;
+            else A::store1(scores, (int64_t)s_key * pitch + hk * rows + r0 + col, x);
+            v[b][r] = x;
+            m = fmaxf(m, x);
+        }
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, kWave));
+    float e = 0.f;
+    if (m > -INFINITY) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) e += expf(v[b][r] - m);
+    }
+    e += __shfl_xor(e, 32, kWave);
+    if (half == 0) wstat[w][col] = make_float2(m, e);
+    __syncthreads();
+    if (tid < rows_here) {
+        float M = -INFINITY, sum = 0.f;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) M = fmaxf(M, wstat[x][tid].x);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const float2 ms = wstat[x][tid];
+            sum += ms.y > 0.f ? ms.y * expf(ms.x - M) : 0.f;
+        }
+        tstats[(size_t)(hk * rows + r0 + tid) * tiles + tile] = make_float2(M, sum);
+    }
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void k_lq_finish(const void* __restrict__ scores, const float2* __restrict__ tstats,
                                                    int rows_total, int pitch, int tiles, int S, void* __restrict__ weights,
@@ -393,6 +493,25 @@ static int launch_lq(const void* q, const void* k, int64_t H, int64_t H_kv, int6
     const int64_t pitch_bytes = ((int64_t)rows_total * kB + 15) & ~(int64_t)15;
     const int pitch = (int)(pitch_bytes / kB);
     float2* tstats = (float2*)((char*)ws + S * pitch_bytes);
+    if constexpr (kB == 2) {
+        // matrix-core scores for the head sizes of real models
+        const dim3 mgrid((unsigned)tiles, (unsigned)H_kv, (unsigned)((rows + 31) / 32));
+        bool done = true;
+#define FF_LQ_MFMA(NK)                                                                                                    \
+    hipLaunchKernelGGL((k_lq_mfma<DT, NK>), mgrid, dim3(256), 0, st, q, k, (int)H, (int)H_kv, (int)num, (int)S, (float)scale, \
+                       causal, pitch, scores, tstats, tiles)
+        if (dh == 64) FF_LQ_MFMA(4);
+        else if (dh == 128) FF_LQ_MFMA(8);
+        else if (dh == 256) FF_LQ_MFMA(16);
+        else done = false;
+#undef FF_LQ_MFMA
+        if (done) {
+            hipLaunchKernelGGL(k_lq_finish<DT>, dim3((unsigned)((S + 255) / 256)), dim3(256), (size_t)rows_total * 2 * sizeof(float),
+                               st, (const void*)scores, (const float2*)tstats, rows_total, pitch, tiles, (int)S, weights, importance,
+                               (int)lo, (int)hi, l0, t16_end);
+            return (int)hipGetLastError();
+        }
+    }
     const dim3 grid((unsigned)tiles, (unsigned)H_kv, (unsigned)((rows + kLqRows - 1) / kLqRows));
 #define FF_LQ_TILE(LPK)                                                                                                   \
     hipLaunchKernelGGL((k_lq_tile<DT, LPK>), grid, dim3(256), 0, st, q, k, (int)H, (int)H_kv, (int)num, (int)S, (float)scale, \

@@ -168,7 +168,7 @@ def check_prune(g, name, imp, kept, label, w_rows=None):
         print(f"[{label}] {name}: weights of two (head, query) rows: {int(wd.sum())} of {wd.size} differ ({wd.mean():.1e})")
         assert int(ulps(wb, wr).max()) <= 1
         assert wd.mean() <= 2e-3
-    assert rate <= 2e-3
+    assert rate <= 5e-4          # measured 0.5 - 2.2e-4: the fp32 summation-order floor
     kept_ref = np.unpackbits(g[f"{name}/kept"])[:S].astype(bool)
     kept = kept.numpy().astype(bool)
     assert int(kept.sum()) == L_out == S - n_img + k

@@ -318,6 +318,24 @@ def test_importance_golden(golden, name):
                           rtol=tol, atol=1e-30)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("dh,H,Hk,num,S", [(64, 8, 2, 1, 700), (128, 28, 4, 4, 1111), (256, 4, 4, 1, 300), (128, 40, 4, 4, 520)])
+def test_importance_matrix_core_path(dtype, dh, H, Hk, num, S):
+    """dh in {64, 128, 256}, 16-bit T: q . K^T on MFMA (rows of a GQA group padded to 32, more than 32 rows in
+    passes).  Grid inputs make every product sum exact, so the scores are the oracle's and what is left is the
+    softmax's ulp noise."""
+    g = torch.Generator().manual_seed(dh + S)
+    q = harness.snap(0.5 * torch.randn(1, H, num, dh, generator=g), dtype)
+    k = harness.snap(0.5 * torch.randn(1, Hk, S, dh, generator=g), dtype)
+    want = orc.last_query_attention(q, k, num=num, is_causal=True, enable_gqa=True)
+    got = ffa.scaled_dot_product_attention(dev(q), dev(k), None, num=num, is_causal=True, enable_gqa=True)
+    tol = 2 ** -7 if dtype == torch.bfloat16 else 2 ** -10
+    assert torch.allclose(got.cpu().float(), want.float(), rtol=tol, atol=1e-30)
+    assert float((got.cpu().float() != want.float()).float().mean()) <= 2e-3
+    imp = ffa.last_query_importance(dev(q), dev(k), num=num, is_causal=True)
+    assert torch.allclose(imp.reshape(-1).cpu().float(), torch.mean(want, dim=(1, 2))[0].float(), rtol=tol, atol=1e-30)
+
+
 def test_importance_odd_head_size_general_path():
     """dh * sizeof(T) / 16 not a power of two (dh = 24 bf16 -> 3 lanes per key): the general kernels"""
     g = torch.Generator().manual_seed(5)
