@@ -382,7 +382,9 @@ __global__ __launch_bounds__(256) void k_lq_mfma(const void* __restrict__ q, con
     }
 }
 
-template <int DT>
+// KG lanes share a key (each takes every KG-th 16-byte word of its score row): KG x the waves for the
+// exp / divide work, the partial means meet through DPP.
+template <int DT, int KG>
 __global__ __launch_bounds__(256) void k_lq_finish(const void* __restrict__ scores, const float2* __restrict__ tstats,
                                                    int rows_total, int pitch, int tiles, int S, void* __restrict__ weights,
                                                    void* __restrict__ imp, int lo, int hi, int* __restrict__ l0,
@@ -424,30 +426,33 @@ __global__ __launch_bounds__(256) void k_lq_finish(const void* __restrict__ scor
         }
     }
     __syncthreads();
-    const int s = blockIdx.x * 256 + tid;
+    const int s = blockIdx.x * (256 / KG) + tid / KG, sub_k = tid & (KG - 1);
     float v = 0.f;
-    if (s < S) {
+    {
         float acc = 0.f;
-        const uint4* src = (const uint4*)((const char*)scores + (size_t)s * pitch * A::kBytes);
-        for (int row0 = 0; row0 < rows_total; row0 += E) {
-            float x[E];
-            A::unpack(src[row0 / E], x);
+        if (s < S) {
+            const uint4* src = (const uint4*)((const char*)scores + (size_t)s * pitch * A::kBytes);
+            for (int row0 = sub_k * E; row0 < rows_total; row0 += KG * E) {
+                float x[E];
+                A::unpack(src[row0 / E], x);
 #pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const int row = row0 + e;
-                if (row < rows_total) {
-                    const float p = A::rnd(expf(x[e] - row_ms[2 * row]) / row_ms[2 * row + 1]);
-                    acc += p;
-                    if (weights) A::store1(weights, (int64_t)row * S + s, p);
+                for (int e = 0; e < E; ++e) {
+                    const int row = row0 + e;
+                    if (row < rows_total) {
+                        const float p = A::rnd(expf(x[e] - row_ms[2 * row]) / row_ms[2 * row + 1]);
+                        acc += p;
+                        if (weights) A::store1(weights, (int64_t)row * S + s, p);
+                    }
                 }
             }
         }
-        if (imp) {
+        acc = group_sum<KG>(acc);
+        if (s < S && imp) {
             v = A::rnd(acc / (float)rows_total);
-            A::store1(imp, s, v);
+            if (sub_k == 0) A::store1(imp, s, v);
         }
     }
-    if (l0) importance_tables<DT>(v, s, s >= lo && s < hi, l0, t16_end);
+    if (l0) importance_tables<DT>(v, s, sub_k == 0 && s >= lo && s < hi, l0, t16_end);
 }
 
 template <int DT>
@@ -466,6 +471,21 @@ static int launch_lq_general(const void* q, const void* k, int64_t H, int64_t H_
     if (importance)
         hipLaunchKernelGGL(k_lq_mean<DT>, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, probs, (int)(H * num),
                            (int)S, importance, (int)lo, (int)hi, l0, t16_end);
+    return (int)hipGetLastError();
+}
+
+template <int DT>
+static int launch_lq_finish(void* scores, float2* tstats, int rows_total, int pitch, int tiles, int64_t S, void* weights,
+                            void* importance, int64_t lo, int64_t hi, int* l0, int* t16_end, hipStream_t st) {
+    const int words = pitch * Act<DT>::kBytes / 16;              // 16-byte words of one key's scores
+    const size_t lds = (size_t)rows_total * 2 * sizeof(float);
+#define FF_LQ_FIN(KG)                                                                                                      \
+    hipLaunchKernelGGL((k_lq_finish<DT, KG>), dim3((unsigned)((S * KG + 255) / 256)), dim3(256), lds, st, (const void*)scores, \
+                       (const float2*)tstats, rows_total, pitch, tiles, (int)S, weights, importance, (int)lo, (int)hi, l0, t16_end)
+    if (words >= 8) FF_LQ_FIN(4);
+    else if (words >= 4) FF_LQ_FIN(2);
+    else FF_LQ_FIN(1);
+#undef FF_LQ_FIN
     return (int)hipGetLastError();
 }
 
@@ -506,10 +526,7 @@ static int launch_lq(const void* q, const void* k, int64_t H, int64_t H_kv, int6
         else done = false;
 #undef FF_LQ_MFMA
         if (done) {
-            hipLaunchKernelGGL(k_lq_finish<DT>, dim3((unsigned)((S + 255) / 256)), dim3(256), (size_t)rows_total * 2 * sizeof(float),
-                               st, (const void*)scores, (const float2*)tstats, rows_total, pitch, tiles, (int)S, weights, importance,
-                               (int)lo, (int)hi, l0, t16_end);
-            return (int)hipGetLastError();
+            return launch_lq_finish<DT>(scores, tstats, rows_total, pitch, tiles, S, weights, importance, lo, hi, l0, t16_end, st);
         }
     }
     const dim3 grid((unsigned)tiles, (unsigned)H_kv, (unsigned)((rows + kLqRows - 1) / kLqRows));
@@ -526,10 +543,7 @@ static int launch_lq(const void* q, const void* k, int64_t H, int64_t H_kv, int6
         default: FF_LQ_TILE(64);
     }
 #undef FF_LQ_TILE
-    hipLaunchKernelGGL(k_lq_finish<DT>, dim3((unsigned)((S + 255) / 256)), dim3(256), (size_t)rows_total * 2 * sizeof(float), st,
-                       (const void*)scores, (const float2*)tstats, rows_total, pitch, tiles, (int)S, weights, importance, (int)lo,
-                       (int)hi, l0, t16_end);
-    return (int)hipGetLastError();
+    return launch_lq_finish<DT>(scores, tstats, rows_total, pitch, tiles, S, weights, importance, lo, hi, l0, t16_end, st);
 }
 
 }  // namespace ff
