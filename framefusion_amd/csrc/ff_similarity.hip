@@ -204,22 +204,32 @@ __global__ __launch_bounds__(kSimThreads) void k_pair_similarity(
         }
     }
     if (l0) {
-        // select statistics of the plan kernel that follows (ff_plan.hip): the top byte of the
-        // order-preserving key + count(sim >= thr) into one of kL0Copies level-0 tables, and the top
-        // 16 bits into the level-1 table of this wave's slice - equal values of the wave folded into
-        // one non-returning atomic each, copies chosen per workgroup so that the atomics of a video's
-        // dozen distinct similarity values never pile up on one memory-side word
-        uint32_t bits;
-        if constexpr (DT == FF_F32) bits = __float_as_uint(mine);
-        else if constexpr (DT == FF_BF16) bits = __float_as_uint(mine) >> 16;
-        else { _Float16 h = (_Float16)mine; bits = (uint32_t)__builtin_bit_cast(uint16_t, h); }
-        const uint32_t key = order_key<DT>(bits);
-        int* tab = l0 + (blockIdx.x & (kL0Copies - 1)) * kL0Stride;
-        const int n_ge = __popcll(__ballot(have && mine >= thr));
-        if (lane == 0 && n_ge) atomicAdd(&tab[256], n_ge);
-        wave_agg_add<kPairs>(tab, key >> (A::kKeyBits - 8), have);
-        int* t16 = t16_slice(t16_end, j0 / kSelSlice) + (blockIdx.x & (kT16Copies - 1)) * 65536;
-        wave_agg_add<kPairs>(t16, t16_bin(key >> (A::kKeyBits - 16)), have);
+        // select statistics of the plan kernel that follows (ff_plan.hip): the workgroup's similarities
+        // meet in LDS and ONE wave folds them - the top byte of the order-preserving key + count(sim >= thr)
+        // into one of kL0Copies level-0 tables, the top 16 bits into the level-1 table of the group's slice;
+        // equal values folded into one non-returning atomic each (a video's similarities are a dozen
+        // distinct values: per-wave folding left ~4x the atomics on the same few memory-side words)
+        __shared__ float sims[kSimWaves * kPairs];
+        if (lane < kPairs) sims[wave_id() * kPairs + lane] = have ? mine : __int_as_float(0x7fc00001);   // (a NaN payload no similarity has: "absent")
+        __syncthreads();
+        // (waves past the end of the order have exited: the barrier counts the live ones; their entries stay
+        // unwritten, so the folding wave only trusts entries of slots below nv)
+        const int g0 = (blockIdx.x * kSimWaves) * kPairs;            // first slot of the workgroup
+        if (j0 == g0) {                                            // the workgroup's first wave is always live
+            const bool got = lane < kSimWaves * kPairs && g0 + lane < nv;
+            const float sv = got ? sims[lane] : -2.0f;
+            uint32_t bits;
+            if constexpr (DT == FF_F32) bits = __float_as_uint(sv);
+            else if constexpr (DT == FF_BF16) bits = __float_as_uint(sv) >> 16;
+            else { _Float16 h = (_Float16)sv; bits = (uint32_t)__builtin_bit_cast(uint16_t, h); }
+            const uint32_t key = order_key<DT>(bits);
+            int* tab = l0 + (blockIdx.x & (kL0Copies - 1)) * kL0Stride;
+            const int n_ge = __popcll(__ballot(got && sv >= thr));
+            if (lane == 0 && n_ge) atomicAdd(&tab[256], n_ge);
+            wave_agg_add<3>(tab, key >> (A::kKeyBits - 8), got);
+            int* t16 = t16_slice(t16_end, g0 / kSelSlice) + (blockIdx.x & (kT16Copies - 1)) * 65536;
+            wave_agg_add<6>(t16, t16_bin(key >> (A::kKeyBits - 16)), got);
+        }
     }
 }
 
