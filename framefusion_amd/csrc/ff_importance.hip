@@ -111,27 +111,63 @@ __device__ inline void importance_tables(float value, int s, bool in_range, int*
     wave_agg_add<2>(t16, t16_bin(key >> (A::kKeyBits - 16)), in_range);
 }
 
-// importance[s] = T(mean over H*num of attn_w[h, n, s]) accumulated in fp32 (main.py:70); with l0 the
-// select tables of the values in [lo, hi) are accumulated on the way.
+// importance[s] = T(mean over H*num of attn_w[h, n, s]) accumulated in fp32 in row order (main.py:70); with
+// l0 the select tables of the values in [lo, hi) are accumulated on the way.  A workgroup owns 8 sixteen-byte
+// pieces of positions; its 256 threads load 32 rows of them at once (kHmDepth such passes in flight) and
+// the first threads add the rows up through LDS.
+constexpr int kHmDepth = 4;
 template <int DT>
 __global__ __launch_bounds__(256) void k_head_mean(const void* __restrict__ w, int rows, int S,
                                                    void* __restrict__ imp, int lo, int hi, int* __restrict__ l0,
                                                    int* t16_end) {
     using A = Act<DT>;
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    float v = 0.f;
-    if (s < S) {
-        float acc = 0.f;
-        for (int r = 0; r < rows; ++r) acc += A::load1(w, (int64_t)r * S + s);
-        v = A::rnd(acc / (float)rows);
-        A::store1(imp, s, v);
+    constexpr int E = A::kPer16, P = 8 * E;          // positions per workgroup
+    __shared__ float tile[32][P + 1];
+    const int t = threadIdx.x, piece = t & 7, rip = t >> 3;
+    const int s0 = blockIdx.x * P + piece * E;
+    const bool vec = (S % E) == 0;                   // rows keep the 16-byte alignment of the base
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(w, (uint32_t)((int64_t)rows * S * A::kBytes));
+    float acc = 0.f;
+    for (int r0 = 0; r0 < rows; r0 += 32 * kHmDepth) {
+        float x[kHmDepth][E];
+#pragma unroll
+        for (int u = 0; u < kHmDepth; ++u) {
+            const int r = r0 + u * 32 + rip;
+            if (vec) {
+                // (past the last row or the last position the range check returns zeros)
+                const uint4 v = buf_load16(rs, r < rows && s0 < S ? (uint32_t)(((int64_t)r * S + s0) * A::kBytes) : 0xfffffff0u);
+                A::unpack(v, x[u]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < E; ++e) x[u][e] = r < rows && s0 + e < S ? A::load1(w, (int64_t)r * S + s0 + e) : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kHmDepth; ++u) {
+            if (r0 + u * 32 >= rows) break;          // (uniform)
+#pragma unroll
+            for (int e = 0; e < E; ++e) tile[rip][piece * E + e] = x[u][e];
+            __syncthreads();
+            if (t < P) {
+                const int n = min(32, rows - (r0 + u * 32));
+                for (int r = 0; r < n; ++r) acc += tile[r][t];
+            }
+            __syncthreads();
+        }
     }
-    if (l0) importance_tables<DT>(v, s, s >= lo && s < hi, l0, t16_end);
+    if (t >= 64) return;                             // (P <= 64: the first wave finishes)
+    const int s = blockIdx.x * P + t;
+    const bool ok = t < P && s < S;
+    const float v = A::rnd(acc / (float)rows);
+    if (ok) A::store1(imp, s, v);
+    if (l0) importance_tables<DT>(v, s, ok && s >= lo && s < hi, l0, t16_end);
 }
 
 int launch_head_mean(const void* attn_w, int dtype, int64_t H, int64_t num, int64_t S, void* importance,
                      int64_t lo, int64_t hi, int* l0, int* t16_end, hipStream_t st) {
-    const unsigned blocks = (unsigned)((S + 255) / 256);
+    const int64_t per_block = 8 * (dtype == FF_F32 ? 4 : 8);
+    const unsigned blocks = (unsigned)((S + per_block - 1) / per_block);
+    if ((int64_t)H * num * S * (dtype == FF_F32 ? 4 : 2) >= (1ll << 32)) return FF_ERR_UNSUPPORTED;
     switch (dtype) {
         case FF_F32:
             hipLaunchKernelGGL(k_head_mean<FF_F32>, dim3(blocks), dim3(256), 0, st, attn_w, (int)(H * num), (int)S, importance, (int)lo, (int)hi, l0, t16_end);
