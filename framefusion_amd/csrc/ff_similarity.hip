@@ -14,7 +14,6 @@
 //     dot = T(sum_fp32 T(a_i*b_i));  na = T(sqrt_fp32(sum_fp32 a_i^2));  sim = T(dot / T(na*nb))
 // sqrt and divide are the correctly rounded fp32 forms (hipcc default).
 #include "ff_common.h"
-#include <cstdlib>
 
 namespace ff {
 
@@ -234,195 +233,6 @@ __global__ __launch_bounds__(kSimThreads) void k_pair_similarity(
     }
 }
 
-// Sequential-row decomposition of the same computation: a wave owns kSeqSlots consecutive by-patch
-// positions j0..j0+15, i.e. the 17 rows order[j0-1 .. j0+15], and streams them ONE AFTER THE OTHER - a
-// single sequential stream of 1 KiB tiles per wave, kDepth tiles in flight - keeping the previous row in
-// registers (kTiles packed tiles; rows shorter than kTiles KiB read zeros through the range check).  Per-lane
-// partial sums are parked in LDS row by row; lane v folds value v's 64 partials in the order of the
-// butterfly (wave_sum) after the last row, so the results are bit-identical with k_pair_similarity's.
-template <int DT, int kTiles, int kSeqThreads, int kDepth, bool kHint, bool kAdd, int kSeqSlots = 16>
-__global__ __launch_bounds__(kSeqThreads) void k_pair_similarity_seq(
-    const char* __restrict__ hidden, const char* __restrict__ addend, uint32_t row_bytes, const int64_t* __restrict__ ptype,
-    const int32_t* __restrict__ order, const int64_t* __restrict__ stats, void* __restrict__ sim,
-    int* __restrict__ l0, int* t16_end, float thr, const LayoutHint hint, int32_t* __restrict__ order_out,
-    int32_t* __restrict__ inv_out, int64_t* __restrict__ stats_out) {
-    using A = Act<DT>;
-    constexpr int E = A::kPer16;
-    constexpr int R = kSeqSlots + 1;
-    constexpr int kWaves = kSeqThreads / kWave;
-    __shared__ float part[kWaves][2 * R][kWave + 1];
-    const int lane = lane_id();
-    int nv;
-    if constexpr (kHint) {
-        nv = hint.patches * hint.frames;
-        const int n_tail = hint.L - nv;
-        const int gtid = blockIdx.x * kSeqThreads + threadIdx.x;
-        for (int q = gtid; q < n_tail; q += (int)gridDim.x * kSeqThreads) {
-            const int i = q < hint.pre ? q : q + nv;
-            if (ptype[i] != -1) atomicOr((unsigned long long*)(stats_out + FF_STAT_ERROR), (unsigned long long)FF_ERR_BIT_LAYOUT);
-            order_out[nv + q] = i;
-            if (inv_out) inv_out[i] = nv + q;
-        }
-        if (gtid == 0) {
-            stats_out[FF_STAT_NV] = nv;
-            stats_out[FF_STAT_FTN] = nv;
-        }
-    } else {
-        nv = (int)stats[FF_STAT_NV];
-    }
-    const int j0 = uniform((blockIdx.x * kWaves + wave_id()) * kSeqSlots);
-    if (j0 >= nv) return;
-
-    // lane r < 17: the position of the wave's row r = slot j0-1+r (clamped into the order);
-    // lane r < 16 also owns slot j0+r at the end
-    auto pos_of = [&](int j, int& p_out, int& f_out) {
-        if constexpr (kHint) {
-            const int p = j / hint.frames, f = j - p * hint.frames;
-            p_out = p; f_out = f;
-            return hint.pre + f * hint.patches + p;
-        } else {
-            p_out = 0; f_out = 0;
-            return (int)order[j];
-        }
-    };
-    int my_row, slot_i, slot_p, slot_f;
-    {
-        int j = j0 - 1 + lane, pp, ff_;
-        j = j < 0 ? 0 : (j >= nv ? nv - 1 : j);
-        my_row = pos_of(j, pp, ff_);
-        const int js = min(j0 + lane, nv - 1);
-        slot_i = pos_of(js, slot_p, slot_f);
-    }
-    const int my_slot = j0 + lane;
-    const bool owner = lane < kSeqSlots && my_slot < nv;
-    int64_t my_type = 0, left_type = 0;
-    if (owner) {
-        my_type = ptype[slot_i];                                   // requested now, used at the end
-        if constexpr (!kHint) left_type = ptype[my_row];           // (lane r's row r is slot j0+r-1)
-    }
-
-    // the row being consumed and the one after it (wave-uniform descriptors; past the last row: an empty
-    // range, whose loads return zeros); tile t+kDepth of the stream is requested when tile t is consumed
-    static_assert(kTiles % kDepth == 0 && kDepth <= kTiles, "static prefetch slots");
-    const uint32_t lane_off = (uint32_t)lane * 16;
-    auto desc = [&](int r, const char* base) {
-        const int64_t i = (int64_t)__builtin_amdgcn_readlane(my_row, r < R ? r : 0);
-        return make_rsrc(base + i * row_bytes, r < R ? row_bytes : 0u);
-    };
-    __amdgpu_buffer_rsrc_t cur = desc(0, hidden), nxt = desc(1, hidden), cur2 = cur, nxt2 = nxt;
-    if constexpr (kAdd) { cur2 = desc(0, addend); nxt2 = desc(1, addend); }
-    uint4 b[kDepth], b2[kAdd ? kDepth : 1];
-#pragma unroll
-    for (int d = 0; d < kDepth; ++d) {
-        b[d] = buf_load16(cur, d * 1024u + lane_off);
-        if constexpr (kAdd) b2[d] = buf_load16(cur2, d * 1024u + lane_off);
-    }
-    uint4 prev[kTiles];
-#pragma unroll
-    for (int t = 0; t < kTiles; ++t) prev[t] = make_uint4(0, 0, 0, 0);
-    for (int r = 0; r < R; ++r) {
-        float nacc = 0.f, dacc = 0.f;
-#pragma unroll
-        for (int t = 0; t < kTiles; ++t) {
-            uint4 v = b[t % kDepth];
-            if constexpr (kAdd) v = add16<DT>(v, b2[t % kDepth]);
-            {
-                const int tt = (t + kDepth) % kTiles;
-                const bool same = t + kDepth < kTiles;
-                b[t % kDepth] = buf_load16(same ? cur : nxt, tt * 1024u + lane_off);
-                if constexpr (kAdd) b2[t % kDepth] = buf_load16(same ? cur2 : nxt2, tt * 1024u + lane_off);
-            }
-            if constexpr (DT == FF_BF16) {
-                float x[E], pv[E];
-                nacc = A::sumsq(v, nacc);
-                A::unpack(prev[t], pv);
-                A::unpack(v, x);
-                dacc = A::dot_rounded(pv, x, dacc);
-            } else if constexpr (DT == FF_F16) {
-                nacc = A::sumsq(v, nacc);
-                dacc = A::dot_rounded_raw(prev[t], v, dacc);
-            } else {
-                float x[E], pv[E];
-                A::unpack(prev[t], pv);
-                A::unpack(v, x);
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    nacc = __builtin_fmaf(x[e], x[e], nacc);
-                    dacc += A::rnd(pv[e] * x[e]);
-                }
-            }
-            prev[t] = v;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        cur = nxt;
-        nxt = desc(r + 2, hidden);
-        if constexpr (kAdd) { cur2 = nxt2; nxt2 = desc(r + 2, addend); }
-        part[wave_id()][r][lane] = nacc;
-        part[wave_id()][R + r][lane] = dacc;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-    // lane v: the butterfly sum of value v (v < R: |row v|^2; v >= R: dot(row v-R-1, row v-R)), left in the
-    // pad column of its LDS row
-    for (int v = lane; v < 2 * R; v += kWave) {
-        float* pr = part[wave_id()][v];
-        float s2[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s2[i] = (pr[i] + pr[i + 32]) + (pr[i + 16] + pr[i + 48]);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) s2[i] = s2[i] + s2[i + 8];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) s2[i] = s2[i] + s2[i + 4];
-        pr[kWave] = (s2[0] + s2[2]) + (s2[1] + s2[3]);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int lr = lane < kSeqSlots ? lane : 0;
-    const float na_sum = part[wave_id()][lr][kWave];               // row r = left row of slot j0+r
-    const float nb_sum = part[wave_id()][lr + 1][kWave];
-    const float d_sum = part[wave_id()][R + 1 + lr][kWave];
-
-    float mine = -2.0f;   // IGNORE_TOKEN (main.py:225-238)
-    if (owner) {
-        bool same_type;
-        if constexpr (kHint) {
-            if (my_type != (int64_t)slot_p)
-                atomicOr((unsigned long long*)(stats_out + FF_STAT_ERROR), (unsigned long long)FF_ERR_BIT_LAYOUT);
-            order_out[my_slot] = slot_i;
-            if (inv_out) inv_out[slot_i] = my_slot;
-            same_type = slot_f != 0;                               // the previous slot is the same patch one frame earlier
-        } else {
-            same_type = my_slot > 0 && left_type == my_type;
-        }
-        if (same_type) {
-            const float d = A::rnd(d_sum);
-            const float na = A::rnd(sqrtf(na_sum));
-            const float nb = A::rnd(sqrtf(nb_sum));
-            const float den = A::rnd(na * nb);
-            mine = A::rnd(d / den);
-        }
-        A::store1(sim, my_slot, mine);
-    }
-    if (l0) {
-        // select statistics of the plan kernel that follows (see k_pair_similarity): the wave's 16 values
-        uint32_t bits;
-        if constexpr (DT == FF_F32) bits = __float_as_uint(mine);
-        else if constexpr (DT == FF_BF16) bits = __float_as_uint(mine) >> 16;
-        else { _Float16 h = (_Float16)mine; bits = (uint32_t)__builtin_bit_cast(uint16_t, h); }
-        const uint32_t key = order_key<DT>(bits);
-        const int wv = blockIdx.x * kWaves + wave_id();
-        int* tab = l0 + (wv & (kL0Copies - 1)) * kL0Stride;
-        const int n_ge = __popcll(__ballot(owner && mine >= thr));
-        if (lane == 0 && n_ge) atomicAdd(&tab[256], n_ge);
-        wave_agg_add<3>(tab, key >> (A::kKeyBits - 8), owner);
-        int* t16 = t16_slice(t16_end, j0 / kSelSlice) + (wv & (kT16Copies - 1)) * 65536;
-        wave_agg_add<6>(t16, t16_bin(key >> (A::kKeyBits - 16)), owner);
-    }
-}
-
 struct SimArgs {
     const void* hidden;
     const void* addend;       // NULL: the rows are hidden's
@@ -440,22 +250,13 @@ struct SimArgs {
     int64_t* stats_out;
 };
 
-static unsigned exp_lds() {
-#ifdef FF_K1_EXPERIMENT
-    static const unsigned v = getenv("FF_K1_LDS") ? (unsigned)atoi(getenv("FF_K1_LDS")) : 0u;
-    return v;
-#else
-    return 0u;
-#endif
-}
-
 template <int DT, int kPairs, int kSimThreads>
 static int launch_similarity_pt(const SimArgs& a, hipStream_t st) {
     const int64_t row_bytes = a.d * Act<DT>::kBytes;
     const int64_t per_block = (int64_t)(kSimThreads / kWave) * kPairs;
     const int64_t blocks = (a.L + per_block - 1) / per_block;
 #define FF_SIM_LAUNCH(HINT, ADD, OO, IO, SO)                                                                              \
-    hipLaunchKernelGGL((k_pair_similarity<DT, kPairs, kSimThreads, HINT, ADD>), dim3((unsigned)blocks), dim3(kSimThreads), exp_lds(), \
+    hipLaunchKernelGGL((k_pair_similarity<DT, kPairs, kSimThreads, HINT, ADD>), dim3((unsigned)blocks), dim3(kSimThreads), 0, \
                        st, (const char*)a.hidden, (const char*)a.addend, (uint32_t)row_bytes, a.ptype, a.order, a.stats,    \
                        a.sim, a.l0, a.t16_end, a.thr, a.hint, OO, IO, SO)
     if (a.hint.frames > 0) {
@@ -469,49 +270,8 @@ static int launch_similarity_pt(const SimArgs& a, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-template <int DT, int kTiles, int kSeqThreads, int kDepth, int kSeqSlots = 16>
-static int launch_similarity_seq(const SimArgs& a, hipStream_t st) {
-    const int64_t row_bytes = a.d * Act<DT>::kBytes;
-    const int64_t per_block = (int64_t)(kSeqThreads / kWave) * kSeqSlots;
-    const int64_t blocks = (a.L + per_block - 1) / per_block;
-#define FF_SEQ_LAUNCH(HINT, ADD, OO, IO, SO)                                                                          \
-    hipLaunchKernelGGL((k_pair_similarity_seq<DT, kTiles, kSeqThreads, kDepth, HINT, ADD, kSeqSlots>), dim3((unsigned)blocks), \
-                       dim3(kSeqThreads), 0, st, (const char*)a.hidden, (const char*)a.addend, (uint32_t)row_bytes,    \
-                       a.ptype, a.order, a.stats, a.sim, a.l0, a.t16_end, a.thr, a.hint, OO, IO, SO)
-    if (a.hint.frames > 0) {
-        if (a.addend) FF_SEQ_LAUNCH(true, true, a.order_out, a.inv_out, a.stats_out);
-        else FF_SEQ_LAUNCH(true, false, a.order_out, a.inv_out, a.stats_out);
-    } else {
-        if (a.addend) FF_SEQ_LAUNCH(false, true, (int32_t*)nullptr, (int32_t*)nullptr, (int64_t*)nullptr);
-        else FF_SEQ_LAUNCH(false, false, (int32_t*)nullptr, (int32_t*)nullptr, (int64_t*)nullptr);
-    }
-#undef FF_SEQ_LAUNCH
-    return (int)hipGetLastError();
-}
-
 template <int DT>
-static int launch_similarity(const SimArgs& a, hipStream_t st) {
-#ifdef FF_K1_EXPERIMENT
-    static const int pairs = getenv("FF_K1_PAIRS") ? atoi(getenv("FF_K1_PAIRS")) : 4;
-    if (pairs == 8) return launch_similarity_pt<DT, 8, 256>(a, st);
-    if (pairs == 6) return launch_similarity_pt<DT, 6, 256>(a, st);
-    if (pairs == 82) return launch_similarity_pt<DT, 8, 128>(a, st);
-    static const int seq = getenv("FF_K1_SEQ") ? atoi(getenv("FF_K1_SEQ")) : 0;
-    const int64_t rb = a.d * Act<DT>::kBytes;
-    if (seq && rb <= 8192) {
-        if (seq == 2) return launch_similarity_seq<DT, 8, 256, 2>(a, st);
-        if (seq == 4) return launch_similarity_seq<DT, 8, 256, 4>(a, st);
-        if (seq == 8) return launch_similarity_seq<DT, 8, 256, 8>(a, st);
-        if (seq == 12) return launch_similarity_seq<DT, 8, 64, 2>(a, st);
-        if (seq == 14) return launch_similarity_seq<DT, 8, 64, 4>(a, st);
-        if (seq == 22) return launch_similarity_seq<DT, 8, 128, 2>(a, st);
-        if (seq == 322) return launch_similarity_seq<DT, 8, 64, 2, 32>(a, st);
-        if (seq == 324) return launch_similarity_seq<DT, 8, 64, 4, 32>(a, st);
-        if (seq == 82) return launch_similarity_seq<DT, 8, 64, 2, 8>(a, st);
-    }
-#endif
-    return launch_similarity_pt<DT, 4, 256>(a, st);
-}
+static int launch_similarity(const SimArgs& a, hipStream_t st) { return launch_similarity_pt<DT, 4, 256>(a, st); }
 
 // hint_frames > 0: frame-major closed form (see LayoutHint); `order` and `stats` are then outputs.
 int launch_similarity_any(const void* hidden, const void* addend, int dtype, int64_t L, int64_t d, const int64_t* ptype,
