@@ -35,7 +35,7 @@ __global__ void k_read_flat(const uint4* __restrict__ p, size_t n16, uint4* __re
 
 // pattern 1: "rows": a wave owns R rows of row_bytes (rows `row_stride` rows apart), walks them in
 // 1 KiB tiles with R loads in flight + the next tile prefetched (K1's access pattern)
-template <int R, int PF>
+template <int R, int PF, int ROT = 0>
 __global__ void k_read_rows(const char* __restrict__ base, int n_rows, int row_bytes, int row_stride, uint4* __restrict__ sink) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -53,11 +53,14 @@ __global__ void k_read_rows(const char* __restrict__ base, int n_rows, int row_b
     uint4 acc = make_uint4(0, 0, 0, 0);
     uint4 cur[R], nxt[R];
     const int tiles = row_bytes >> 10;
+    // ROT: every wave starts at its own tile and wraps around (waves that start together do not walk the
+    // same 1 KiB column of every row together)
+    const int rot = ROT == 1 ? (wave & (tiles - 1)) : ROT == 2 ? ((wave * 5 + (wave >> 3)) & (tiles - 1)) : 0;
 #pragma unroll
-    for (int r = 0; r < R; ++r) cur[r] = *(const uint4*)(row[r] + lane * 16);
+    for (int r = 0; r < R; ++r) cur[r] = *(const uint4*)(row[r] + rot * 1024 + lane * 16);
     if (PF) {
         for (int t = 0; t < tiles; ++t) {
-            const int no = (t + 1 < tiles ? t + 1 : t) * 1024 + lane * 16;
+            const int no = (((t + 1 < tiles ? t + 1 : t) + rot) & (tiles - 1)) * 1024 + lane * 16;
 #pragma unroll
             for (int r = 0; r < R; ++r) nxt[r] = *(const uint4*)(row[r] + no);
 #pragma unroll
@@ -218,6 +221,12 @@ int main(int argc, char** argv) {
         float us = time_us([&] { flip ^= 1; hipLaunchKernelGGL((k_read_rows<R, PF>), dim3(blocks), dim3(TPB), 0, 0, (const char*)(flip ? a : b), n_rows, row_bytes, F, sink); }, 10); \
         printf("rows  R=%d pf=%d tpb=%4d blocks=%6d : %7.1f us  %7.1f GB/s\n", R, PF, TPB, blocks, us, (double)n_rows * row_bytes / us / 1e3); }
     ROWSP(5, 256, 0) ROWSP(4, 256, 0) ROWSP(3, 256, 0) ROWSP(2, 256, 0) ROWSP(1, 256, 0) ROWSP(5, 512, 0) ROWSP(5, 128, 0) ROWSP(3, 256, 1) ROWSP(9, 256, 0) ROWSP(9, 256, 1)
+#define ROWSR(R, TPB, ROT) { \
+        const int waves = (n_rows + R - 1) / R, blocks = (waves * 64 + TPB - 1) / TPB; \
+        float us = time_us([&] { flip ^= 1; hipLaunchKernelGGL((k_read_rows<R, 1, ROT>), dim3(blocks), dim3(TPB), 0, 0, (const char*)(flip ? a : b), n_rows, row_bytes, F, sink); }, 10); \
+        printf("rows  R=%d pf=1 rot=%d tpb=%4d blocks=%6d : %7.1f us  %7.1f GB/s\n", R, ROT, TPB, blocks, us, (double)n_rows * row_bytes / us / 1e3); }
+    ROWSR(5, 256, 0) ROWSR(5, 256, 1) ROWSR(5, 256, 2) ROWSR(4, 256, 0) ROWSR(4, 256, 1) ROWSR(4, 256, 2) ROWSR(5, 256, 0) ROWSR(5, 256, 1) ROWSR(5, 256, 2)
+    if (argc > 2) return 0;
     ROWS(1, 256) ROWS(2, 256) ROWS(4, 256) ROWS(5, 256) ROWS(8, 256) ROWS(4, 128) ROWS(4, 512) ROWS(2, 512)
 #define SEQ(NR, DEPTH, TPB, OV) { \
         const int waves = (n_rows + (NR - OV) - 1) / (NR - OV), blocks = (waves * 64 + TPB - 1) / TPB; \
