@@ -236,10 +236,10 @@ __device__ inline int block_excl_scan(int v, int* scratch, int& total) {
 // the END of the workspace (slice g ends at ws_end - g * kT16SliceInts): both locations depend on
 // neither L nor the call, so "zero on entry" survives calls of different lengths.
 constexpr int kSelSlice = 4096;
-constexpr int kL0Copies = 16;
+constexpr int kL0Copies = 4;
 constexpr int kL0Stride = 260;                    // 256 bins + count + pad
 constexpr int kL0Ints = kL0Copies * kL0Stride;
-constexpr int kT16Copies = 2;
+constexpr int kT16Copies = 1;
 constexpr size_t kT16SliceInts = (size_t)kT16Copies * 65536;
 
 __device__ __host__ inline int* t16_slice(int* t16_end, int g) { return t16_end - (size_t)(g + 1) * kT16SliceInts; }
