@@ -4,7 +4,7 @@
 // reference runs as 6+ kernels with host syncs, by one launch that reads every surviving or
 // folded row exactly once and writes every output row exactly once.
 //
-// Work decomposition: by INPUT rows, not output rows - a wave owns kSlots consecutive slots t of
+// Work decomposition: by INPUT rows, not output rows - a wave owns `slots` consecutive slots t of
 // the by-patch order (then the non-visual tail) for one 1 KiB column block.  Member slots are
 // read by the wave that owns their anchor.  Because every input row
 // is read by exactly one wave per column block and slots are spread evenly, the HBM read load is
@@ -21,7 +21,7 @@ namespace ff {
 
 constexpr int kMergeThreads = 256;
 constexpr int kMergeWaves = kMergeThreads / kWave;
-constexpr int kSlotsDefault = 32;  // consecutive by-patch slots per workgroup (<= 56)
+constexpr int kSlotsMin = 16, kSlotsMax = 56;   // consecutive by-patch slots per workgroup (chosen per launch)
 
 
 struct AuxPack {
@@ -49,11 +49,11 @@ __device__ inline void copy_row(const char* __restrict__ src, char* __restrict__
     }
 }
 
-// Waves are independent (no LDS, no barrier): the 4 waves of a workgroup own the same kSlots
+// Waves are independent (no LDS, no barrier): the 4 waves of a workgroup own the same `slots`
 // consecutive by-patch slots and one 1 KiB column tile each (16 bytes per lane), so a workgroup
 // reads 4 KiB of a row at a time.  A wave treats its job as a STREAM of rows in by-patch order:
 // it starts at its first non-member slot and runs until the first non-member slot at or beyond
-// t0 + kSlots; a non-member row opens a new output row, a member row is folded into the open one.
+// t0 + slots; a non-member row opens a new output row, a member row is folded into the open one.
 // One coalesced load of order[] / member[] for 64 slots tells the wave the whole stream, so the
 // row pieces are requested kDepth at a time, the next batch being issued BEFORE the current one
 // is folded (two register batches), with no dependent index fetch in between (dst[] is only
@@ -98,11 +98,10 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
     const int32_t* __restrict__ order, const uint8_t* __restrict__ member, int fold,
     const int32_t* __restrict__ dst, const uint8_t* __restrict__ keep, AuxPack aux, int n_main,
     int n_aux_blocks, int n_next_blocks, int32_t* __restrict__ order_next, int32_t* __restrict__ inv_next,
-    int64_t* __restrict__ stats, const int64_t* __restrict__ identity_stats, ZeroJob zero) {
+    int64_t* __restrict__ stats, const int64_t* __restrict__ identity_stats, ZeroJob zero, int slots) {
     using A = Act<DT>;
     constexpr int E = A::kPer16;
     constexpr int kDepth = 4;                     // row pieces requested per batch (two batches in flight)
-    constexpr int kSlots = kSlotsDefault;
     const int lane = lane_id();
     if ((int)blockIdx.x >= n_main + n_aux_blocks + n_next_blocks) {
         // ---- the select tables of this call have been consumed by the plan kernel: clear them for the
@@ -179,13 +178,13 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
     // slot groups are walked from the END of the by-patch order: the similarity pass read the rows
     // in ascending order, so its most recently fetched rows - the ones the 256 MiB Infinity Cache
     // still holds - are the first ones this pass asks for
-    const int t0 = (n_main - 1 - (int)blockIdx.x) * kSlots;
+    const int t0 = (n_main - 1 - (int)blockIdx.x) * slots;
     const int cb = uniform(blockIdx.y * kMergeWaves + wave_id());     // 1 KiB column tile
     const uint32_t col = (uint32_t)cb * 1024u;
     if (col >= row_bytes) return;
     const uint32_t blk_bytes = min(1024u, row_bytes - col);
     const uint32_t voff = (uint32_t)lane * 16;
-    const int t_end = min(t0 + kSlots, L);
+    const int t_end = min(t0 + slots, L);
 
     // window of 64 slots: row indices and member flags
     int win = t0;
@@ -196,7 +195,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
     const int dv = anchor_lane ? dst[ordw] : 0;
 
     // first slot of the stream
-    const unsigned long long own = (1ull << (t_end - t0)) - 1ull;         // kSlots <= 56
+    const unsigned long long own = (1ull << (t_end - t0)) - 1ull;         // slots <= kSlotsMax
     const unsigned long long starts = ~memw & own;
     if (starts == 0ull) return;                             // every slot here belongs to an earlier anchor
 
@@ -323,6 +322,38 @@ __global__ __launch_bounds__(256) void k_gather_mask(const char* __restrict__ ma
     }
 }
 
+// Slots per workgroup.  The waves of this kernel are long streams, so a launch whose workgroups do not all
+// fit on the chip at once ends with a nearly empty second round (32 slots at 64 x 576 x 4096: 2 304 workgroups
+// on 2 048 places, 79 us; 37 slots: 1 994 workgroups, 71 us; 36 / 38 slots: 73.6 us).  The main workgroups
+// are sized to fill ~97 % of r rounds' places - the rest is for the short aux / order / table blocks that
+// pass through - with the smallest r that keeps the slot window within kSlotsMax.
+template <int DT, bool kAdd>
+static int merge_places() {
+    static const int places = [] {
+        int dev = 0, per_cu = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_merge_compact<DT, kAdd>, kMergeThreads, 0) != hipSuccess ||
+            per_cu < 1)
+            return 2048;
+        return per_cu * prop.multiProcessorCount;
+    }();
+    return places;
+}
+static int merge_slots(int dtype, bool add, int64_t L, int ny) {
+    int places;
+    switch (dtype) {
+        case FF_F32: places = add ? merge_places<FF_F32, true>() : merge_places<FF_F32, false>(); break;
+        case FF_BF16: places = add ? merge_places<FF_BF16, true>() : merge_places<FF_BF16, false>(); break;
+        default: places = add ? merge_places<FF_F16, true>() : merge_places<FF_F16, false>();
+    }
+    const double fill = 0.975 * (double)places;
+    for (int r = 1;; ++r) {
+        const int s = (int)((double)L * ny / (fill * r)) + 1;
+        if (s <= kSlotsMax) return s < kSlotsMin ? kSlotsMin : s;
+    }
+}
+
 int launch_merge_compact(const void* hidden, const void* addend, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
                          const int32_t* order, const uint8_t* member, int fold, const int32_t* dst,
                          const uint8_t* keep, const ff_aux_t* aux_host, int n_aux, int32_t* order_next,
@@ -334,21 +365,22 @@ int launch_merge_compact(const void* hidden, const void* addend, void* hidden_ou
     for (int x = pack.n; x < FF_MAX_AUX; ++x) pack.a[x] = ff_aux_t{nullptr, nullptr, 0, 0};
     const int64_t row_bytes = d * (dtype == FF_F32 ? 4 : 2);
     const int nblk = (int)((row_bytes + 1023) / 1024);
-    const int n_main = (int)((L + kSlotsDefault - 1) / kSlotsDefault);
+    const int ny = (nblk + kMergeWaves - 1) / kMergeWaves;
+    const int slots = merge_slots(dtype, addend != nullptr, L, ny);
+    const int n_main = (int)((L + slots - 1) / slots);
     const int n_aux_blocks = pack.n ? (int)((L + kMergeWaves * 4 - 1) / (kMergeWaves * 4)) : 0;
     if (!order || !stats) order_next = nullptr;
     const int n_next_blocks = order_next ? (int)((L + kMergeThreads * 16 - 1) / (kMergeThreads * 16)) : 0;
     ZeroJob zero{(uint4*)zero_a, (int)(zero_a_bytes / 16), zero_keys, (int)zero_n, zero_key_dt, t16_end, 0};
     if (zero_a) zero.n_blocks = zero_keys ? (int)((zero_n + kMergeThreads * 16 - 1) / (kMergeThreads * 16)) : 1;
-    const dim3 grid((unsigned)(n_main + n_aux_blocks + n_next_blocks + zero.n_blocks),
-                    (unsigned)((nblk + kMergeWaves - 1) / kMergeWaves));
+    const dim3 grid((unsigned)(n_main + n_aux_blocks + n_next_blocks + zero.n_blocks), (unsigned)ny);
     const char* h = (const char*)hidden;
     char* o = (char*)hidden_out;
     const int64_t* ident = (skip_identity && stats) ? stats : nullptr;
 #define FF_MC_LAUNCH(DT, ADD)                                                                                          \
     hipLaunchKernelGGL((k_merge_compact<DT, ADD>), grid, dim3(kMergeThreads), 0, st, h, (const char*)addend, o,          \
                        (uint32_t)row_bytes, (int)L, L_cap, order, member, fold, dst, keep, pack, n_main, n_aux_blocks,  \
-                       n_next_blocks, order_next, inv_next, stats, ident, zero)
+                       n_next_blocks, order_next, inv_next, stats, ident, zero, slots)
     switch (dtype) {
         case FF_F32: if (addend) FF_MC_LAUNCH(FF_F32, true); else FF_MC_LAUNCH(FF_F32, false); break;
         case FF_BF16: if (addend) FF_MC_LAUNCH(FF_BF16, true); else FF_MC_LAUNCH(FF_BF16, false); break;
