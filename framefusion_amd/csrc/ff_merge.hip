@@ -21,7 +21,6 @@ namespace ff {
 
 constexpr int kMergeThreads = 256;
 constexpr int kMergeWaves = kMergeThreads / kWave;
-constexpr int kSlotsMin = 16, kSlotsMax = 56;   // consecutive by-patch slots per workgroup (chosen per launch)
 
 
 struct AuxPack {
@@ -195,7 +194,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
     const int dv = anchor_lane ? dst[ordw] : 0;
 
     // first slot of the stream
-    const unsigned long long own = (1ull << (t_end - t0)) - 1ull;         // slots <= kSlotsMax
+    const unsigned long long own = (1ull << (t_end - t0)) - 1ull;         // slots <= 53 (merge_slots)
     const unsigned long long starts = ~memw & own;
     if (starts == 0ull) return;                             // every slot here belongs to an earlier anchor
 
@@ -322,11 +321,15 @@ __global__ __launch_bounds__(256) void k_gather_mask(const char* __restrict__ ma
     }
 }
 
-// Slots per workgroup.  The waves of this kernel are long streams, so a launch whose workgroups do not all
-// fit on the chip at once ends with a nearly empty second round (32 slots at 64 x 576 x 4096: 2 304 workgroups
-// on 2 048 places, 79 us; 37 slots: 1 994 workgroups, 71 us; 36 / 38 slots: 73.6 us).  The main workgroups
-// are sized to fill ~97 % of r rounds' places - the rest is for the short aux / order / table blocks that
-// pass through - with the smallest r that keeps the slot window within kSlotsMax.
+// Slots per workgroup, chosen per launch (measured at 64 x 576 x 4096, K4 in the step; 32 was the fixed value):
+//  * the waves are long streams, so a launch whose workgroups do not all fit on the chip at once ends with a
+//    nearly empty extra round: 32 slots = 2 304 workgroups on 2 048 places 79 us, 36 slots (2 048) 73.6 us,
+//    40 slots (1 844) 75.8 us, 48 slots (1 536) 80.5 us.  The main workgroups are sized to ~97 % of r rounds'
+//    places (the rest is for the short aux / order / table blocks passing through), smallest r that fits;
+//  * all workgroups start together and advance at the same pace: when the slot count shares a factor with the
+//    frames per patch they all sit on the same few frames - the same few MB - at any time (64 frames: 16 / 24 /
+//    32 slots 34.5 us, 19 / 21 slots 31 us at 64 x 210 x 3584; 36 / 38 slots 73.6 us, 37 slots 71 us above).
+//    A prime count staggers the workgroups over the frames whatever the frame count is.
 template <int DT, bool kAdd>
 static int merge_places() {
     static const int places = [] {
@@ -347,10 +350,12 @@ static int merge_slots(int dtype, bool add, int64_t L, int ny) {
         case FF_BF16: places = add ? merge_places<FF_BF16, true>() : merge_places<FF_BF16, false>(); break;
         default: places = add ? merge_places<FF_F16, true>() : merge_places<FF_F16, false>();
     }
+    static const int primes[] = {17, 19, 23, 29, 31, 37, 41, 43, 47, 53};
     const double fill = 0.975 * (double)places;
     for (int r = 1;; ++r) {
-        const int s = (int)((double)L * ny / (fill * r)) + 1;
-        if (s <= kSlotsMax) return s < kSlotsMin ? kSlotsMin : s;
+        const double want = (double)L * ny / (fill * r);
+        for (int p : primes)
+            if ((double)p >= want) return p;
     }
 }
 
