@@ -14,7 +14,6 @@
 //     dot = T(sum_fp32 T(a_i*b_i));  na = T(sqrt_fp32(sum_fp32 a_i^2));  sim = T(dot / T(na*nb))
 // sqrt and divide are the correctly rounded fp32 forms (hipcc default).
 #include "ff_common.h"
-#include <cstdlib>
 
 namespace ff {
 
@@ -234,205 +233,6 @@ __global__ __launch_bounds__(kSimThreads) void k_pair_similarity(
     }
 }
 
-// ---- column-tile decomposition -----------------------------------------------------------------------
-// The same computation laid out like the merge pass (ff_merge.hip): a workgroup of 8 waves owns `slots`
-// consecutive by-patch positions, i.e. the rows order[t0-1 .. t0+slots-1]; wave w owns the 1 KiB column
-// tile(s) w (and w+8) of every row and STREAMS the rows one after the other - the previous row's piece stays
-// in 4 registers, kDepth pieces in flight - so a row is re-read once per `slots` rows instead of once per 4.
-// Per row and column the lanes' partial |x|^2 and sum of T-rounded products are reduced on the DPP network
-// and parked in LDS; the first wave adds the columns up at the end and finishes its slots.
-__device__ inline float wave_total_dpp(float v) {
-#define FF_DPP_ADD(ctrl, rows) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rows, 0xf, false))
-    FF_DPP_ADD(0x111, 0xf);     // row_shr:1
-    FF_DPP_ADD(0x112, 0xf);     // row_shr:2
-    FF_DPP_ADD(0x114, 0xf);     // row_shr:4
-    FF_DPP_ADD(0x118, 0xf);     // row_shr:8
-    FF_DPP_ADD(0x142, 0xa);     // row_bcast:15
-    FF_DPP_ADD(0x143, 0xc);     // row_bcast:31
-#undef FF_DPP_ADD
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-
-constexpr int kColThreads = 512, kColWaves = kColThreads / kWave, kColMaxSlots = 53;
-template <int DT, int kCpw, int kDepth, bool kHint, bool kAdd>
-__global__ __launch_bounds__(kColThreads) void k_pair_similarity_col(
-    const char* __restrict__ hidden, const char* __restrict__ addend, uint32_t row_bytes, const int64_t* __restrict__ ptype,
-    const int32_t* __restrict__ order, const int64_t* __restrict__ stats, void* __restrict__ sim,
-    int* __restrict__ l0, int* t16_end, float thr, const LayoutHint hint, int32_t* __restrict__ order_out,
-    int32_t* __restrict__ inv_out, int64_t* __restrict__ stats_out, int slots) {
-    using A = Act<DT>;
-    constexpr int E = A::kPer16;
-    __shared__ float sm_n[kColMaxSlots + 1][kColWaves], sm_d[kColMaxSlots + 1][kColWaves];
-    const int lane = lane_id(), w = uniform(wave_id());
-    int nv;
-    if constexpr (kHint) {
-        nv = hint.patches * hint.frames;
-        const int n_tail = hint.L - nv;
-        const int gtid = blockIdx.x * kColThreads + threadIdx.x;
-        for (int q = gtid; q < n_tail; q += (int)gridDim.x * kColThreads) {
-            const int i = q < hint.pre ? q : q + nv;
-            if (ptype[i] != -1) atomicOr((unsigned long long*)(stats_out + FF_STAT_ERROR), (unsigned long long)FF_ERR_BIT_LAYOUT);
-            order_out[nv + q] = i;
-            if (inv_out) inv_out[i] = nv + q;
-        }
-        if (gtid == 0) {
-            stats_out[FF_STAT_NV] = nv;
-            stats_out[FF_STAT_FTN] = nv;
-        }
-    } else {
-        nv = (int)stats[FF_STAT_NV];
-    }
-    const int t0 = (int)blockIdx.x * slots;
-    if (t0 >= nv) return;                                         // (the whole workgroup)
-    const int n = min(slots, nv - t0), rows = n + 1;              // row r = slot t0-1+r
-
-    auto pos_of = [&](int j, int& p_out, int& f_out) {
-        if constexpr (kHint) {
-            const int p = j / hint.frames, f = j - p * hint.frames;
-            p_out = p; f_out = f;
-            return hint.pre + f * hint.patches + p;
-        } else {
-            p_out = 0; f_out = 0;
-            return (int)order[j];
-        }
-    };
-    int my_row, slot_i, slot_p, slot_f;
-    {
-        int j = t0 - 1 + lane, pp, ff_;
-        j = j < 0 ? 0 : (j >= nv ? nv - 1 : j);
-        my_row = pos_of(j, pp, ff_);
-        slot_i = pos_of(min(t0 + lane, nv - 1), slot_p, slot_f);
-    }
-    const int my_slot = t0 + lane;
-    const bool owner = w == 0 && lane < n;
-    int64_t my_type = 0, left_type = 0;
-    if (owner) {
-        my_type = ptype[slot_i];                                   // requested now, used at the end
-        if constexpr (!kHint) left_type = ptype[my_row];           // (lane r's row r is slot t0+r-1)
-    }
-
-    // the pieces of this wave: column tile w (+ 8) of rows 0 .. rows-1, kDepth rows ahead
-    const uint32_t lane_off = (uint32_t)lane * 16;
-    auto desc = [&](int r, const char* base, int k) {
-        const int64_t i = (int64_t)__builtin_amdgcn_readlane(my_row, r < rows ? r : 0);
-        const uint32_t col = (uint32_t)(w + k * kColWaves) * 1024u;
-        const uint32_t len = (r < rows && col < row_bytes) ? min(1024u, row_bytes - col) : 0u;     // (0: the loads return zeros)
-        return make_rsrc(base + i * row_bytes + col, len);
-    };
-    // two register batches of kDepth rows: one is requested while the other is reduced (the shape the merge
-    // kernel uses; a finer-grained rotation makes the compiler copy registers that loads are still pending on)
-    struct Batch { uint4 v[kDepth][kCpw]; uint4 v2[kAdd ? kDepth : 1][kCpw]; };
-    Batch ba, bb;
-    uint4 prev[kCpw];
-#pragma unroll
-    for (int k = 0; k < kCpw; ++k) prev[k] = make_uint4(0, 0, 0, 0);
-    auto issue = [&](Batch& t, int rbase) {
-#pragma unroll
-        for (int d = 0; d < kDepth; ++d)
-#pragma unroll
-            for (int k = 0; k < kCpw; ++k) {
-                t.v[d][k] = buf_load16(desc(rbase + d, hidden, k), lane_off);
-                if constexpr (kAdd) t.v2[d][k] = buf_load16(desc(rbase + d, addend, k), lane_off);
-            }
-    };
-    auto reduce = [&](Batch& t, int rbase) {
-#pragma unroll
-        for (int d = 0; d < kDepth; ++d) {
-            const int r = rbase + d;
-            float nacc = 0.f, dacc = 0.f;
-#pragma unroll
-            for (int k = 0; k < kCpw; ++k) {
-                uint4 v = t.v[d][k];
-                if constexpr (kAdd) v = add16<DT>(v, t.v2[d][k]);
-                if constexpr (DT == FF_BF16) {
-                    float x[E], pv[E];
-                    nacc = A::sumsq(v, nacc);
-                    A::unpack(prev[k], pv);
-                    A::unpack(v, x);
-                    dacc = A::dot_rounded(pv, x, dacc);
-                } else if constexpr (DT == FF_F16) {
-                    nacc = A::sumsq(v, nacc);
-                    dacc = A::dot_rounded_raw(prev[k], v, dacc);
-                } else {
-                    float x[E], pv[E];
-                    A::unpack(prev[k], pv);
-                    A::unpack(v, x);
-#pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        nacc = __builtin_fmaf(x[e], x[e], nacc);
-                        dacc += A::rnd(pv[e] * x[e]);
-                    }
-                }
-                prev[k] = v;
-            }
-            const float ns = wave_total_dpp(nacc), ds = wave_total_dpp(dacc);
-            if (lane == 0 && r < rows) { sm_n[r][w] = ns; sm_d[r][w] = ds; }
-        }
-    };
-    issue(ba, 0);
-    for (int r0 = 0; r0 < rows; r0 += 2 * kDepth) {
-        issue(bb, r0 + kDepth);
-        __builtin_amdgcn_sched_barrier(0);
-        reduce(ba, r0);
-        __builtin_amdgcn_sched_barrier(0);
-        issue(ba, r0 + 2 * kDepth);
-        __builtin_amdgcn_sched_barrier(0);
-        reduce(bb, r0 + kDepth);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    __syncthreads();
-    if (w != 0) return;
-
-    float mine = -2.0f;   // IGNORE_TOKEN (main.py:225-238)
-    if (owner) {
-        float na_sum = 0.f, nb_sum = 0.f, d_sum = 0.f;
-#pragma unroll
-        for (int c = 0; c < kColWaves; ++c) {
-            na_sum += sm_n[lane][c];
-            nb_sum += sm_n[lane + 1][c];
-            d_sum += sm_d[lane + 1][c];
-        }
-        bool same_type;
-        if constexpr (kHint) {
-            if (my_type != (int64_t)slot_p)
-                atomicOr((unsigned long long*)(stats_out + FF_STAT_ERROR), (unsigned long long)FF_ERR_BIT_LAYOUT);
-            order_out[my_slot] = slot_i;
-            if (inv_out) inv_out[slot_i] = my_slot;
-            same_type = slot_f != 0;                               // the previous slot is the same patch one frame earlier
-        } else {
-            same_type = my_slot > 0 && left_type == my_type;
-        }
-        if (same_type) {
-            const float d = A::rnd(d_sum);
-            const float na = A::rnd(sqrtf(na_sum));
-            const float nb = A::rnd(sqrtf(nb_sum));
-            const float den = A::rnd(na * nb);
-            mine = A::rnd(d / den);
-        }
-        A::store1(sim, my_slot, mine);
-    }
-    if (l0) {
-        // select statistics of the plan kernel that follows (see k_pair_similarity): the workgroup's values.
-        // (a workgroup's slots may straddle two 4096-slices of the level-1 tables: one fold per slice)
-        uint32_t bits;
-        if constexpr (DT == FF_F32) bits = __float_as_uint(mine);
-        else if constexpr (DT == FF_BF16) bits = __float_as_uint(mine) >> 16;
-        else { _Float16 h = (_Float16)mine; bits = (uint32_t)__builtin_bit_cast(uint16_t, h); }
-        const uint32_t key = order_key<DT>(bits);
-        int* tab = l0 + (blockIdx.x & (kL0Copies - 1)) * kL0Stride;
-        const int n_ge = __popcll(__ballot(owner && mine >= thr));
-        if (lane == 0 && n_ge) atomicAdd(&tab[256], n_ge);
-        wave_agg_add<3>(tab, key >> (A::kKeyBits - 8), owner);
-        const int s_lo = t0 / kSelSlice, s_mine = my_slot / kSelSlice;
-        int* t16a = t16_slice(t16_end, s_lo) + (blockIdx.x & (kT16Copies - 1)) * 65536;
-        wave_agg_add<6>(t16a, t16_bin(key >> (A::kKeyBits - 16)), owner && s_mine == s_lo);
-        if ((t0 + n - 1) / kSelSlice != s_lo) {                   // (uniform)
-            int* t16b = t16_slice(t16_end, s_lo + 1) + (blockIdx.x & (kT16Copies - 1)) * 65536;
-            wave_agg_add<6>(t16b, t16_bin(key >> (A::kKeyBits - 16)), owner && s_mine != s_lo);
-        }
-    }
-}
-
 struct SimArgs {
     const void* hidden;
     const void* addend;       // NULL: the rows are hidden's
@@ -470,39 +270,8 @@ static int launch_similarity_pt(const SimArgs& a, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-template <int DT, int kCpw, int kDepth>
-static int launch_similarity_col(const SimArgs& a, hipStream_t st, int slots) {
-    const int64_t row_bytes = a.d * Act<DT>::kBytes;
-    const int64_t blocks = (a.L + slots - 1) / slots;
-#define FF_COL_LAUNCH(HINT, ADD, OO, IO, SO)                                                                           \
-    hipLaunchKernelGGL((k_pair_similarity_col<DT, kCpw, kDepth, HINT, ADD>), dim3((unsigned)blocks), dim3(kColThreads), 0, \
-                       st, (const char*)a.hidden, (const char*)a.addend, (uint32_t)row_bytes, a.ptype, a.order, a.stats,   \
-                       a.sim, a.l0, a.t16_end, a.thr, a.hint, OO, IO, SO, slots)
-    if (a.hint.frames > 0) {
-        if (a.addend) FF_COL_LAUNCH(true, true, a.order_out, a.inv_out, a.stats_out);
-        else FF_COL_LAUNCH(true, false, a.order_out, a.inv_out, a.stats_out);
-    } else {
-        if (a.addend) FF_COL_LAUNCH(false, true, (int32_t*)nullptr, (int32_t*)nullptr, (int64_t*)nullptr);
-        else FF_COL_LAUNCH(false, false, (int32_t*)nullptr, (int32_t*)nullptr, (int64_t*)nullptr);
-    }
-#undef FF_COL_LAUNCH
-    return (int)hipGetLastError();
-}
-
 template <int DT>
-static int launch_similarity(const SimArgs& a, hipStream_t st) {
-#ifdef FF_K1_EXPERIMENT
-    static const int col = getenv("FF_K1_COL") ? atoi(getenv("FF_K1_COL")) : 0;
-    static const int slots = getenv("FF_K1_SLOTS") ? atoi(getenv("FF_K1_SLOTS")) : 37;
-    const int64_t rb = a.d * Act<DT>::kBytes;
-    if (col && rb <= 8192) {
-        if (col == 2) return launch_similarity_col<DT, 1, 2>(a, st, slots);
-        if (col == 4) return launch_similarity_col<DT, 1, 4>(a, st, slots);
-        if (col == 8) return launch_similarity_col<DT, 1, 8>(a, st, slots);
-    }
-#endif
-    return launch_similarity_pt<DT, 4, 256>(a, st);
-}
+static int launch_similarity(const SimArgs& a, hipStream_t st) { return launch_similarity_pt<DT, 4, 256>(a, st); }
 
 // hint_frames > 0: frame-major closed form (see LayoutHint); `order` and `stats` are then outputs.
 int launch_similarity_any(const void* hidden, const void* addend, int dtype, int64_t L, int64_t d, const int64_t* ptype,
