@@ -80,6 +80,28 @@ __global__ void k_read_rows(const char* __restrict__ base, int n_rows, int row_b
 }
 
 
+// pattern 1b: frame-major sweep: wave i reads row i and row i + P (its partner in the next frame), memory order:
+// every row is read twice, the second time P rows (4.7 MB) after the first - from the Infinity Cache, if it
+// delivers on top of the HBM stream
+template <int PF>
+__global__ void k_read_pairs(const char* __restrict__ base, int n_rows, int row_bytes, int P, uint4* __restrict__ sink) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (wave + P >= n_rows) return;
+    const char* ra = base + (size_t)wave * row_bytes;
+    const char* rb = base + (size_t)(wave + P) * row_bytes;
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    const int tiles = row_bytes >> 10;
+    uint4 ca = *(const uint4*)(ra + lane * 16), cb = *(const uint4*)(rb + lane * 16);
+    for (int t = 0; t < tiles; ++t) {
+        const int no = (t + 1 < tiles ? t + 1 : t) * 1024 + lane * 16;
+        const uint4 na = *(const uint4*)(ra + no), nb = *(const uint4*)(rb + no);
+        acc.x ^= ca.x ^ cb.x; acc.y ^= ca.y ^ cb.y; acc.z ^= ca.z ^ cb.z; acc.w ^= ca.w ^ cb.w;
+        ca = na; cb = nb;
+    }
+    if (acc.x == 0x12345678u && acc.y == 0x9abcdef0u) sink[0] = acc;
+}
+
 // pattern 2: a wave owns NR consecutive by-patch rows and streams them ONE AFTER THE OTHER (a single
 // sequential stream per wave, DEPTH tiles in flight) - the shape of a similarity kernel that keeps
 // the previous row in registers instead of reading R rows side by side
@@ -226,6 +248,12 @@ int main(int argc, char** argv) {
         float us = time_us([&] { flip ^= 1; hipLaunchKernelGGL((k_read_rows<R, 1, ROT>), dim3(blocks), dim3(TPB), 0, 0, (const char*)(flip ? a : b), n_rows, row_bytes, F, sink); }, 10); \
         printf("rows  R=%d pf=1 rot=%d tpb=%4d blocks=%6d : %7.1f us  %7.1f GB/s\n", R, ROT, TPB, blocks, us, (double)n_rows * row_bytes / us / 1e3); }
     ROWSR(5, 256, 0) ROWSR(5, 256, 1) ROWSR(5, 256, 2) ROWSR(4, 256, 0) ROWSR(4, 256, 1) ROWSR(4, 256, 2) ROWSR(5, 256, 0) ROWSR(5, 256, 1) ROWSR(5, 256, 2)
+    { const int P = n_rows / F;
+      for (int tpb : {256, 512, 64}) {
+        const int blocks = (n_rows * 64 + tpb - 1) / tpb;
+        float us = time_us([&] { flip ^= 1; hipLaunchKernelGGL((k_read_pairs<1>), dim3(blocks), dim3(tpb), 0, 0, (const char*)(flip ? a : b), n_rows, row_bytes, P, sink); }, 10);
+        printf("pairs frame-major tpb=%4d : %7.1f us  %7.1f GB/s (unique bytes; every row read twice)\n", tpb, us, (double)n_rows * row_bytes / us / 1e3);
+      } }
     if (argc > 2) return 0;
     ROWS(1, 256) ROWS(2, 256) ROWS(4, 256) ROWS(5, 256) ROWS(8, 256) ROWS(4, 128) ROWS(4, 512) ROWS(2, 512)
 #define SEQ(NR, DEPTH, TPB, OV) { \
