@@ -236,7 +236,7 @@ __device__ inline int block_excl_scan(int v, int* scratch, int& total) {
 // the END of the workspace (slice g ends at ws_end - g * kT16SliceInts): both locations depend on
 // neither L nor the call, so "zero on entry" survives calls of different lengths.
 constexpr int kSelSlice = 4096;
-constexpr int kL0Copies = 4;
+constexpr int kL0Copies = 16;
 constexpr int kL0Stride = 260;                    // 256 bins + count + pad
 constexpr int kL0Ints = kL0Copies * kL0Stride;
 constexpr int kT16Copies = 1;
