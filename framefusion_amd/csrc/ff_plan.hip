@@ -338,13 +338,11 @@ __device__ inline void publish(int64_t* __restrict__ stats, int64_t* host_mapped
 // chain.  The tag is a per-workspace launch counter kept on the device (graph-replay safe).
 constexpr int kRegChunks = 5;               // 40 960 slots in registers; longer sequences load the rest on the fly
 constexpr int kChunkStride = kPlanThreads * 8;
-constexpr int kRowSlicesLds = 16;           // level-1 rows kept in LDS for the tie-slice search (else re-read)
+constexpr int kRowSlicesLds = 16;           // k_plan_fast: level-1 rows kept in LDS for the tie-slice search
 constexpr int kMaxPlanGroups = 240;         // every workgroup must be resident (one per CU): L < 983 040
-static_assert(65536 / 1024 <= 64, "k_plan_fast polls its predecessors in one pass of 64 lanes");
 
 struct PlanLds {
     SelLds<kPlanThreads> sel;
-    int rows[kRowSlicesLds][256];
 };
 
 template <int DT>
@@ -385,34 +383,7 @@ __device__ inline void load_chunk(__amdgpu_buffer_rsrc_t values, int t0, uint4* 
     for (int x = 0; x < KW; ++x) kw[x] = buf_load16(values, (uint32_t)t0 * (uint32_t)Act<DT>::kBytes + 16u * x);
 }
 
-// wave 0: the bin, from the top, in which the running count over tot[q][*] reaches `rem`
-template <int NQ>
-__device__ inline void wave_pick(const int (*part)[256], int lane, int rem, int& bin_out, int& above_out) {
-    const int top = 255 - 4 * lane;
-    int v[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        v[e] = 0;
-#pragma unroll
-        for (int x = 0; x < NQ; ++x) v[e] += part[x][top - e];
-    }
-    const int sum = v[0] + v[1] + v[2] + v[3];
-    const int incl = wave_incl_scan(sum);
-    const int first = __ffsll((long long)__ballot(incl >= rem)) - 1;
-    int ab = incl - sum, bin = top;
-    if (ab + v[0] >= rem) { bin = top; }
-    else if (ab + v[0] + v[1] >= rem) { ab += v[0]; bin = top - 1; }
-    else if (ab + v[0] + v[1] + v[2] >= rem) { ab += v[0] + v[1]; bin = top - 2; }
-    else { ab += v[0] + v[1] + v[2]; bin = top - 3; }
-    bin_out = __builtin_amdgcn_readlane(bin, first);
-    above_out = __builtin_amdgcn_readlane(ab, first);
-}
-
-// kFast: 16-bit keys, at most kRowSlicesLds slices, every value chunk in registers (L <= kRegChunks x 8192):
-// the common case gets a kernel without the general paths - this kernel starts with a cold
-// instruction cache (its predecessor streamed hundreds of MB through every L2), and what it costs is
-// mostly the number of instruction lines it walks through.
-template <int DT, bool kFast>
+template <int DT>
 __global__ __launch_bounds__(kPlanThreads) void k_plan(
     const void* __restrict__ values, int cap, PlanParams pp, const int* __restrict__ l0, int* t16_end,
     const int* __restrict__ lv, int64_t* __restrict__ stats, const int32_t* __restrict__ inv, int L,
@@ -422,11 +393,8 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan(
     constexpr int kLevels = A::kKeyBits / 8;
     constexpr int KW = A::kBytes == 2 ? 1 : 2;
     constexpr int NW = kPlanThreads / kWave;
-    constexpr int NQ = kPlanThreads / 256;
-    constexpr int kSpec = 3;                      // speculative level-1 slices per thread (12 slices = 49 152 values)
-    static_assert(!kFast || kLevels == 2, "the fast variant resolves exactly two radix levels");
     __shared__ PlanLds s;
-    const int tid = threadIdx.x, lane = lane_id(), c = tid & 255, q = tid >> 8;
+    const int tid = threadIdx.x, lane = lane_id();
     const int base = blockIdx.x * kSelSlice;
 #ifdef FF_PLAN_PROBE
     long long stamp[6];
@@ -439,19 +407,6 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan(
     // are even issued.
     const long long nv_raw = stats[FF_STAT_NV];
     const long long ftn = stats[FF_STAT_FTN];
-    int l0v[kL0Copies / NQ], specv[kSpec][kT16Copies];
-#pragma unroll
-    for (int x = 0; x < kL0Copies / NQ; ++x) l0v[x] = l0[(q + x * NQ) * kL0Stride + c];
-    const int l0cnt_raw = l0[(tid & (kL0Copies - 1)) * kL0Stride + 256];
-    if constexpr (kFast) {
-#pragma unroll
-        for (int j = 0; j < kSpec; ++j) {
-            const int g = min(q + j * NQ, pp.n_slices - 1);          // (clamped: the value is only used for g < n_slices)
-            const int* row = t16_slice(t16_end, g) + t16_bin(((uint32_t)pp.p0_guess << 8) | (uint32_t)c);
-#pragma unroll
-            for (int x = 0; x < kT16Copies; ++x) specv[j][x] = row[x * 65536];
-        }
-    }
     const uint32_t tag_prev = *tagword;
     const int i0 = base + tid * 4;                // my positions
     const __amdgpu_buffer_rsrc_t inv_rsrc = make_rsrc(inv ? (const void*)inv : values, inv ? (uint32_t)L * 4u : 0u);
@@ -488,9 +443,7 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan(
 #pragma unroll
                 for (int w = 0; w < KW; ++w) sel[w] = kw[y][w];
             }
-        if constexpr (!kFast) {
-            if (x >= kRegChunks) load_chunk<DT>(val_rsrc, t0, sel);
-        }
+        if (x >= kRegChunks) load_chunk<DT>(val_rsrc, t0, sel);
         chunk_keys<DT>(sel, key);
         patch_last<DT>(key, t0, cap, last_key);
     };
@@ -498,94 +451,7 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan(
     // ---- decision + k-th key -------------------------------------------------------------------------
     Resolved r;
     int sl = 0, want = 0;                         // the want-th (1-based) entry equal to kth inside slice sl is the last one taken
-    if constexpr (kFast) {
-        // two rounds (radix levels 0 and 1), each: every thread drops its partial column sum into LDS,
-        // wave 0 picks the bin.  bcast: [0] topk, [1] count, [2] k, [3] prefix so far, [4] remaining,
-        // [5] tie slice, [6] want
-        int colsum = 0;
-#pragma unroll
-        for (int x = 0; x < kL0Copies / NQ; ++x) colsum += l0v[x];
-        if (tid < kL0Copies) s.sel.scratch[tid] = l0cnt_raw;
-        r.topk = false; r.k = 0; r.count = 0; r.prefix = 0; r.remaining = 0;
-#pragma unroll 1
-        for (int level = 0; level < 2; ++level) {
-            s.sel.part[q][c] = colsum;
-            __syncthreads();
-            if (tid < kWave) {
-                int rem, prefix = 0;
-                bool go;
-                if (level == 0) {
-                    int cnt = lane < kL0Copies ? s.sel.scratch[lane] : 0;
-                    cnt = wave_sum_i(cnt);
-                    bool topk;
-                    long long k;
-                    if (pp.mode == 0 && pp.k_given >= 0) {
-                        topk = true;                              // fixed-sparsity policy (modeling_qwen2_baseline.py:920,1001)
-                        k = pp.k_given > nv ? (long long)nv : pp.k_given;
-                    } else if (pp.mode == 0) {
-                        // main.py:114-116 in double, as python: ratio = count / ftn ; ratio < sub ?
-                        const double ratio = ftn > 0 ? (double)cnt / (double)ftn : 0.0;
-                        topk = !(ratio < pp.sub);
-                        k = 0;
-                        if (topk) {
-                            k = (long long)(pp.sub * (double)ftn);   // int(sub * ftn), main.py:122
-                            if (k > nv) k = nv;
-                            if (k < 0) k = 0;
-                        }
-                    } else {
-                        topk = true;
-                        k = pp.k_given;
-                    }
-                    if (lane == 0) { s.sel.bcast[0] = topk ? 1 : 0; s.sel.bcast[1] = cnt; s.sel.bcast[2] = (int)k; }
-                    rem = (int)k;
-                    go = topk && k > 0;
-                } else {
-                    rem = s.sel.bcast[4];
-                    prefix = s.sel.bcast[3];
-                    go = true;
-                }
-                int bin = 0, above = 0;
-                if (go) wave_pick<NQ>(s.sel.part, lane, rem, bin, above);
-                rem -= above;
-                prefix = (prefix << 8) | bin;
-                if (level == 1) {
-                    // the slice that holds the rem-th entry equal to the k-th key (entries per slice = rows[g][bin])
-                    const int ties = lane < pp.n_slices ? s.rows[lane][bin] : 0;
-                    const int tincl = wave_incl_scan(ties);
-                    const int hit = __ffsll((long long)__ballot(tincl >= rem)) - 1;
-                    const int before_hit = __builtin_amdgcn_readlane(tincl - ties, hit);
-                    if (lane == 0) { s.sel.bcast[5] = hit; s.sel.bcast[6] = rem - before_hit; }
-                }
-                if (lane == 0) { s.sel.bcast[3] = prefix; s.sel.bcast[4] = rem; }
-            }
-            __syncthreads();
-            if (level == 0) {
-                r.topk = s.sel.bcast[0] != 0; r.count = s.sel.bcast[1]; r.k = s.sel.bcast[2];
-                if (!(r.topk && r.k > 0)) break;                    // (uniform)
-                // level-1 rows of the level-0 bin: the speculated ones if the guess was right
-                const int p0 = s.sel.bcast[3];
-                colsum = 0;
-                for (int g = q, j = 0; g < pp.n_slices; g += NQ, ++j) {
-                    int v = 0;
-                    if (j < kSpec && p0 == pp.p0_guess) {
-#pragma unroll
-                        for (int x = 0; x < kT16Copies; ++x) v += j == 0 ? specv[0][x] : (j == 1 ? specv[1][x] : specv[2][x]);
-                    } else {
-                        const int* row = t16_slice(t16_end, g) + t16_bin(((uint32_t)p0 << 8) | (uint32_t)c);
-#pragma unroll
-                        for (int x = 0; x < kT16Copies; ++x) v += row[x * 65536];
-                    }
-                    s.rows[g][c] = v;
-                    colsum += v;
-                }
-            } else {
-                r.prefix = (uint32_t)s.sel.bcast[3];
-                r.remaining = s.sel.bcast[4];
-                sl = s.sel.bcast[5];
-                want = s.sel.bcast[6];
-            }
-        }
-    } else {
+    {
         r = resolve<kPlanThreads>(pp, l0, t16_end, lv, kLevels, ftn, nv, s.sel);
         if (r.topk && r.k > 0) {
             // entries equal to kth per slice: the last level's rows count exactly those
@@ -766,14 +632,14 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan(
 
 // ---- k_plan_fast: the same plan for 16-bit values of at most 65 536 tokens ------------------------------
 // The general kernel above is bound by instruction issue (16 waves on one CU walk ~2 500 instructions
-// each: register-chunk selection, shuffle scans through LDS, divergent branches) and pays a second
-// global round trip for whatever is not in registers.  Here a workgroup of 16 waves owns only 1024
-// slots and 1024 positions - ONE of each per thread - and ALL values sit in LDS (74 KB at 64 x 576,
-// filled by one batch of loads): any slot is one ds_read away, so the tie-slot search, the member flag
-// and the gather through inv[] need neither register selection nor another trip to memory; the wave
-// scans run on the DPP network and the classification is branch-free.  The rest is as above: tables ->
-// k-th key by wave 0, tie slot t*, per-workgroup totals exchanged as {tag, count} granules (published
-// before the member flags are computed, so the hop overlaps with work).
+// each: register-chunk selection, shuffle scans through LDS, divergent branches).  Here a workgroup of
+// kFastThreads threads owns kFastThreads slots and as many positions - ONE of each per thread, loaded in
+// the first round together with the tables (staging ALL values in LDS was tried: one CU pulls ~12 B/clk, the
+// first barrier came at 4.9 us).  The only load that depends on the decision is the 8 KB slice that holds
+// the tie slot t*; the wave scans run on the DPP network and the classification is branch-free.  The rest
+// is as above: tables -> k-th key by wave 0, tie slot t*, per-workgroup totals exchanged as {tag, count}
+// granules (published before the member flags are computed, so the hop overlaps with work; a workgroup
+// polls its <= 127 predecessors in two passes of 64 lanes).
 #ifndef FF_FAST_THREADS
 #define FF_FAST_THREADS 512
 #endif
@@ -1253,7 +1119,7 @@ static int launch_plan(const void* values, PlanParams pp, bool have_tables, int6
             return FF_OK;
         }
     }
-    hipLaunchKernelGGL((k_plan<DT, false>), dim3(G), dim3(kPlanThreads), 0, st, values, (int)cap, pp, (const int*)l0, t16_end,
+    hipLaunchKernelGGL(k_plan<DT>, dim3(G), dim3(kPlanThreads), 0, st, values, (int)cap, pp, (const int*)l0, t16_end,
                        (const int*)lv, stats, inv, (int)L, member, keep, dst, ws_agg(ws), ws_tag(ws), host_mapped, seq);
     int rc = (int)hipGetLastError();
     if (rc) return rc;
