@@ -80,6 +80,33 @@ __global__ void k_read_rows(const char* __restrict__ base, int n_rows, int row_b
 }
 
 
+// pattern 1c: K1's shape (R rows of one patch side by side) with the waves mapped patch-fastest: adjacent waves read
+// ADJACENT rows of the same frames (contiguous 8 KiB pieces) instead of later frames of the same patch
+template <int R>
+__global__ void k_read_rows_pf(const char* __restrict__ base, int n_rows, int row_bytes, int F, uint4* __restrict__ sink) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int P = n_rows / F, groups = F / R;
+    if (wave >= P * groups) return;
+    const int pp = wave % P, g = wave / P;
+    const char* row[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) row[r] = base + (size_t)((g * R + r) * P + pp) * row_bytes;
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    uint4 cur[R], nxt[R];
+    const int tiles = row_bytes >> 10;
+#pragma unroll
+    for (int r = 0; r < R; ++r) cur[r] = *(const uint4*)(row[r] + lane * 16);
+    for (int t = 0; t < tiles; ++t) {
+        const int no = (t + 1 < tiles ? t + 1 : t) * 1024 + lane * 16;
+#pragma unroll
+        for (int r = 0; r < R; ++r) nxt[r] = *(const uint4*)(row[r] + no);
+#pragma unroll
+        for (int r = 0; r < R; ++r) { acc.x ^= cur[r].x; acc.y ^= cur[r].y; acc.z ^= cur[r].z; acc.w ^= cur[r].w; cur[r] = nxt[r]; }
+    }
+    if (acc.x == 0x12345678u && acc.y == 0x9abcdef0u) sink[0] = acc;
+}
+
 // pattern 1b: frame-major sweep: wave i reads row i and row i + P (its partner in the next frame), memory order:
 // every row is read twice, the second time P rows (4.7 MB) after the first - from the Infinity Cache, if it
 // delivers on top of the HBM stream
@@ -248,6 +275,17 @@ int main(int argc, char** argv) {
         float us = time_us([&] { flip ^= 1; hipLaunchKernelGGL((k_read_rows<R, 1, ROT>), dim3(blocks), dim3(TPB), 0, 0, (const char*)(flip ? a : b), n_rows, row_bytes, F, sink); }, 10); \
         printf("rows  R=%d pf=1 rot=%d tpb=%4d blocks=%6d : %7.1f us  %7.1f GB/s\n", R, ROT, TPB, blocks, us, (double)n_rows * row_bytes / us / 1e3); }
     ROWSR(5, 256, 0) ROWSR(5, 256, 1) ROWSR(5, 256, 2) ROWSR(4, 256, 0) ROWSR(4, 256, 1) ROWSR(4, 256, 2) ROWSR(5, 256, 0) ROWSR(5, 256, 1) ROWSR(5, 256, 2)
+    for (int rep = 0; rep < 2; ++rep) {
+        { const int waves = n_rows / 4, blocks = (waves * 64 + 255) / 256;
+          float us = time_us([&] { flip ^= 1; hipLaunchKernelGGL((k_read_rows_pf<4>), dim3(blocks), dim3(256), 0, 0, (const char*)(flip ? a : b), n_rows, row_bytes, F, sink); }, 10);
+          printf("rows  R=4 pf=1 patch-fastest waves : %7.1f us  %7.1f GB/s\n", us, (double)n_rows * row_bytes / us / 1e3); }
+        { const int waves = n_rows / 2, blocks = (waves * 64 + 255) / 256;
+          float us = time_us([&] { flip ^= 1; hipLaunchKernelGGL((k_read_rows_pf<2>), dim3(blocks), dim3(256), 0, 0, (const char*)(flip ? a : b), n_rows, row_bytes, F, sink); }, 10);
+          printf("rows  R=2 pf=1 patch-fastest waves : %7.1f us  %7.1f GB/s\n", us, (double)n_rows * row_bytes / us / 1e3); }
+        { const int waves = n_rows / 8, blocks = (waves * 64 + 255) / 256;
+          float us = time_us([&] { flip ^= 1; hipLaunchKernelGGL((k_read_rows_pf<8>), dim3(blocks), dim3(256), 0, 0, (const char*)(flip ? a : b), n_rows, row_bytes, F, sink); }, 10);
+          printf("rows  R=8 pf=1 patch-fastest waves : %7.1f us  %7.1f GB/s\n", us, (double)n_rows * row_bytes / us / 1e3); }
+    }
     { const int P = n_rows / F;
       for (int tpb : {256, 512, 64}) {
         const int blocks = (n_rows * 64 + tpb - 1) / tpb;
