@@ -235,3 +235,23 @@ def test_very_long_sequence_exact(p_change, pre):
         assert (f.finish_merging, f.finish_pruning, f.sparsity_list) == (o.finish_merging, o.finish_pruning, o.sparsity_list)
         ho, hg = harness.layer_stub(ho, layer), harness.layer_stub(hg, layer)
     assert calls >= 1 and ho.shape[1] < L
+
+
+@pytest.mark.parametrize("frames", [370, 450, 570, 610, 810, 850, 930])
+def test_merge_workgroup_slot_counts(frames):
+    """The merge kernel sizes its workgroups per launch (a prime number of by-patch slots, ff_merge.hip
+    merge_slots): with one column group (d = 64) and 100 patches these lengths land on 19, 23, 29, 31, 41, 43
+    and 47 slots per workgroup - the windows of 64 slots are refilled at different points of the runs.
+    One merge call each, bit-exact against the oracle on the dyadic grid."""
+    P, d = 100, 64
+    h, pt = video_tokens(frames, P, d, p_change=0.25, sigma=0.3, seed=frames, pre=3, post=5, dtype=torch.bfloat16, grid=0.125)
+    L = h.shape[1]
+    o = orc.OracleFrameFusion(0.3, 0.6, 0.02)
+    o.prepare(pt.clone(), P, 3, 3 + frames * P - 1, frames * P, L)
+    f = ffa.FrameFusion(0.3, 0.6, 0.02)
+    f.prepare(pt.to(DEV), P, 3, 3 + frames * P - 1, frames * P, L)
+    ho, po, _ = o.forward(h, torch.arange(L)[None], None)
+    hg, pg, _ = f(h.to(DEV), torch.arange(L, device=DEV)[None], None)
+    assert ho.shape[1] < L
+    assert torch.equal(pg.cpu(), po)
+    assert same_bits(hg.cpu(), ho)
