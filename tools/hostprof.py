@@ -14,7 +14,7 @@ import framefusion_amd as ffa                                   # noqa: E402
 from framefusion_amd.synth import video_tokens, rotary_tables   # noqa: E402
 
 DEV = "cuda:0"
-F, P, d = 8, 64, 256
+F, P, d = (int(x) for x in (sys.argv[1:4] if len(sys.argv) > 3 else (8, 64, 256)))
 h, pt = video_tokens(F, P, d, p_change=0.3, seed=1, pre=4, post=4, dtype=torch.bfloat16, device=DEV)
 L = h.shape[1]
 cos, sin = rotary_tables(L, 64, torch.bfloat16, device=DEV)
@@ -40,4 +40,4 @@ pr.enable()
 for _ in range(n):
     call()
 pr.disable()
-pstats.Stats(pr).sort_stats("tottime").print_stats(14)
+pstats.Stats(pr).sort_stats("tottime").print_stats(22)
