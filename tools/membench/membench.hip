@@ -214,7 +214,7 @@ __global__ void k_copy_coltile(const char* __restrict__ src, char* __restrict__ 
         int rr[DEPTH];
 #pragma unroll
         for (int u = 0; u < DEPTH; ++u) {
-            int j = g0 + s0 + u; if (j >= n_rows) j = n_rows - 1;
+            int j = g0 + min(s0 + u, SLOTS - 1); if (j >= n_rows) j = n_rows - 1;      // (past the group's end: its last row again, an L2 hit)
             const int pp = j / F, f = j - pp * F;
             rr[u] = f * P + pp;
             const char* p = src + (size_t)rr[u] * 8192 + tile * 1024 + lane * 16;
@@ -310,7 +310,7 @@ int main(int argc, char** argv) {
         float us = time_us([&] { flip ^= 1; hipLaunchKernelGGL((k_copy_coltile<SLOTS, DEPTH, NT>), grid, dim3(256), 0, 0, (const char*)(flip ? a : b), c, n_rows, F, KEEP); }, 10); \
         const double moved = (double)n_rows * row_bytes * (1.0 + KEEP / 256.0); \
         printf("colt  slots=%2d depth=%d nt=%d keep=%3d/256 : %7.1f us  %7.1f GB/s (read + written bytes)\n", SLOTS, DEPTH, NT, KEEP, us, moved / us / 1e3); }
-    COLT(32, 4, 1, 77) COLT(32, 4, 0, 77) COLT(32, 8, 1, 77) COLT(16, 4, 1, 77) COLT(64, 4, 1, 77) COLT(32, 2, 1, 77)
+    COLT(37, 4, 1, 77) COLT(36, 4, 1, 77) COLT(19, 4, 1, 77) COLT(32, 4, 1, 77) COLT(32, 4, 0, 77) COLT(32, 8, 1, 77) COLT(16, 4, 1, 77) COLT(64, 4, 1, 77) COLT(32, 2, 1, 77)
     COPY(0, 256, 2048) COPY(1, 256, 2048) COPY(0, 77, 2048) COPY(1, 77, 2048) COPY(1, 77, 4096) COPY(1, 77, 1024) COPY(1, 128, 2048)
     return 0;
 }
