@@ -107,6 +107,35 @@ __global__ void k_read_rows_pf(const char* __restrict__ base, int n_rows, int ro
     if (acc.x == 0x12345678u && acc.y == 0x9abcdef0u) sink[0] = acc;
 }
 
+// pattern 1d: frame-major pairs with NP consecutive patches per wave: rows (f-1, p0..p0+NP-1) and (f, p0..p0+NP-1)
+template <int NP>
+__global__ void k_read_pairs_np(const char* __restrict__ base, int n_rows, int row_bytes, int P, uint4* __restrict__ sink) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int groups = P / NP, F = n_rows / P;
+    if (wave >= groups * (F - 1)) return;
+    const int g = wave % groups, f = wave / groups + 1;
+    const char* row[2 * NP];
+#pragma unroll
+    for (int r = 0; r < NP; ++r) {
+        row[r] = base + (size_t)((f - 1) * P + g * NP + r) * row_bytes;
+        row[NP + r] = base + (size_t)(f * P + g * NP + r) * row_bytes;
+    }
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    uint4 cur[2 * NP], nxt[2 * NP];
+    const int tiles = row_bytes >> 10;
+#pragma unroll
+    for (int r = 0; r < 2 * NP; ++r) cur[r] = *(const uint4*)(row[r] + lane * 16);
+    for (int t = 0; t < tiles; ++t) {
+        const int no = (t + 1 < tiles ? t + 1 : t) * 1024 + lane * 16;
+#pragma unroll
+        for (int r = 0; r < 2 * NP; ++r) nxt[r] = *(const uint4*)(row[r] + no);
+#pragma unroll
+        for (int r = 0; r < 2 * NP; ++r) { acc.x ^= cur[r].x; acc.y ^= cur[r].y; acc.z ^= cur[r].z; acc.w ^= cur[r].w; cur[r] = nxt[r]; }
+    }
+    if (acc.x == 0x12345678u && acc.y == 0x9abcdef0u) sink[0] = acc;
+}
+
 // pattern 1b: frame-major sweep: wave i reads row i and row i + P (its partner in the next frame), memory order:
 // every row is read twice, the second time P rows (4.7 MB) after the first - from the Infinity Cache, if it
 // delivers on top of the HBM stream
@@ -286,6 +315,15 @@ int main(int argc, char** argv) {
           float us = time_us([&] { flip ^= 1; hipLaunchKernelGGL((k_read_rows_pf<8>), dim3(blocks), dim3(256), 0, 0, (const char*)(flip ? a : b), n_rows, row_bytes, F, sink); }, 10);
           printf("rows  R=8 pf=1 patch-fastest waves : %7.1f us  %7.1f GB/s\n", us, (double)n_rows * row_bytes / us / 1e3); }
     }
+    { const int P = n_rows / F;
+      for (int rep = 0; rep < 2; ++rep) {
+        { const int waves = (P / 4) * (F - 1), blocks = (waves * 64 + 255) / 256;
+          float us = time_us([&] { flip ^= 1; hipLaunchKernelGGL((k_read_pairs_np<4>), dim3(blocks), dim3(256), 0, 0, (const char*)(flip ? a : b), n_rows, row_bytes, P, sink); }, 10);
+          printf("pairs frame-major 4 patches x 2 frames per wave : %7.1f us  %7.1f GB/s (unique bytes)\n", us, (double)n_rows * row_bytes / us / 1e3); }
+        { const int waves = (P / 2) * (F - 1), blocks = (waves * 64 + 255) / 256;
+          float us = time_us([&] { flip ^= 1; hipLaunchKernelGGL((k_read_pairs_np<2>), dim3(blocks), dim3(256), 0, 0, (const char*)(flip ? a : b), n_rows, row_bytes, P, sink); }, 10);
+          printf("pairs frame-major 2 patches x 2 frames per wave : %7.1f us  %7.1f GB/s (unique bytes)\n", us, (double)n_rows * row_bytes / us / 1e3); }
+      } }
     { const int P = n_rows / F;
       for (int tpb : {256, 512, 64}) {
         const int blocks = (n_rows * 64 + tpb - 1) / tpb;
