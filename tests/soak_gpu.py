@@ -3,6 +3,7 @@ tens of thousands of tokens, so that the merge kernel's workgroup slot counts (1
 by-patch runs are all in play - for as many seeds as the time budget allows.
 
     python tests/soak_gpu.py [seconds = 240] [first seed = 0]
+    python tests/soak_gpu.py importance [seconds = 120] [first seed = 0]     # K5: random head layouts vs the oracle
 """
 import sys
 import time
@@ -34,7 +35,51 @@ def draw(rng):
                 heads=int(rng.choice([1, 4])), num=int(rng.choice([1, 4])), seed=int(rng.integers(0, 1 << 30)))
 
 
+def importance_soak(budget, first):
+    """Grid-valued q / k (exact scores): every weight within 1 ulp of the oracle's, few of them different."""
+    t0, done, seed, worst, worst32 = time.time(), 0, first, 0.0, 0.0
+    while time.time() - t0 < budget:
+        rng = np.random.default_rng(90_000 + seed)
+        seed += 1
+        dt = DTYPES[int(rng.integers(0, 3))]
+        dh = int(rng.choice([16, 24, 32, 64, 128, 256]))
+        Hk = int(rng.choice([1, 2, 4, 8]))
+        H = Hk * int(rng.choice([1, 2, 4, 7, 8]))
+        num = int(rng.choice([1, 1, 4, 16]))
+        S = int(rng.choice([17, 255, 256, 257, 1000, 4097, 12000, 33000]))
+        if S <= num:
+            continue
+        g = torch.Generator().manual_seed(seed)
+        q = harness.snap(0.5 * torch.randn(1, H, num, dh, generator=g), dt)
+        k = harness.snap(0.5 * torch.randn(1, Hk, S, dh, generator=g), dt)
+        want = orc.last_query_attention(q, k, num=num, is_causal=True, enable_gqa=True)
+        got = ffa.scaled_dot_product_attention(q.to(DEV), k.to(DEV), None, num=num, is_causal=True, enable_gqa=True).cpu()
+        cfg = (dt, dh, H, Hk, num, S, seed - 1)
+
+        def close(a, b):
+            if dt == torch.float32:
+                return torch.allclose(a, b, rtol=2e-5, atol=1e-30)       # (33 k exponentials added in two orders)
+            # non-negative 16-bit values: neighbouring bit patterns are neighbouring values (subnormals included)
+            return int((a.view(torch.int16).int() - b.view(torch.int16).int()).abs().max()) <= 1
+
+        assert close(got, want), cfg
+        rate = float((got.float() != want.float()).float().mean())
+        # the two sides add the row's exponentials in different orders: a relative 1e-6 on the sum moves ~1e-6 / ulp of the
+        # probabilities across a rounding boundary (bf16 ulp 2^-8, fp16 2^-11); fp32 differs by a few ulps of exp everywhere
+        assert dt == torch.float32 or rate <= (2e-3 if dt == torch.bfloat16 else 1.6e-2), (cfg, rate)
+        worst = max(worst, rate if dt != torch.float32 else 0.0)
+        if dt == torch.float32:
+            worst32 = max(worst32, float(((got - want).abs() / want.abs().clamp_min(1e-30)).max()))
+        imp = ffa.last_query_importance(q.to(DEV), k.to(DEV), num=num, is_causal=True).reshape(-1).cpu()
+        assert close(imp, torch.mean(want, dim=(1, 2))[0]), cfg
+        done += 1
+    print(f"importance soak: {done} head layouts within 1 ulp (worst 16-bit mismatch rate {worst:.2e}, worst fp32 relative difference {worst32:.1e}), "
+          f"seeds {first}..{seed - 1}, {time.time() - t0:.0f} s")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "importance":
+        return importance_soak(float(sys.argv[2]) if len(sys.argv) > 2 else 120.0, int(sys.argv[3]) if len(sys.argv) > 3 else 0)
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     t0, done, skipped, seed = time.time(), 0, 0, first
