@@ -350,13 +350,17 @@ def test_importance_odd_head_size_general_path():
         assert torch.allclose(imp.reshape(-1).cpu().float(), torch.mean(want, dim=(1, 2))[0].float(), rtol=2 ** -7, atol=1e-30)
 
 
-def test_head_mean_exact():
-    w = harness.attention_stub(28, 4, 5000, torch.bfloat16)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("H,num,S", [(28, 4, 5000), (1, 1, 64), (3, 11, 4097), (8, 16, 1003), (65, 8, 777), (4, 1, 36898)])
+def test_head_mean_exact(dtype, H, num, S):
+    """1, 33, 112, 128 and 520 rows (one, several, and several groups of 32-row passes), lengths that are and are not
+    whole 16-byte words (the scalar-load path); the stub's sums are exact in fp32, so the mean is torch's to the bit."""
+    w = harness.attention_stub(H, num, S, dtype)
     want = torch.mean(w, dim=(1, 2))[0]
     lib = _lib.load()
     wd = dev(w)
-    imp = torch.empty(5000, dtype=torch.bfloat16, device=DEV)
-    _lib.check(lib.ff_head_mean(wd.data_ptr(), _lib.FF_BF16, 28, 4, 5000, imp.data_ptr(), _lib.stream_ptr()), "hm")
+    imp = torch.empty(S, dtype=dtype, device=DEV)
+    _lib.check(lib.ff_head_mean(wd.data_ptr(), _lib.DTYPE_CODE[dtype], H, num, S, imp.data_ptr(), _lib.stream_ptr()), "hm")
     assert same_bits(imp.cpu(), want)
 
 
