@@ -56,11 +56,11 @@ def importance_soak(budget, first):
         got = ffa.scaled_dot_product_attention(q.to(DEV), k.to(DEV), None, num=num, is_causal=True, enable_gqa=True).cpu()
         cfg = (dt, dh, H, Hk, num, S, seed - 1)
 
-        def close(a, b):
+        def close(a, b, ulps=1):
             if dt == torch.float32:
-                return torch.allclose(a, b, rtol=2e-5, atol=1e-30)       # (33 k exponentials added in two orders)
+                return torch.allclose(a, b, rtol=2e-5 * ulps, atol=1e-30)       # (33 k exponentials added in two orders)
             # non-negative 16-bit values: neighbouring bit patterns are neighbouring values (subnormals included)
-            return int((a.view(torch.int16).int() - b.view(torch.int16).int()).abs().max()) <= 1
+            return int((a.view(torch.int16).int() - b.view(torch.int16).int()).abs().max()) <= ulps
 
         assert close(got, want), cfg
         rate = float((got.float() != want.float()).float().mean())
@@ -71,7 +71,10 @@ def importance_soak(budget, first):
         if dt == torch.float32:
             worst32 = max(worst32, float(((got - want).abs() / want.abs().clamp_min(1e-30)).max()))
         imp = ffa.last_query_importance(q.to(DEV), k.to(DEV), num=num, is_causal=True).reshape(-1).cpu()
-        assert close(imp, torch.mean(want, dim=(1, 2))[0]), cfg
+        # the fused importance is the head mean of THIS build's weights (1 ulp: the fp32 order of the mean); against the
+        # oracle's it inherits their 1-ulp differences, which can add up to 2 across a binade boundary
+        assert close(imp, torch.mean(got, dim=(1, 2))[0]), cfg
+        assert close(imp, torch.mean(want, dim=(1, 2))[0], ulps=2), cfg
         done += 1
     print(f"importance soak: {done} head layouts within 1 ulp (worst 16-bit mismatch rate {worst:.2e}, worst fp32 relative difference {worst32:.1e}), "
           f"seeds {first}..{seed - 1}, {time.time() - t0:.0f} s")
