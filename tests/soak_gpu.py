@@ -4,6 +4,7 @@ by-patch runs are all in play - for as many seeds as the time budget allows.
 
     python tests/soak_gpu.py [seconds = 240] [first seed = 0]
     python tests/soak_gpu.py importance [seconds = 120] [first seed = 0]     # K5: random head layouts vs the oracle
+    python tests/soak_gpu.py residual [seconds = 120] [first seed = 0]       # call B fused with the residual add
 """
 import sys
 import time
@@ -80,7 +81,42 @@ def importance_soak(budget, first):
           f"seeds {first}..{seed - 1}, {time.time() - t0:.0f} s")
 
 
+def residual_soak(budget, first):
+    """forward_residual(residual, attn_out) against the oracle fed with the eager sum: one merge call, then (when the
+    state machine asks for it) the prune call, large shapes, bit for bit."""
+    from tests.test_gpu_residual import split
+    t0, done, seed = time.time(), 0, first
+    while time.time() - t0 < budget:
+        rng = np.random.default_rng(130_000 + seed)
+        seed += 1
+        c = draw(rng)
+        h, pt = video_tokens(c["F"], c["P"], c["d"], p_change=c["p_change"], sigma=0.3, sigma_hi=1.4, seed=c["seed"],
+                             pre=c["pre"], post=c["post"], dtype=c["dt"], grid=0.125, clip=2.0)
+        L, nvis = h.shape[1], c["F"] * c["P"]
+        o = orc.OracleFrameFusion(c["cost"], c["thr"], c["lb"])
+        f = ffa.FrameFusion(c["cost"], c["thr"], c["lb"])
+        o.prepare(pt.clone(), c["P"], c["pre"], c["pre"] + nvis, nvis, L)
+        f.prepare(pt.to(DEV), c["P"], c["pre"], c["pre"] + nvis, nvis, L)
+        ho, po, hg, pg = h, torch.arange(L)[None], None, torch.arange(L, device=DEV)[None]
+        for layer in range(3):
+            res, attn = split(ho, c["seed"] % 1000 + layer)
+            w = harness.attention_stub(c["heads"], c["num"], ho.shape[1], c["dt"])
+            need_w = o.finish_merging and not o.finish_pruning
+            try:
+                ho, po, _ = o.forward(res + attn, po, None, w if need_w else None)
+            except ValueError:
+                break
+            hg, pg, _ = f.forward_residual(res.to(DEV), attn.to(DEV), pg, None, w.to(DEV) if need_w else None)
+            assert (f.finish_merging, f.finish_pruning, f.sparsity_list) == (o.finish_merging, o.finish_pruning, o.sparsity_list), (c, layer)
+            assert torch.equal(pg.cpu(), po) and same_bits(hg.cpu(), ho), (c, layer)
+            ho = harness.layer_stub(ho, layer)
+        done += 1
+    print(f"residual soak: {done} prefills (up to 3 fused calls each) bit-exact, seeds {first}..{seed - 1}, {time.time() - t0:.0f} s")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "residual":
+        return residual_soak(float(sys.argv[2]) if len(sys.argv) > 2 else 120.0, int(sys.argv[3]) if len(sys.argv) > 3 else 0)
     if len(sys.argv) > 1 and sys.argv[1] == "importance":
         return importance_soak(float(sys.argv[2]) if len(sys.argv) > 2 else 120.0, int(sys.argv[3]) if len(sys.argv) > 3 else 0)
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
