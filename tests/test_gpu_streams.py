@@ -1,0 +1,82 @@
+"""GPU: every launch of a call goes to the caller's CURRENT stream (SURVEY.md §8b "all work on the caller's current
+stream"; the reference's demo runs two model replicas from two threads, llava_video_compare.py:217-223, never sharing
+an instance).  A prefill on a side stream, and two instances interleaved on two side streams, against the oracle."""
+import pytest
+import torch
+
+import framefusion_amd as ffa
+from framefusion_amd.synth import video_tokens, rotary_tables
+from oracle import ff_oracle as orc
+from tests import harness
+from tests.conftest import same_bits
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def sample(seed, p_change):
+    F, P, d, pre, post = 20, 64, 256, 4, 6
+    h, pt = video_tokens(F, P, d, p_change=p_change, sigma=0.3, sigma_hi=1.4, seed=seed, pre=pre, post=post,
+                         dtype=torch.bfloat16, grid=0.125)
+    return h, pt, P, pre, F * P
+
+
+def oracle_cascade(h, pt, P, pre, nvis, layers=3):
+    want, _ = harness.run_cascade(orc.OracleFrameFusion(0.3, 0.6, 0.1), h.clone(), pt.clone(), P,
+                                  rotary_tables(h.shape[1], 16, torch.bfloat16), None, layers, 4, 1, start=pre, n_visual=nvis)
+    return want
+
+
+def check(got, want):
+    assert len(got) == len(want)
+    for a, b in zip(got, want):
+        assert (a["tag"], a["length"], a["finish_merging"], a["finish_pruning"], a["sparsity"]) == \
+               (b["tag"], b["length"], b["finish_merging"], b["finish_pruning"], b["sparsity"])
+        assert same_bits(a["hidden"].cpu(), b["hidden"])
+
+
+def test_prefill_on_a_side_stream():
+    h, pt, P, pre, nvis = sample(3, 0.5)
+    want = oracle_cascade(h, pt, P, pre, nvis)
+    side = torch.cuda.Stream(device=DEV)
+    hd, ptd = h.to(DEV), pt.to(DEV)
+    pe = [t.to(DEV) for t in rotary_tables(h.shape[1], 16, torch.bfloat16)]
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        got, _ = harness.run_cascade(ffa.FrameFusion(0.3, 0.6, 0.1), hd, ptd, P, pe, None, 3, 4, 1, start=pre, n_visual=nvis)
+    side.synchronize()
+    check(got, want)
+
+
+def test_two_instances_on_two_streams_interleaved():
+    """Call by call alternation between two prefills that live on different streams: each instance keeps its own
+    scratch, select tables and result block, so nothing of one shows up in the other."""
+    sa, sb = sample(5, 0.2), sample(6, 0.6)
+    wa, wb = oracle_cascade(*sa, layers=2), oracle_cascade(*sb, layers=2)
+    streams = [torch.cuda.Stream(device=DEV), torch.cuda.Stream(device=DEV)]
+    ffs = [ffa.FrameFusion(0.3, 0.6, 0.1), ffa.FrameFusion(0.3, 0.6, 0.1)]
+    state = []
+    for (h, pt, P, pre, nvis), f in zip((sa, sb), ffs):
+        L = h.shape[1]
+        f.prepare(pt.to(DEV), P, pre, pre + nvis, nvis, L)
+        state.append(dict(h=h.to(DEV), pe=[t.to(DEV) for t in rotary_tables(L, 16, torch.bfloat16)], recs=[]))
+    torch.cuda.synchronize()
+    # the harness protocol by hand: call A, then per layer the stub + call B (with weights when the hook asks for them)
+    for step in range(3):
+        for x in (0, 1):
+            f, st = ffs[x], state[x]
+            with torch.cuda.stream(streams[x]):
+                if step > 0:
+                    st["h"] = harness.layer_stub(st["h"], step - 1)
+                w = None
+                if f.finish_merging and not f.finish_pruning:
+                    w = harness.attention_stub(4, 1, st["h"].shape[1], torch.bfloat16, device=DEV)
+                st["h"], st["pe"], _ = f(st["h"], st["pe"], None, w)
+                st["recs"].append((st["h"].shape[1], f.finish_merging, f.finish_pruning, st["h"]))
+    for s in streams:
+        s.synchronize()
+    for recs, want in ((state[0]["recs"], wa), (state[1]["recs"], wb)):
+        assert len(recs) == len(want)
+        for (length, fm, fp, hid), b in zip(recs, want):
+            assert (length, fm, fp) == (b["length"], b["finish_merging"], b["finish_pruning"])
+            assert same_bits(hid.cpu(), b["hidden"])
