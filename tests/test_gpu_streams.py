@@ -80,3 +80,36 @@ def test_two_instances_on_two_streams_interleaved():
         for (length, fm, fp, hid), b in zip(recs, want):
             assert (length, fm, fp) == (b["length"], b["finish_merging"], b["finish_pruning"])
             assert same_bits(hid.cpu(), b["hidden"])
+
+
+def test_two_threads_two_instances():
+    """The reference's demo shape (llava_video_compare.py:217-223, 310-313): two Python threads, each with its own
+    instance (and here its own stream on the one GPU).  The result-block poll of one thread must not starve the other."""
+    import threading
+    samples = [sample(8, 0.2), sample(9, 0.5)]
+    wants = [oracle_cascade(*s) for s in samples]
+    results, errors = [None, None], []
+
+    def work(x):
+        try:
+            h, pt, P, pre, nvis = samples[x]
+            stream = torch.cuda.Stream(device=DEV)
+            with torch.cuda.stream(stream):
+                pe = [t.to(DEV) for t in rotary_tables(h.shape[1], 16, torch.bfloat16)]
+                for _ in range(5):                                   # several prefills per thread
+                    got, _ = harness.run_cascade(ffa.FrameFusion(0.3, 0.6, 0.1), h.to(DEV), pt.to(DEV), P, list(pe), None, 3, 4, 1,
+                                                 start=pre, n_visual=nvis)
+            stream.synchronize()
+            results[x] = got
+        except Exception as e:                                       # noqa: BLE001 - reported by the main thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(x,)) for x in (0, 1)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+        assert not t.is_alive(), "a worker thread hangs"
+    assert not errors, errors
+    for got, want in zip(results, wants):
+        check(got, want)
