@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import struct
 import subprocess
 
 import torch  # noqa: F401  (must precede the CDLL below)
@@ -28,11 +29,65 @@ STAT_ERROR = 11
 ERR_BIT_BARRIER, ERR_BIT_LAYOUT = 1, 2
 STAT_WORDS = 32
 MAX_AUX = 4
-ABI_VERSION = 6
+ABI_VERSION = 7
+ERR_DEVICE, ERR_STATE = -5, -6
 
 
 class FFAux(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("row_bytes", C.c_int64), ("outer", C.c_int64)]
+
+
+class FFCtx(C.Structure):
+    """ff_ctx_t: names the per-sample scratch + the state the library keeps between the calls of a prefill."""
+    _fields_ = [("cap", C.c_int64), ("order", C.c_void_p), ("order_next", C.c_void_p), ("inv", C.c_void_p),
+                ("inv_next", C.c_void_p), ("sim", C.c_void_p), ("member", C.c_void_p), ("dst", C.c_void_p),
+                ("keep", C.c_void_p), ("stats", C.c_void_p), ("stats_host", C.c_void_p), ("ws", C.c_void_p),
+                ("ws_bytes", C.c_size_t),
+                ("seq", C.c_int64), ("order_len", C.c_int64), ("dirty", C.c_int64), ("in_flight", C.c_int64),
+                ("swaps", C.c_int64)]
+
+
+class FFMergeCall(C.Structure):
+    """ff_merge_call_t (every member 8 bytes wide: filled with ONE struct.pack_into per call, MERGE_CALL_HEAD)."""
+    _fields_ = [("hidden", C.c_void_p), ("addend", C.c_void_p), ("hidden_out", C.c_void_p), ("patch_type", C.c_void_p),
+                ("dtype", C.c_int64), ("L", C.c_int64), ("d", C.c_int64), ("L_cap", C.c_int64), ("patch_num", C.c_int64),
+                ("order_valid", C.c_int64),
+                ("threshold", C.c_double), ("sub", C.c_double), ("ratio_lb", C.c_double),
+                ("force_k", C.c_int64), ("fold", C.c_int64),
+                ("hint_pre", C.c_int64), ("hint_frames", C.c_int64), ("stream", C.c_void_p), ("n_aux", C.c_int64),
+                ("aux", FFAux * MAX_AUX),
+                ("mask", C.c_void_p), ("mask_out", C.c_void_p), ("mask_elem_bytes", C.c_int64)]
+
+
+# head of ff_merge_call_t up to and including n_aux; aux entries (4 x 8 bytes each) and the mask triple follow
+MERGE_CALL_HEAD = struct.Struct("=4Q6q3d4qQq")
+MERGE_CALL_AUX_OFFSET = MERGE_CALL_HEAD.size
+AUX_ENTRY = struct.Struct("=2Q2q")
+MERGE_CALL_MASK_OFFSET = MERGE_CALL_AUX_OFFSET + MAX_AUX * AUX_ENTRY.size
+MASK_TRIPLE = struct.Struct("=2Qq")
+
+
+class FFMergeResult(C.Structure):
+    _fields_ = [("nv", C.c_int64), ("ftn", C.c_int64), ("count", C.c_int64), ("branch", C.c_int64), ("k", C.c_int64),
+                ("l_out", C.c_int64), ("error", C.c_int64), ("unhinted", C.c_int64), ("wait_ns", C.c_int64)]
+
+
+MERGE_RESULT = struct.Struct("=9q")
+
+
+class FFPruneCall(C.Structure):
+    """ff_prune_call_t."""
+    _fields_ = [("hidden", C.c_void_p), ("addend", C.c_void_p), ("hidden_out", C.c_void_p), ("attn_w", C.c_void_p),
+                ("dtype", C.c_int64), ("S", C.c_int64), ("d", C.c_int64), ("L_cap", C.c_int64), ("w_dtype", C.c_int64),
+                ("H", C.c_int64), ("num", C.c_int64), ("tables_ready", C.c_int64),
+                ("start", C.c_int64), ("n_img", C.c_int64), ("k", C.c_int64), ("stream", C.c_void_p), ("n_aux", C.c_int64),
+                ("aux", FFAux * MAX_AUX),
+                ("mask", C.c_void_p), ("mask_out", C.c_void_p), ("mask_elem_bytes", C.c_int64)]
+
+
+PRUNE_CALL_HEAD = struct.Struct("=4Q11qQq")
+PRUNE_CALL_AUX_OFFSET = PRUNE_CALL_HEAD.size
+PRUNE_CALL_MASK_OFFSET = PRUNE_CALL_AUX_OFFSET + MAX_AUX * AUX_ENTRY.size
 
 
 class FFSegment(C.Structure):
@@ -74,6 +129,13 @@ PROTOTYPES = {
     "ff_token_span": (_i32, [_vp, _i64, _i64, _vp, _vp]),
     "ff_fill_patch_type": (_i32, [_vp, _i64, C.POINTER(FFSegment), _i64, _vp]),
     "ff_patch_type_from_mask": (_i32, [_vp, _i64, _i64, _vp, _vp, _vp]),
+    "ff_ctx_merge_begin": (_i32, [_vp, _vp]),
+    "ff_ctx_merge_finish": (_i32, [_vp, _vp, _vp]),
+    "ff_ctx_merge": (_i32, [_vp, _vp, _vp]),
+    "ff_ctx_prune": (_i32, [_vp, _vp]),
+    "ff_ctx_reset": (_i32, [_vp, _vp]),
+    "ff_ctx_expect_tables": (None, [_vp]),
+    "ff_abi_sizeof": (_sz, [_i32]),
     "ff_merge_step": (_i32, [_vp, _vp, _vp, _i32, _i64, _i64, _i64, _vp, _i64, _i32, _f64, _f64, _f64, _vp, _vp, _vp, _vp,
                              _vp, _vp, _vp, _vp, _i64, C.POINTER(FFAux), _i32, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
 }
@@ -117,6 +179,10 @@ def load():
     got = lib.ff_abi_version()
     if got != ABI_VERSION:
         raise FrameFusionHipError(f"ABI mismatch: library {got}, binding {ABI_VERSION}")
+    for which, cls in enumerate((FFCtx, FFMergeCall, FFMergeResult, FFPruneCall, FFAux)):
+        if lib.ff_abi_sizeof(which) != C.sizeof(cls):
+            raise FrameFusionHipError(f"ABI mismatch: sizeof({cls.__name__}) is {C.sizeof(cls)} here, "
+                                      f"{lib.ff_abi_sizeof(which)} in the library")
     _lib = lib
     return lib
 

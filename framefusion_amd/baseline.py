@@ -13,7 +13,7 @@ Differences from FrameFusion.forward (main.py): k is given instead of derived fr
 a budget, and a run is averaged in fp32 with one rounding (``FF_FOLD_MEAN``) instead of the
 per-add rounding of ``index_add_``.  Everything else - K0 order (maintained across layers), K1
 similarities, the radix select, the scan, K4 with its aux gathers - is shared
-(``ff_merge_begin`` + ``ff_merge_finish_topk``).  top-k ties go to the lowest by-patch index, as in
+(``ff_ctx_merge_begin`` / ``ff_ctx_merge_finish`` with ``force_k`` and ``FF_FOLD_MEAN``).  top-k ties go to the lowest by-patch index, as in
 the main path.
 """
 from __future__ import annotations
@@ -24,8 +24,8 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import FFAux, FrameFusionHipError
-from .main import FrameFusion, TEXT_TOKEN, _Scratch, _dtype_code
+from ._lib import FrameFusionHipError
+from .main import FrameFusion, TEXT_TOKEN, _PACK_I64, _PACK_PTR, _Scratch, _dtype_code, _fail
 
 
 def compute_density_overhead(sparsity_list) -> tuple:
@@ -68,20 +68,20 @@ class FixedSparsityMerging:
         self.patch_type = patch_type
         self.patch_num = patch_num
         self._ftn = None
-        for s in self._scratch.values():
-            s.order_valid_for = None
 
-    def _scratch_for(self, device, L, dtype) -> _Scratch:
+    def _scratch_for(self, device, L):
         key = (device.type, device.index)
         s = self._scratch.get(key)
         if s is None:
             s = self._scratch[key] = _Scratch(device)
-        cur = torch.cuda.current_stream(device)
-        last = getattr(s, "last_stream", None)
-        if last is not None and last != cur:
-            cur.wait_stream(last)
-        s.last_stream = cur
-        return s.ensure(L, dtype)
+        ptr = _lib.stream_ptr()
+        if s.last_stream_ptr != ptr:
+            cur = torch.cuda.current_stream(device)
+            last = s.last_stream
+            if last is not None and last != cur:
+                cur.wait_stream(last)
+            s.last_stream, s.last_stream_ptr = cur, ptr
+        return s.ensure(L), ptr
 
     def merge(self, layer_idx: int, hidden_states: torch.Tensor, position_embeddings: Optional[List[torch.Tensor]] = None,
               residual: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor], Optional[torch.Tensor]]:
@@ -114,70 +114,59 @@ class FixedSparsityMerging:
         lib = _lib.load()
         code = _dtype_code(hidden_states)
         hidden = hidden_states if hidden_states.is_contiguous() else hidden_states.contiguous()
-        sc = self._scratch_for(device, L, dtype)
-        stream = _lib.stream_ptr()
-        order_valid = 1 if sc.order_valid_for == (self._ptype_gen, L) else 0
-        if sc.dirty:
-            sc.ws.zero_()
-            sc.stats.zero_()
-            sc.dirty = False
-        sc.seq += 1
-        seq = sc.seq
-        sc.dirty = True
-        _lib.check(lib.ff_merge_begin(hidden.data_ptr(), None, code, L, d, ptype.data_ptr(), int(self.patch_num), order_valid,
-                                      0.0, sc.order.data_ptr(), sc.inv.data_ptr(), sc.sim32.data_ptr(), sc.stats.data_ptr(),
-                                      seq, 0, 0,
-                                      sc.ws.data_ptr(), sc.ws_bytes, stream), "ff_merge_begin")
+        sc, stream = self._scratch_for(device, L)
+        order_valid = 1 if sc.order_gen == self._ptype_gen else 0
+        call = sc.call
+        _lib.MERGE_CALL_HEAD.pack_into(call, 0, hidden.data_ptr(), 0, 0, ptype.data_ptr(), code, L, d, L, int(self.patch_num),
+                                       order_valid, 0.0, 0.0, 0.0, prune_num, _lib.FOLD_MEAN, 0, 0, stream or 0, 0)
+        sc.order_gen = None
+        rc = lib.ff_ctx_merge_begin(sc.ctx_ptr, sc.call_ptr)
+        if rc:
+            _fail(rc, "merge")
 
         out = torch.empty(1, L, d, dtype=dtype, device=device)
         ptype_out = torch.empty(1, L, dtype=torch.int64, device=device)
-        aux = (FFAux * _lib.MAX_AUX)()
-        n_aux = FrameFusion._fill_aux(aux, 0, [ptype.view(1, L)], [ptype_out], L)
+        srcs, outs = [ptype.view(1, L)], [ptype_out]
         rebuild = None
         if position_embeddings is not None:
             if type(position_embeddings) != list:
                 raise NotImplementedError("position_embeddings must be the mutable [cos, sin] list (:1273)")
-            srcs, outs, rebuild = FrameFusion._aux_for_positions(position_embeddings, L, L)
-            n_aux = FrameFusion._fill_aux(aux, n_aux, srcs, outs, L)
+            s2, o2, rebuild = FrameFusion._aux_for_positions(position_embeddings, L, L)
+            srcs += s2
+            outs += o2
         res_out = None
         if residual is not None:
             if residual.shape != hidden_states.shape or residual.device != device:
                 raise FrameFusionHipError("residual must have the shape and device of hidden_states")
             res = residual.contiguous()
             res_out = torch.empty_like(res)
-            n_aux = FrameFusion._fill_aux(aux, n_aux, [res], [res_out], L)
-        _lib.check(lib.ff_merge_finish_topk(hidden.data_ptr(), out.data_ptr(), code, L, d, L, prune_num, _lib.FOLD_MEAN,
-                                            sc.order.data_ptr(), sc.inv.data_ptr(), sc.sim32.data_ptr(),
-                                            sc.member.data_ptr(), sc.dst.data_ptr(), sc.keep.data_ptr(),
-                                            sc.stats.data_ptr(), sc.stats_host_ptr, seq, aux, n_aux,
-                                            sc.order_next.data_ptr(), sc.inv_next.data_ptr(),
-                                            sc.ws.data_ptr(), sc.ws_bytes, stream), "ff_merge_finish_topk")
-        sc.dirty = False
+            srcs.append(res)
+            outs.append(res_out)
+        n_aux = sc.put_aux(call, _lib.MERGE_CALL_AUX_OFFSET, zip(srcs, outs), L)
+        _PACK_PTR.pack_into(call, 16, out.data_ptr())
+        _PACK_I64.pack_into(call, _lib.MERGE_CALL_AUX_OFFSET - 8, n_aux)
+        _lib.MASK_TRIPLE.pack_into(call, _lib.MERGE_CALL_MASK_OFFSET, 0, 0, 0)
+        rc = lib.ff_ctx_merge_finish(sc.ctx_ptr, sc.call_ptr, sc.res_ptr)
+        nv, _ftn, _count, _branch, k_used, L_out, err, _unhinted, _wait = _lib.MERGE_RESULT.unpack_from(sc.res)
+        if rc:
+            _fail(rc, "merge", err)
+        sc.sync_views()
         token_mask = sc.keep[:L].bool().view(1, L)          # a copy: the scratch is reused by the next layer
-
-        st = sc.wait_stats(seq)
-        if int(st[_lib.STAT_ERROR]):
-            sc.dirty = True
-            sc.order_valid_for = None
-            raise FrameFusionHipError(f"device-side check failed in the merge call (error bits {int(st[_lib.STAT_ERROR]):#x})")
-        nv, L_out = int(st[_lib.STAT_NV]), int(st[_lib.STAT_LOUT])
         if nv <= 0:
             raise ValueError("No token in this patch")                               # :982-983
         if L_out == L:
             # the forced top-k folded nothing (its only candidate was by-patch slot 0, which has no
             # predecessor): the merge kernel wrote nothing - the caller's tensors ARE the result and the
             # by-patch order in the scratch still describes them
-            self.last_call = dict(kind="merge", L_in=L, L_out=L, nv=nv, ftn=ftn, k=int(st[_lib.STAT_K]),
+            self.last_call = dict(kind="merge", L_in=L, L_out=L, nv=nv, ftn=ftn, k=k_used,
                                   scratch=sc, dtype=dtype, order=sc.order)
-            sc.order_valid_for = (self._ptype_gen, L)
+            sc.order_gen = self._ptype_gen
             return hidden_states, token_mask, residual
         self._ftn = ftn - (L - L_out)                       # every dropped token was a visual one
+        self.last_call = dict(kind="merge", L_in=L, L_out=L_out, nv=nv, ftn=ftn, k=k_used,
+                              scratch=sc, dtype=dtype, order=sc.order_next)
         self.patch_type = ptype_out[:, :L_out]                                       # :1051
-        self.last_call = dict(kind="merge", L_in=L, L_out=L_out, nv=nv, ftn=ftn, k=int(st[_lib.STAT_K]),
-                              scratch=sc, dtype=dtype, order=sc.order)
-        sc.order, sc.order_next = sc.order_next, sc.order
-        sc.inv, sc.inv_next = sc.inv_next, sc.inv
-        sc.order_valid_for = (self._ptype_gen, L_out)
+        sc.order_gen = self._ptype_gen
         if rebuild is not None:
             rebuild(L_out)
         return out[:, :L_out], token_mask, (res_out[:, :L_out] if res_out is not None else None)

@@ -38,6 +38,8 @@ extern "C" const char* ff_error_string(int code) {
         case FF_ERR_ALIGN: return "pointer or row size not 16-byte aligned";
         case FF_ERR_UNSUPPORTED: return "size outside the supported range";
         case FF_ERR_WORKSPACE: return "workspace too small (see ff_workspace_bytes)";
+        case FF_ERR_DEVICE: return "a device-side check failed or the result block was never published";
+        case FF_ERR_STATE: return "context call out of order (finish without begin)";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
     }
 }
@@ -183,4 +185,197 @@ extern "C" int ff_prune_step(const void* hidden, const void* addend, void* hidde
     return ff::launch_merge_compact(hidden, addend, hidden_out, dtype, S, d, L_cap, nullptr, member, FF_FOLD_DROP, dst, keep,
                                     aux_host, n_aux, nullptr, nullptr, nullptr, st, false, za, zab, have_tables ? imp : nullptr,
                                     S, w_dtype, ff::ws_t16_end(ws, ws_bytes));
+}
+
+// ---- call context (ABI v7): one host call per FrameFusion.forward call ------------------------------------
+#include <time.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+static inline void cpu_relax() { _mm_pause(); }
+#else
+static inline void cpu_relax() {}
+#endif
+
+static inline int64_t now_ns() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (int64_t)ts.tv_sec * 1000000000ll + ts.tv_nsec;
+}
+
+static int ctx_check(const ff_ctx_t* c, int64_t L) {
+    if (!c || !c->order || !c->order_next || !c->inv || !c->inv_next || !c->sim || !c->member || !c->dst || !c->keep ||
+        !c->stats || !c->stats_host || !c->ws)
+        return FF_ERR_ARG;
+    if (L < 0 || L > c->cap) return FF_ERR_ARG;
+    if (c->ws_bytes < ff_workspace_bytes(c->cap, 1)) return FF_ERR_WORKSPACE;
+    return FF_OK;
+}
+
+// restore the workspace protocol after a call that died half-way (zeroed tables, zeroed stats)
+static int ctx_clean(ff_ctx_t* c, hipStream_t st) {
+    if (!c->dirty) return FF_OK;
+    hipError_t e = hipMemsetAsync(c->ws, 0, c->ws_bytes, st);
+    if (e == hipSuccess) e = hipMemsetAsync(c->stats, 0, FF_STAT_WORDS * sizeof(int64_t), st);
+    if (e != hipSuccess) return (int)e;
+    c->dirty = 0;
+    c->order_len = 0;          // stats[NV] / stats[FTN] went with the reset: K0 (or the hinted K1) rebuilds them
+    return FF_OK;
+}
+
+extern "C" int ff_ctx_reset(ff_ctx_t* c, ff_stream_t stream) {
+    if (!c) return FF_ERR_ARG;
+    c->order_len = 0;
+    c->in_flight = 0;
+    return ctx_clean(c, (hipStream_t)stream);
+}
+
+extern "C" size_t ff_abi_sizeof(int which) {
+    switch (which) {
+        case 0: return sizeof(ff_ctx_t);
+        case 1: return sizeof(ff_merge_call_t);
+        case 2: return sizeof(ff_merge_result_t);
+        case 3: return sizeof(ff_prune_call_t);
+        case 4: return sizeof(ff_aux_t);
+        default: return 0;
+    }
+}
+
+extern "C" void ff_ctx_expect_tables(ff_ctx_t* c) {
+    if (c) c->dirty = 1;
+}
+
+static int ctx_begin(ff_ctx_t* c, const ff_merge_call_t* a, bool hinted) {
+    hipStream_t st = (hipStream_t)a->stream;
+    int rc = ctx_clean(c, st);
+    if (rc) return rc;
+    const int order_valid = (a->order_valid && c->order_len == a->L) ? 1 : 0;
+    c->seq += 1;
+    c->dirty = 1;                // until finish has enqueued the kernel that clears the select tables
+    c->in_flight = 1;
+    return ff_merge_begin(a->hidden, a->addend, (int)a->dtype, a->L, a->d, a->patch_type, a->patch_num, order_valid,
+                          a->threshold, c->order, c->inv, c->sim, c->stats, c->seq, a->hint_pre,
+                          hinted ? a->hint_frames : 0, c->ws, c->ws_bytes, a->stream);
+}
+
+extern "C" int ff_ctx_merge_begin(ff_ctx_t* c, const ff_merge_call_t* a) {
+    if (!a) return FF_ERR_ARG;
+    int rc = ctx_check(c, a->L);
+    if (rc) return rc;
+    if (a->L == 0) return FF_ERR_ARG;
+    return ctx_begin(c, a, true);
+}
+
+// spin on the pinned result block; no HIP call on the fast path
+static int ctx_wait(ff_ctx_t* c, hipStream_t st, int64_t* waited_ns) {
+    volatile int64_t* host = c->stats_host;
+    const int64_t seq = c->seq;
+    const int64_t t0 = now_ns();
+    int64_t next_query = t0 + 1000000;               // first look at the stream after 1 ms
+    int rc = FF_OK;
+    for (uint32_t spins = 0;; ++spins) {
+        if (__atomic_load_n(&host[FF_STAT_SEQ], __ATOMIC_ACQUIRE) == seq) break;
+        cpu_relax();
+        if ((spins & 255u) != 255u) continue;
+        const int64_t t = now_ns();
+        if (t < next_query) continue;
+        next_query = t + 50000;
+        hipError_t e = hipStreamQuery(st);
+        if (e == hipErrorNotReady) continue;
+        // the stream drained (or failed): the block is there now or never will be
+        if (__atomic_load_n(&host[FF_STAT_SEQ], __ATOMIC_ACQUIRE) == seq) break;
+        rc = e == hipSuccess ? FF_ERR_DEVICE : (int)e;
+        break;
+    }
+    *waited_ns = now_ns() - t0;
+    return rc;
+}
+
+static int ctx_finish_enqueue(ff_ctx_t* c, const ff_merge_call_t* a) {
+    if (a->fold != FF_FOLD_SEQUENTIAL && a->fold != FF_FOLD_MEAN) return FF_ERR_ARG;
+    int rc = merge_finish(a->hidden, a->addend, a->hidden_out, (int)a->dtype, a->L, a->d, a->L_cap, a->threshold, a->sub,
+                          a->ratio_lb, a->force_k < 0 ? -1 : (long long)a->force_k, (int)a->fold, c->order, c->inv, c->sim,
+                          c->member, c->dst, c->keep, c->stats, c->stats_host, c->seq, a->aux, (int)a->n_aux, c->order_next,
+                          c->inv_next, c->ws, c->ws_bytes, a->stream);
+    if (rc) return rc;
+    c->dirty = 0;
+    if (a->mask) rc = ff_gather_mask(a->mask, a->mask_out, a->mask_elem_bytes, a->L, a->L_cap, c->dst, a->stream);
+    return rc;
+}
+
+extern "C" int ff_ctx_merge_finish(ff_ctx_t* c, const ff_merge_call_t* a, ff_merge_result_t* r) {
+    if (!a || !r) return FF_ERR_ARG;
+    int rc = ctx_check(c, a->L);
+    if (rc) return rc;
+    if (!c->in_flight) return FF_ERR_STATE;
+    if (a->mask && !a->mask_out) return FF_ERR_ARG;
+    c->in_flight = 0;
+    hipStream_t st = (hipStream_t)a->stream;
+    r->unhinted = 0;
+    r->wait_ns = 0;
+    for (int attempt = 0;; ++attempt) {
+        rc = ctx_finish_enqueue(c, a);
+        if (rc) { c->dirty = 1; c->order_len = 0; return rc; }
+        int64_t waited = 0;
+        rc = ctx_wait(c, st, &waited);
+        r->wait_ns += waited;
+        if (rc) { c->dirty = 1; c->order_len = 0; r->error = 0; return rc; }
+        const int64_t* h = c->stats_host;
+        const int64_t err = h[FF_STAT_ERROR];
+        r->error = err;
+        if ((err & FF_ERR_BIT_LAYOUT) && !(err & ~(int64_t)FF_ERR_BIT_LAYOUT) && attempt == 0) {
+            // patch_type is not the frame-major layout the hint described: everything this call enqueued is
+            // void - reset the workspace and repeat it through K0
+            c->dirty = 1;
+            rc = ctx_begin(c, a, false);
+            c->in_flight = 0;
+            if (rc) { c->dirty = 1; c->order_len = 0; return rc; }
+            r->unhinted = 1;
+            continue;
+        }
+        if (err) { c->dirty = 1; c->order_len = 0; return FF_ERR_DEVICE; }
+        r->nv = h[FF_STAT_NV];
+        r->ftn = h[FF_STAT_FTN];
+        r->count = h[FF_STAT_COUNT];
+        r->branch = h[FF_STAT_BRANCH];
+        r->k = h[FF_STAT_K];
+        r->l_out = h[FF_STAT_LOUT];
+        break;
+    }
+    if (r->l_out != a->L) {
+        // the merge kernel wrote the by-patch order of the compacted sequence: it is the current one now
+        int32_t* t = c->order; c->order = c->order_next; c->order_next = t;
+        t = c->inv; c->inv = c->inv_next; c->inv_next = t;
+        c->swaps += 1;
+        c->order_len = r->l_out;
+    } else {
+        c->order_len = a->L;       // nothing folded: the order describes the unchanged sequence
+    }
+    return FF_OK;
+}
+
+extern "C" int ff_ctx_merge(ff_ctx_t* c, const ff_merge_call_t* a, ff_merge_result_t* r) {
+    int rc = ff_ctx_merge_begin(c, a);
+    if (rc) return rc;
+    return ff_ctx_merge_finish(c, a, r);
+}
+
+extern "C" int ff_ctx_prune(ff_ctx_t* c, const ff_prune_call_t* a) {
+    if (!a) return FF_ERR_ARG;
+    int rc = ctx_check(c, a->S);
+    if (rc) return rc;
+    if (a->mask && !a->mask_out) return FF_ERR_ARG;
+    hipStream_t st = (hipStream_t)a->stream;
+    if (!a->tables_ready) {
+        rc = ctx_clean(c, st);     // (tables announced by ff_ctx_expect_tables but not used: start from zero)
+        if (rc) return rc;
+    }
+    c->dirty = 1;
+    c->order_len = 0;              // the sequence changes and no order is maintained through a prune
+    rc = ff_prune_step(a->hidden, a->addend, a->hidden_out, (int)a->dtype, a->S, a->d, a->L_cap, a->attn_w, (int)a->w_dtype,
+                       a->H, a->num, c->sim, (int)a->tables_ready, a->start, a->n_img, a->k, c->member, c->dst, c->keep,
+                       c->stats, a->aux, (int)a->n_aux, c->ws, c->ws_bytes, a->stream);
+    if (rc) return rc;
+    c->dirty = 0;
+    if (a->mask) rc = ff_gather_mask(a->mask, a->mask_out, a->mask_elem_bytes, a->S, a->L_cap, c->dst, a->stream);
+    return rc;
 }

@@ -13,14 +13,14 @@ There is no eager/CPU fallback: CPU tensors raise ``FrameFusionHipError``.
 from __future__ import annotations
 
 import ctypes as C
-import time
+import struct
 from typing import List, Optional
 
 import torch
 from torch import nn
 
 from . import _lib
-from ._lib import FFAux, FrameFusionHipError
+from ._lib import FrameFusionHipError
 
 TEXT_TOKEN = -1
 IGNORE_TOKEN = -2
@@ -43,18 +43,43 @@ def _to_int(x) -> int:
     return int(x.item()) if isinstance(x, torch.Tensor) else int(x)
 
 
+_get_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
+_PACK_PTR = struct.Struct("=Q")
+_PACK_I64 = struct.Struct("=q")
+
+
 class _Scratch:
-    """Per-device integer scratch reused across calls (order, member, dst, keep, stats)."""
+    """Per-device scratch of one instance (order, member, dst, keep, stats, select tables) named by an
+    ``ff_ctx_t``, plus the reusable call / result blocks: a forward call crosses the C ABI with one
+    pointer to each (include/framefusion_hip.h, "call context")."""
 
     def __init__(self, device):
         self.device = device
         self.cap = 0
-        self.order_valid_for = None     # (patch_type generation, L) the cached by-patch order belongs to
+        self.ctx = _lib.FFCtx()
+        self.ctx_ptr = C.addressof(self.ctx)
+        self.call = _lib.FFMergeCall()
+        self.call_ptr = C.addressof(self.call)
+        self.pcall = _lib.FFPruneCall()
+        self.pcall_ptr = C.addressof(self.pcall)
+        self.res = _lib.FFMergeResult()
+        self.res_ptr = C.addressof(self.res)
+        self.order_gen = None           # patch_type generation the context's by-patch order belongs to
+        self.tables_token = None
+        self.last_stream = None
+        self.last_stream_ptr = None
 
-    def ensure(self, L: int, sim_dtype):
+    _BUFFERS = ("order", "order_next", "inv", "inv_next", "member", "dst", "keep", "sim32", "ws", "stats")
+
+    def ensure(self, L: int):
         if L > self.cap:
             cap = max(L, 1024)
             dev = self.device
+            if self.cap and self.last_stream is not None:
+                # kernels of the stream that used the old buffers last may still read them: keep the
+                # allocator from handing the memory out before that stream gets there
+                for name in self._BUFFERS:
+                    getattr(self, name).record_stream(self.last_stream)
             self.order = torch.empty(cap, dtype=torch.int32, device=dev)
             self.order_next = torch.empty(cap, dtype=torch.int32, device=dev)
             self.inv = torch.empty(cap, dtype=torch.int32, device=dev)          # inverse of order (slot of a position)
@@ -69,30 +94,74 @@ class _Scratch:
             self.stats_host = torch.zeros(_lib.STAT_WORDS, dtype=torch.int64).pin_memory()
             self.stats_host_ptr = self.stats_host.data_ptr()     # device-visible (pinned, UVA)
             self.stats_np = self.stats_host.numpy()              # shares the pinned memory
-            self.seq = 0
-            self.dirty = False          # a call died between begin and finish: the select tables need a reset
+            c = self.ctx
+            c.cap = cap
+            c.order, c.order_next = self.order.data_ptr(), self.order_next.data_ptr()
+            c.inv, c.inv_next = self.inv.data_ptr(), self.inv_next.data_ptr()
+            c.sim, c.member, c.dst, c.keep = (self.sim32.data_ptr(), self.member.data_ptr(), self.dst.data_ptr(),
+                                              self.keep.data_ptr())
+            c.stats, c.stats_host = self.stats.data_ptr(), self.stats_host_ptr
+            c.ws, c.ws_bytes = self.ws.data_ptr(), self.ws_bytes
+            c.order_len, c.dirty, c.in_flight, c.swaps = 0, 0, 0, 0
+            self._swaps = 0
             self.cap = cap
-            self.order_valid_for = None
+            self.order_gen = None
         return self
+
+    # ---- views for tests / tools ----
+    @property
+    def dirty(self) -> bool:
+        return bool(self.ctx.dirty)
+
+    @property
+    def seq(self) -> int:
+        return int(self.ctx.seq)
+
+    @property
+    def order_valid_for(self):
+        """(patch_type generation, sequence length) the maintained by-patch order describes, or None."""
+        n = int(self.ctx.order_len)
+        return (self.order_gen, n) if (n > 0 and self.order_gen is not None) else None
+
+    def forget_order(self):
+        self.order_gen = None
 
     def sim(self, dtype, n):
         return self.sim32.view(dtype)[:n]
 
-    def wait_stats(self, seq, spins=4_000_000):
-        """Poll the pinned result block until the device has published call `seq`."""
-        view = self.stats_np
-        word = _lib.STAT_SEQ
+    def sync_views(self):
+        """The library exchanges order <-> order_next (and the inverses) inside the context when a merge
+        call shortened the sequence: mirror it on the tensors that own the memory."""
+        if (int(self.ctx.swaps) - self._swaps) & 1:
+            self.order, self.order_next = self.order_next, self.order
+            self.inv, self.inv_next = self.inv_next, self.inv
+        self._swaps = int(self.ctx.swaps)
+
+    # ---- the call blocks ----
+    def put_aux(self, block, offset, pairs, L):
+        """Describe (src, out) tensor pairs as ff_aux_t entries; returns their number."""
         n = 0
-        while view[word] != seq:
+        pack = _lib.AUX_ENTRY.pack_into
+        for s, o in pairs:
+            if n >= _lib.MAX_AUX:
+                raise FrameFusionHipError("too many auxiliary tensors")
+            if s.ndim == 2:         # [B, L] ids
+                row, outer = s.element_size(), s.shape[0]
+            else:                   # [..., L, dh]
+                last = s.shape[-1]
+                row = last * s.element_size()
+                outer = s.numel() // (L * last)
+            pack(block, offset + 32 * n, s.data_ptr(), o.data_ptr(), row, outer)
             n += 1
-            if (n & 1023) == 0:
-                time.sleep(0)                    # let other Python threads (other replicas) run
-            if n > spins:
-                torch.cuda.current_stream().synchronize()
-                if view[word] != seq:
-                    raise FrameFusionHipError("the device never published the result block of this call")
-                break
-        return view
+        return n
+
+
+def _fail(rc: int, what: str, err_bits: int = 0):
+    if rc == _lib.ERR_DEVICE:
+        if err_bits:
+            raise FrameFusionHipError(f"device-side check failed in the {what} call (error bits {err_bits:#x})")
+        raise FrameFusionHipError(f"the device never published the result block of this {what} call")
+    _lib.check(rc, what)
 
 
 class FrameFusion(nn.Module):
@@ -103,9 +172,11 @@ class FrameFusion(nn.Module):
         self.ratio_lower_bound = ratio_lower_bound
         self._scratch = {}
         self._ptype_gen = 0       # bumped whenever patch_type is (re)assigned: keys the cached by-patch order
+        self._host_ints = {}      # id(0-d device tensor) -> (tensor, int): the prepare() scalars, read back once
         self.last_call = None     # diagnostics of the most recent reduction (tests / bench)
 
     _PLAIN = (bool, int, float, str, list, tuple, dict, type(None), torch.Tensor)
+    supports_residual = True      # forward(..., residual=) exists: see call_b_with_residual()
 
     def __setattr__(self, name, value):
         # The module has no parameters, buffers or submodules; its attributes are per-prefill state
@@ -126,6 +197,7 @@ class FrameFusion(nn.Module):
         # publishes results into: a copy.deepcopy / pickle of a used instance must not share it.
         state = self.__dict__.copy()
         state["_scratch"] = {}
+        state["_host_ints"] = {}
         state["last_call"] = None
         return state
 
@@ -142,34 +214,49 @@ class FrameFusion(nn.Module):
                 image_token_end_index, image_token_length, original_length: int,
                 finish_merging: bool = False, finish_pruning: bool = False,
                 sparsity_list: Optional[List[float]] = None):
-        self.patch_type = patch_type
-        self.patch_num = patch_num
-        self.image_token_start_index = image_token_start_index
-        self.image_token_end_index = image_token_end_index
-        self.image_token_length = image_token_length
-        self.original_length = original_length
-        self.finish_merging = finish_merging
-        self.finish_pruning = finish_pruning
-        self.sparsity_list = [] if sparsity_list is None else sparsity_list
-        for s in self._scratch.values():
-            s.order_valid_for = None
-        self._layout_hint = self._frame_major_hint(patch_num, image_token_start_index, image_token_length)
+        d = self.__dict__
+        d["_ptype_gen"] = d.get("_ptype_gen", 0) + 1
+        d["patch_type"] = patch_type
+        d["patch_num"] = patch_num
+        d["image_token_start_index"] = image_token_start_index
+        d["image_token_end_index"] = image_token_end_index
+        d["image_token_length"] = image_token_length
+        d["original_length"] = original_length
+        d["finish_merging"] = finish_merging
+        d["finish_pruning"] = finish_pruning
+        d["sparsity_list"] = [] if sparsity_list is None else sparsity_list
+        d["_host_ints"] = {}
+        d["_layout_hint"] = self._frame_major_hint(patch_num, image_token_start_index, image_token_length)
 
-    @staticmethod
-    def _frame_major_hint(patch_num, start, length):
+    def _host_int(self, x):
+        """int(x) for the prepare() scalars.  The reference's packers hand them over as 0-d / 1-element
+        DEVICE tensors (llava_video/modeling_llava_video.py:332: ``torch.where(...)[0]``) right after
+        having synchronised on them themselves (``[TEXT_TOKEN] * image_token_start_index``, :335); the
+        reference reads them back in every prune call (main.py:64-66).  Here each is read back once per
+        prefill and remembered."""
+        if not isinstance(x, torch.Tensor):
+            return int(x)
+        hit = self._host_ints.get(id(x))
+        if hit is not None and hit[0] is x:
+            return hit[1]
+        v = int(x.item())
+        self._host_ints[id(x)] = (x, v)
+        return v
+
+    def _frame_major_hint(self, patch_num, start, length):
         """(pre, frames) if the scalars describe whole frames of `patch_num` tokens starting at `start`
-        (the layout every packer of the reference builds), else None.  Only host values are looked at
-        (no device read-back); the similarity kernel verifies the hint against patch_type."""
-        def host_int(x):
+        (the layout every packer of the reference builds), else None.  The similarity kernel verifies
+        the hint against patch_type."""
+        def whole(x):
             if isinstance(x, torch.Tensor):
-                if x.is_cuda or x.numel() != 1:
+                if x.numel() != 1 or x.is_floating_point() or x.dtype == torch.bool:
                     return None
-                x = x.reshape(-1)[0].item()
+                return self._host_int(x)
             try:
                 return int(x) if float(x) == int(x) else None
             except (TypeError, ValueError):
                 return None
-        P, pre, n = host_int(patch_num), host_int(start), host_int(length)
+        P, pre, n = whole(patch_num), whole(start), whole(length)
         if P is None or pre is None or n is None or P < 1 or pre < 0 or n < P or n % P:
             return None
         return pre, n // P
@@ -181,7 +268,7 @@ class FrameFusion(nn.Module):
         (models/qwen2/modeling_qwen2.py:64-67) - formed inside the two streaming passes instead of by an
         eager add whose result would be written once and read twice."""
         dev = hidden_states.device
-        if dev.type == "cuda" and dev.index != torch.cuda.current_device():
+        if dev.type == "cuda" and dev.index != _get_device():
             # the kernels are launched through ctypes on the CURRENT device's stream: follow the
             # tensors (several replicas on several GPUs in one process, as in the reference's demo)
             with torch.cuda.device(dev):
@@ -211,11 +298,12 @@ class FrameFusion(nn.Module):
     # ---- helpers -------------------------------------------------------------------------------
     def _threshold_for(self, dtype) -> float:
         key = (self.similarity_lower_bound, dtype)
-        if getattr(self, "_thr_cache_key", None) != key:
+        if self.__dict__.get("_thr_cache_key") != key:
             self._thr_cache_key, self._thr_cache = key, _round_to(self.similarity_lower_bound, dtype)
         return self._thr_cache
 
-    def _scratch_for(self, device, L, dtype) -> _Scratch:
+    def _scratch_for(self, device, L) -> _Scratch:
+        """The scratch of `device` sized for L tokens, and the raw hipStream_t of PyTorch's current stream."""
         key = (device.type, device.index)
         s = self._scratch.get(key)
         if s is None:
@@ -223,32 +311,37 @@ class FrameFusion(nn.Module):
         # the scratch is reused call after call: if the caller switched streams, order the new
         # stream behind the one that last touched it
         ptr = _lib.stream_ptr()
-        if getattr(s, "last_stream_ptr", None) != ptr:
+        if s.last_stream_ptr != ptr:
             cur = torch.cuda.current_stream(device)
-            last = getattr(s, "last_stream", None)
+            last = s.last_stream
             if last is not None and last != cur:
                 cur.wait_stream(last)
             s.last_stream, s.last_stream_ptr = cur, ptr
-        return s.ensure(L, dtype)
+        if L > s.cap:
+            s.ensure(L)
+        return s, ptr
 
     @staticmethod
     def _aux_for_positions(position_embeddings, L: int, L_cap: int):
         """Describe the position container for K4 (main.py:142-178): returns
-        (aux descriptors, outputs, rebuild(outs, L_out) -> new container)."""
+        (sources, outputs, rebuild(L_out) -> new container)."""
         if type(position_embeddings) == list:
             assert len(position_embeddings) == 2
             srcs, outs = [], []
             for t in position_embeddings:
-                if t.ndim not in (3, 4) or t.shape[-2] != L:
-                    raise FrameFusionHipError(f"position embedding of shape {tuple(t.shape)} does not have "
+                shape = t.shape
+                if t.ndim not in (3, 4) or shape[-2] != L:
+                    raise FrameFusionHipError(f"position embedding of shape {tuple(shape)} does not have "
                                               f"{L} tokens on its second-to-last axis")
-                t = t.contiguous()
+                if not t.is_contiguous():
+                    t = t.contiguous()
                 srcs.append(t)
-                outs.append(torch.empty(t.shape[:-2] + (L_cap, t.shape[-1]), dtype=t.dtype, device=t.device))
+                outs.append(torch.empty(shape[:-2] + (L_cap, shape[-1]), dtype=t.dtype, device=t.device))
 
             def rebuild(L_out):
-                for i in range(2):
-                    position_embeddings[i] = outs[i].narrow(outs[i].ndim - 2, 0, L_out)
+                ax = outs[0].ndim - 2
+                position_embeddings[0] = outs[0].narrow(ax, 0, L_out)
+                position_embeddings[1] = outs[1].narrow(ax, 0, L_out)
                 return position_embeddings
             return srcs, outs, rebuild
         if type(position_embeddings) == torch.Tensor:
@@ -260,49 +353,31 @@ class FrameFusion(nn.Module):
         raise NotImplementedError("Only support list or tensor for position embeddings")
 
     @staticmethod
-    def _fill_aux(arr, n0, srcs, outs, L):
-        n = n0
-        for s, o in zip(srcs, outs):
-            if n >= _lib.MAX_AUX:
-                raise FrameFusionHipError("too many auxiliary tensors")
-            if s.ndim == 2:         # [B, L] ids
-                row, outer = s.element_size(), s.shape[0]
-            else:                   # [..., L, dh]
-                row = s.shape[-1] * s.element_size()
-                outer = s.numel() // (L * s.shape[-1])
-            arr[n] = FFAux(s.data_ptr(), o.data_ptr(), row, outer)
-            n += 1
-        return n
-
-    def _gather_mask(self, attention_mask, L, L_cap, dst, stream):
+    def _mask_for(attention_mask, L, L_cap):
         m = attention_mask
         if m.ndim != 4 or m.shape[0] != 1 or m.shape[1] != 1 or m.shape[2] != L or m.shape[3] != L:
             raise FrameFusionHipError(f"attention mask of shape {tuple(m.shape)} is not [1, 1, {L}, {L}]")
         m = m.contiguous()
-        out = torch.empty(1, 1, L_cap, L_cap, dtype=m.dtype, device=m.device)
-        _lib.check(_lib.load().ff_gather_mask(m.data_ptr(), out.data_ptr(), m.element_size(), L, L_cap,
-                                              dst.data_ptr(), stream), "ff_gather_mask")
-        return out
+        return m, torch.empty(1, 1, L_cap, L_cap, dtype=m.dtype, device=m.device)
 
     # ---- merge call: main.py:104-138 -------------------------------------------------------------
     def _merge(self, hidden_states, position_embeddings, attention_mask, residual=None):
-        return self._merge_complete(self._merge_launch(hidden_states, position_embeddings, attention_mask, residual=residual))
-
-    def _merge_launch(self, hidden_states, position_embeddings, attention_mask, use_hint=True, residual=None):
-        """Enqueue the whole merge call on the current stream and return without waiting: the
-        state machine is advanced by _merge_complete."""
+        """One merge call = two crossings of the C ABI: ff_ctx_merge_begin enqueues the similarity pass
+        before any output tensor exists (the allocations below overlap it), ff_ctx_merge_finish enqueues
+        plan + merge and waits - in C, interpreter lock released - for the 256-byte result block the plan
+        kernel publishes before the second streaming pass starts."""
         _lib.require_gpu(hidden_states, "FrameFusion.forward")
         lib = _lib.load()
-        bsz, L, d = hidden_states.size()
+        bsz, L, d = hidden_states.shape
         assert bsz == 1, "Only support batch size 1"                                # main.py:203
         device = hidden_states.device
         dtype = hidden_states.dtype
         code = _dtype_code(hidden_states)
         hidden = hidden_states if hidden_states.is_contiguous() else hidden_states.contiguous()
-        addend = None
+        addend_ptr = 0
         if residual is not None:
             addend = residual if residual.is_contiguous() else residual.contiguous()
-        addend_ptr = addend.data_ptr() if addend is not None else None
+            addend_ptr = addend.data_ptr()
 
         ptype = self.patch_type
         if ptype.device != device or ptype.dtype != torch.int64 or not ptype.is_contiguous():
@@ -312,81 +387,50 @@ class FrameFusion(nn.Module):
             raise FrameFusionHipError(f"patch_type has {ptype.numel()} entries for a sequence of {L}")
 
         sub = self._compute_pruning_ratio(self.sparsity_list, self.cost)           # main.py:109
-        sc = self._scratch_for(device, L, dtype)
-        stream = _lib.stream_ptr()
-        sim_ptr = sc.sim32.data_ptr()
-        order_valid = 1 if sc.order_valid_for == (self._ptype_gen, L) else 0
-
-        # first half (K0 + K1) goes out before any output tensor exists: the allocations below
-        # overlap the similarity pass
-        thr = self._threshold_for(dtype)
-        if sc.dirty:                 # restore the workspace protocol (zeroed tables, fresh parity)
-            sc.ws.zero_()
-            sc.stats.zero_()
-            sc.dirty = False
-        sc.seq += 1
-        seq = sc.seq
-        sc.dirty = True              # cleared once ff_merge_finish has been enqueued
+        sc, stream = self._scratch_for(device, L)
+        order_valid = 1 if sc.order_gen == self._ptype_gen else 0
         # first call of a prefill: hand the frame-major layout the prepare() scalars describe to the
         # similarity kernel, which derives and verifies the by-patch order itself (no K0 launch)
-        hint = getattr(self, "_layout_hint", None) if (use_hint and not order_valid) else None
-        if hint is not None and hint[0] + hint[1] * int(self.patch_num) > L:
-            hint = None
-        hint_pre, hint_frames = hint if hint is not None else (0, 0)
-        rc = lib.ff_merge_begin(hidden.data_ptr(), addend_ptr, code, L, d, ptype.data_ptr(), int(self.patch_num), order_valid,
-                                thr, sc.order.data_ptr(), sc.inv.data_ptr(), sim_ptr, sc.stats.data_ptr(), seq, hint_pre,
-                                hint_frames,
-                                sc.ws.data_ptr(), sc.ws_bytes, stream)
-        _lib.check(rc, "ff_merge_begin")
+        hint_pre = hint_frames = 0
+        P = int(self.patch_num)
+        if not order_valid:
+            hint = self.__dict__.get("_layout_hint")
+            if hint is not None and hint[0] + hint[1] * P <= L:
+                hint_pre, hint_frames = hint
+        call = sc.call
+        _lib.MERGE_CALL_HEAD.pack_into(call, 0, hidden.data_ptr(), addend_ptr, 0, ptype.data_ptr(), code, L, d, L, P,
+                                       order_valid, self._threshold_for(dtype), sub, self.ratio_lower_bound, -1,
+                                       _lib.FOLD_SEQUENTIAL, hint_pre, hint_frames, stream or 0, 0)
+        sc.order_gen = None                  # until the call has come back
+        rc = lib.ff_ctx_merge_begin(sc.ctx_ptr, sc.call_ptr)
+        if rc:
+            _fail(rc, "merge")
 
         L_cap = L
-        out = torch.empty(1, L_cap, d, dtype=dtype, device=device)
-        ptype_out = torch.empty(1, L_cap, dtype=torch.int64, device=device)
+        out = torch.empty((1, L_cap, d), dtype=dtype, device=device)
+        ptype_out = torch.empty((1, L_cap), dtype=torch.int64, device=device)
         srcs, outs, rebuild = self._aux_for_positions(position_embeddings, L, L_cap)
-        aux = (FFAux * _lib.MAX_AUX)()
-        n_aux = self._fill_aux(aux, 0, [ptype.view(1, L)], [ptype_out], L)
-        n_aux = self._fill_aux(aux, n_aux, srcs, outs, L)
-        rc = lib.ff_merge_finish(hidden.data_ptr(), addend_ptr, out.data_ptr(), code, L, d, L_cap,
-                                 float(thr), float(sub), float(self.ratio_lower_bound),
-                                 sc.order.data_ptr(), sc.inv.data_ptr(), sim_ptr, sc.member.data_ptr(),
-                                 sc.dst.data_ptr(), sc.keep.data_ptr(), sc.stats.data_ptr(), sc.stats_host_ptr, seq,
-                                 aux, n_aux, sc.order_next.data_ptr(), sc.inv_next.data_ptr(), sc.ws.data_ptr(),
-                                 sc.ws_bytes, stream)
-        _lib.check(rc, "ff_merge_finish")
-        sc.dirty = False
+        n_aux = sc.put_aux(call, _lib.MERGE_CALL_AUX_OFFSET, zip([ptype.view(1, L)] + srcs, [ptype_out] + outs), L)
+        _PACK_PTR.pack_into(call, 16, out.data_ptr())
+        _PACK_I64.pack_into(call, _lib.MERGE_CALL_AUX_OFFSET - 8, n_aux)
         mask_out = None
         if attention_mask is not None:
-            mask_out = self._gather_mask(attention_mask, L, L_cap, sc.dst, stream)
-
-        return dict(sc=sc, seq=seq, L=L, dtype=dtype, out=out, ptype_out=ptype_out, rebuild=rebuild,
-                    mask_out=mask_out, hinted=hint is not None, residual=residual,
-                    inputs=(hidden_states, position_embeddings, attention_mask))
-
-    def _merge_complete(self, pending):
-        sc, seq, L, dtype = pending["sc"], pending["seq"], pending["L"], pending["dtype"]
-        out, ptype_out, rebuild, mask_out = pending["out"], pending["ptype_out"], pending["rebuild"], pending["mask_out"]
-        attention_mask = None
-        # The one device->host hand-off of the call: the scan kernel stores the result block into
-        # pinned host memory (sequence word last) BEFORE the merge kernel runs, so the host learns
-        # L_out while the second streaming pass is still in flight and returns without waiting for it.
-        st = sc.wait_stats(seq)
-        err = int(st[_lib.STAT_ERROR])
-        if err & ~_lib.ERR_BIT_LAYOUT:
-            sc.dirty = True
-            sc.order_valid_for = None
-            raise FrameFusionHipError(f"device-side check failed in the merge call (error bits {err:#x})")
-        if err & _lib.ERR_BIT_LAYOUT:
-            # patch_type is not the frame-major layout the prepare() scalars suggested (e.g. text
-            # between the frames): everything this call enqueued is void.  Repeat it through K0 and
-            # stop hinting for this prefill.
-            assert pending["hinted"]
+            m, mask_out = self._mask_for(attention_mask, L, L_cap)
+            _lib.MASK_TRIPLE.pack_into(call, _lib.MERGE_CALL_MASK_OFFSET, m.data_ptr(), mask_out.data_ptr(), m.element_size())
+        else:
+            _lib.MASK_TRIPLE.pack_into(call, _lib.MERGE_CALL_MASK_OFFSET, 0, 0, 0)
+        # The one device->host hand-off of the call: the plan kernel stores the result block into pinned
+        # host memory (sequence word last) BEFORE the merge kernel runs, so the host learns L_out while the
+        # second streaming pass is still in flight and returns without waiting for it.
+        rc = lib.ff_ctx_merge_finish(sc.ctx_ptr, sc.call_ptr, sc.res_ptr)
+        nv, ftn, count, branch, k, L_out, err, unhinted, wait_ns = _lib.MERGE_RESULT.unpack_from(sc.res)
+        if unhinted:
+            # patch_type is not the frame-major layout the prepare() scalars suggested (e.g. text between
+            # the frames): the library repeated the call through K0; stop hinting for this prefill
             self._layout_hint = None
-            sc.dirty = True
-            sc.order_valid_for = None
-            return self._merge_complete(self._merge_launch(*pending["inputs"], use_hint=False, residual=pending["residual"]))
-        nv, ftn, count = int(st[_lib.STAT_NV]), int(st[_lib.STAT_FTN]), int(st[_lib.STAT_COUNT])
-        L_out = int(st[_lib.STAT_LOUT])
-        branch = int(st[_lib.STAT_BRANCH])
+        if rc:
+            _fail(rc, "merge", err)
+        sc.sync_views()
         assert nv > 0, "no visual tokens"                                          # main.py:240
 
         above_k_ratio = count / ftn                                                 # main.py:114
@@ -403,26 +447,21 @@ class FrameFusion(nn.Module):
             # the device and wrote nothing - the reduced sequence is the input itself, and the order
             # in the scratch still describes the (unchanged) patch_type
             self.last_call = dict(kind="merge", L_in=L, L_out=L, nv=nv, ftn=ftn, count=count, branch=branch,
-                                  k=int(st[_lib.STAT_K]), scratch=sc, dtype=dtype, order=sc.order)
-            sc.order_valid_for = (self._ptype_gen, L)
-            if pending["residual"] is not None:          # nothing folded, but the caller is owed the sum
-                h_in, pe_in, mask_in = pending["inputs"]
-                return pending["residual"] + h_in, pe_in, mask_in
-            return pending["inputs"]
+                                  k=k, scratch=sc, dtype=dtype, order=sc.order, wait_ns=wait_ns)
+            sc.order_gen = self._ptype_gen
+            if residual is not None:          # nothing folded, but the caller is owed the sum
+                return residual + hidden_states, position_embeddings, attention_mask
+            return hidden_states, position_embeddings, attention_mask
 
-        self.patch_type = ptype_out[:, :L_out]                                      # main.py:132
-        # order maintenance: the merge kernel also wrote the by-patch order of the compacted
-        # sequence, so the next merge call of this prefill skips K0
+        # order maintenance: the merge kernel also wrote the by-patch order of the compacted sequence
+        # (now the context's current one), so the next merge call of this prefill skips K0
         self.last_call = dict(kind="merge", L_in=L, L_out=L_out, nv=nv, ftn=ftn, count=count, branch=branch,
-                              k=int(st[_lib.STAT_K]), scratch=sc, dtype=dtype, order=sc.order)
-        sc.order, sc.order_next = sc.order_next, sc.order
-        sc.inv, sc.inv_next = sc.inv_next, sc.inv
-        sc.order_valid_for = (self._ptype_gen, L_out)
-        hidden_states = out[:, :L_out]
-        position_embeddings = rebuild(L_out)
+                              k=k, scratch=sc, dtype=dtype, order=sc.order_next, wait_ns=wait_ns)
+        self.patch_type = ptype_out.narrow(1, 0, L_out)                             # main.py:132
+        sc.order_gen = self._ptype_gen
         if mask_out is not None:
             attention_mask = mask_out[:, :, :L_out, :L_out]
-        return hidden_states, position_embeddings, attention_mask
+        return out.narrow(1, 0, L_out), rebuild(L_out), attention_mask
 
     def last_plan(self):
         """Diagnostics of the most recent merge / prune call (views into the reusable scratch: valid
@@ -434,20 +473,25 @@ class FrameFusion(nn.Module):
             out.update(sim=sc.sim(c["dtype"], nv), order=c["order"][:nv])
         return out
 
+    def _prune_range(self, q_len):
+        """(start, n_img) of main.py:64-66 as host ints."""
+        start = self._host_int(self.image_token_start_index)
+        n_img = self._host_int(self.image_token_length) - (self._host_int(self.original_length) - q_len)
+        return start, n_img
+
     def _expect_importance(self, S: int, dtype, device):
         """The attention hook is about to compute the importance of a prune call over S tokens: hand out the
         workspace (as the `select` argument of utils._launch_last_query) in which the importance kernel
         accumulates the select tables, and a token _prune recognises the tensor by."""
         with torch.cuda.device(device):
-            sc = self._scratch_for(device, S, dtype)
-            start = _to_int(self.image_token_start_index)
-            n_img = _to_int(self.image_token_length - (self.original_length - S))
+            sc, stream = self._scratch_for(device, S)
+            start, n_img = self._prune_range(S)
             if n_img < 0 or start < 0 or start + n_img > S:
                 return None, None
-            if sc.dirty:
-                sc.ws.zero_()
-                sc.stats.zero_()
-            sc.dirty = True                       # until the prune call has consumed (and cleared) the tables
+            lib = _lib.load()
+            _lib.check(lib.ff_ctx_reset(sc.ctx_ptr, stream), "ff_ctx_reset")    # (zeroes the tables if a call died)
+            sc.order_gen = None
+            lib.ff_ctx_expect_tables(sc.ctx_ptr)    # until the prune call has consumed (and cleared) the tables
             token = (id(sc), sc.seq, S, start, n_img, dtype)
             sc.tables_token = token
             return (start, start + n_img, sc.ws.data_ptr(), sc.ws_bytes), token
@@ -456,15 +500,13 @@ class FrameFusion(nn.Module):
     def _prune(self, hidden_states, position_embeddings, attention_mask, self_attn_weights, residual=None):
         _lib.require_gpu(hidden_states, "FrameFusion.forward")
         lib = _lib.load()
-        bsz, q_len, d = hidden_states.size()
+        bsz, q_len, d = hidden_states.shape
         assert bsz == 1, "Only support batch size 1"
         device, dtype = hidden_states.device, hidden_states.dtype
         code = _dtype_code(hidden_states)
-        hidden = hidden_states.contiguous()
-        start = _to_int(self.image_token_start_index)
-        n_img = _to_int(self.image_token_length - (self.original_length - q_len))
-        stream = _lib.stream_ptr()
-        sc = self._scratch_for(device, q_len, dtype)
+        hidden = hidden_states if hidden_states.is_contiguous() else hidden_states.contiguous()
+        start, n_img = self._prune_range(q_len)                                     # main.py:64-66
+        sc, stream = self._scratch_for(device, q_len)
 
         w = self_attn_weights                                                       # main.py:69-70
         _lib.require_gpu(w, "FrameFusion.forward(self_attn_weights)")
@@ -475,7 +517,9 @@ class FrameFusion(nn.Module):
         w_code = _lib.DTYPE_CODE.get(w.dtype)
         if w_code is None:
             raise FrameFusionHipError(f"unsupported attention-weight dtype {w.dtype} (fp32 / bf16 / fp16 only)")
-        w = w.contiguous()
+        token = getattr(w, "_ff_tables", None)
+        if not w.is_contiguous():
+            w = w.contiguous()
         if w.data_ptr() & 15:
             w = w.clone()
         pruning_ratio = self._compute_pruning_ratio(self.sparsity_list, self.cost)  # main.py:73
@@ -485,34 +529,34 @@ class FrameFusion(nn.Module):
         L_out = q_len - n_img + k
         # importance from last_query_importance(..., framefusion=self): its kernel has already filled the
         # select tables of exactly this call in the workspace
-        token = getattr(w, "_ff_tables", None)
-        tables_ready = int(token is not None and token == getattr(sc, "tables_token", None) and
-                           token == (id(sc), sc.seq, q_len, start, n_img, w.dtype) and w.shape[1] * w.shape[2] == 1)
+        H, num = w.shape[1], w.shape[2]
+        tables_ready = int(token is not None and token == sc.tables_token and
+                           token == (id(sc), sc.seq, q_len, start, n_img, w.dtype) and H * num == 1)
         sc.tables_token = None
-        if sc.dirty and not tables_ready:   # a call died half-way: the select tables must start from zero
-            sc.ws.zero_()
-            sc.stats.zero_()
-            sc.dirty = False
         # nothing is read back (L_out is known): head mean + select tables, plan, gather - one host call
-        out = torch.empty(1, L_out, d, dtype=dtype, device=device)
+        out = torch.empty((1, L_out, d), dtype=dtype, device=device)
         srcs, outs, rebuild = self._aux_for_positions(position_embeddings, q_len, L_out)
-        aux = (FFAux * _lib.MAX_AUX)()
-        n_aux = self._fill_aux(aux, 0, srcs, outs, q_len)
-        imp = sc.sim32[:q_len]       # fp32-sized slots: room for any weight dtype
-        sc.dirty = True
-        addend = residual.contiguous() if residual is not None else None
-        _lib.check(lib.ff_prune_step(hidden.data_ptr(), addend.data_ptr() if addend is not None else None,
-                                     out.data_ptr(), code, q_len, d, L_out,
-                                     w.data_ptr(), w_code, w.shape[1], w.shape[2], imp.data_ptr(), tables_ready,
-                                     start, n_img, k, sc.member.data_ptr(), sc.dst.data_ptr(), sc.keep.data_ptr(),
-                                     sc.stats.data_ptr(), aux, n_aux, sc.ws.data_ptr(), sc.ws_bytes, stream),
-                   "ff_prune_step")
-        sc.dirty = False
+        addend_ptr = 0
+        if residual is not None:
+            addend = residual if residual.is_contiguous() else residual.contiguous()
+            addend_ptr = addend.data_ptr()
+        call = sc.pcall
+        n_aux = sc.put_aux(call, _lib.PRUNE_CALL_AUX_OFFSET, zip(srcs, outs), q_len)
+        _lib.PRUNE_CALL_HEAD.pack_into(call, 0, hidden.data_ptr(), addend_ptr, out.data_ptr(), w.data_ptr(), code, q_len, d,
+                                       L_out, w_code, H, num, tables_ready, start, n_img, k, stream or 0, n_aux)
+        mask_out = None
         if attention_mask is not None:
-            attention_mask = self._gather_mask(attention_mask, q_len, L_out, sc.dst, stream)
+            m, mask_out = self._mask_for(attention_mask, q_len, L_out)
+            _lib.MASK_TRIPLE.pack_into(call, _lib.PRUNE_CALL_MASK_OFFSET, m.data_ptr(), mask_out.data_ptr(), m.element_size())
+        else:
+            _lib.MASK_TRIPLE.pack_into(call, _lib.PRUNE_CALL_MASK_OFFSET, 0, 0, 0)
+        sc.order_gen = None
+        rc = lib.ff_ctx_prune(sc.ctx_ptr, sc.pcall_ptr)
+        if rc:
+            _fail(rc, "prune")
         self.finish_pruning = True                                                  # main.py:101
         self.last_call = dict(kind="prune", L_in=q_len, L_out=L_out, k=k, nv=q_len, scratch=sc, dtype=w.dtype)
-        return out, rebuild(L_out), attention_mask
+        return out, rebuild(L_out), mask_out
 
     # ---- static parity entry points ---------------------------------------------------------------
     @staticmethod
@@ -595,6 +639,16 @@ class FrameFusion(nn.Module):
         if share > 1:
             return 0
         return 1 - share
+
+
+def call_b_with_residual(framefusion, residual, hidden_states, position_embeddings, attention_mask, self_attn_weights=None):
+    """Call B of a decoder layer (models/qwen2/modeling_qwen2.py:64-67: ``hidden = residual + attn_out`` and
+    then ``self.framefusion(hidden, ...)``) for whatever object sits on ``.framefusion``: through
+    ``nn.Module.__call__`` (forward hooks run) with the add fused into the reduction when the object takes
+    ``residual=``, else the reference contract - the eager add and the 4-argument call."""
+    if getattr(framefusion, "supports_residual", False):
+        return framefusion(hidden_states, position_embeddings, attention_mask, self_attn_weights, residual=residual)
+    return framefusion(residual + hidden_states, position_embeddings, attention_mask, self_attn_weights)
 
 
 def cosine_similarity(mat1, mat2):

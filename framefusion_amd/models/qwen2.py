@@ -17,6 +17,7 @@ from __future__ import annotations
 import torch
 
 from ..interface import Family, register_family
+from ..main import call_b_with_residual
 from ..utils import last_query_importance
 
 
@@ -60,8 +61,8 @@ def qwen2_decoder_forward(self, hidden_states, attention_mask=None, position_ids
                                                use_cache=use_cache, position_embeddings=position_embeddings, **kwargs)
     # modeling_qwen2.py:64-67: hidden = residual + attention output, then call B - here the add is formed
     # inside the reduction's two streaming passes (a plain add when no reduction is due)
-    hidden_states, position_embeddings, attention_mask = self.framefusion.forward_residual(
-        residual, hidden_states, position_embeddings, attention_mask, importance)
+    hidden_states, position_embeddings, attention_mask = call_b_with_residual(
+        self.framefusion, residual, hidden_states, position_embeddings, attention_mask, importance)
     residual = hidden_states
     hidden_states = self.mlp(self.post_attention_layernorm(hidden_states))
     hidden_states = residual + hidden_states

@@ -17,6 +17,7 @@ from __future__ import annotations
 import torch
 
 from ..interface import Family, register_family
+from ..main import call_b_with_residual
 from ..utils import last_query_importance
 
 NUM_IMPORTANCE_QUERIES = 4           # modeling_qwen2_vl.py:296
@@ -61,8 +62,8 @@ def qwen2vl_decoder_forward(self, hidden_states, attention_mask=None, position_i
     hidden_states, importance = self.self_attn(hidden_states=hidden_states, attention_mask=attention_mask,
                                                position_ids=position_ids, past_key_values=past_key_values,
                                                use_cache=use_cache, position_embeddings=position_embeddings, **kwargs)
-    hidden_states, position_embeddings, attention_mask = self.framefusion.forward_residual(    # modeling_qwen2_vl.py:197-200
-        residual, hidden_states, position_embeddings, attention_mask, importance)
+    hidden_states, position_embeddings, attention_mask = call_b_with_residual(    # modeling_qwen2_vl.py:197-200
+        self.framefusion, residual, hidden_states, position_embeddings, attention_mask, importance)
     residual = hidden_states
     hidden_states = self.mlp(self.post_attention_layernorm(hidden_states))
     hidden_states = residual + hidden_states

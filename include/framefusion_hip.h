@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FF_ABI_VERSION 6
+#define FF_ABI_VERSION 7
 
 enum { FF_F32 = 0, FF_BF16 = 1, FF_F16 = 2 };
 
@@ -38,7 +38,10 @@ enum {
     FF_ERR_ARG = -1,          /* null pointer / negative size / unknown dtype            */
     FF_ERR_ALIGN = -2,        /* pointer or row size not 16-byte aligned                 */
     FF_ERR_UNSUPPORTED = -3,  /* size outside what the kernels are built for             */
-    FF_ERR_WORKSPACE = -4     /* workspace smaller than ff_workspace_bytes()             */
+    FF_ERR_WORKSPACE = -4,    /* workspace smaller than ff_workspace_bytes()             */
+    FF_ERR_DEVICE = -5,       /* a device-side check failed (ff_merge_result_t.error) or the
+                                 result block of a context call was never published      */
+    FF_ERR_STATE = -6         /* context call out of order (finish without begin, ...)   */
 };
 
 /* Device-side result block written by the plan kernels and read back once per call by the host
@@ -321,6 +324,119 @@ int ff_prune_step(const void* hidden, const void* addend, void* hidden_out, int 
                   int64_t start, int64_t n_img, int64_t k,
                   uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
                   const ff_aux_t* aux_host, int n_aux, void* ws, size_t ws_bytes, ff_stream_t stream);
+
+
+/* ---- call context (ABI v7) --------------------------------------------------------------------
+ * One FrameFusion.forward call (framefusion/main.py:40-140) per host call, for hosts that keep one
+ * `FrameFusion` instance per sample: the context owns nothing, it NAMES the per-sample scratch the
+ * caller allocated once (so a call passes one pointer instead of ~30 scalars) and carries the state
+ * the library keeps between the calls of a prefill (sequence number, which of the two order buffers
+ * is current, whether the workspace needs a reset).  A context is plain host memory: zero it, fill
+ * the "owner" fields, and never share it between threads without a lock (the reference's instance
+ * is not thread-safe either).
+ *
+ * All structure members are 8 bytes wide (pointers, int64_t, double, size_t) so that any FFI can
+ * fill them by offset without padding rules. */
+typedef struct ff_ctx {
+    /* ---- owner fields: device scratch for sequences of up to `cap` tokens ---- */
+    int64_t cap;
+    int32_t* order;        /* [cap] by-patch order of the CURRENT sequence (valid when order_len > 0)   */
+    int32_t* order_next;   /* [cap] written by a merge call; the library swaps the pair on success      */
+    int32_t* inv;          /* [cap] inverse of order                                                    */
+    int32_t* inv_next;     /* [cap]                                                                     */
+    void* sim;             /* [cap] x 4 bytes: similarities (T) / importance scratch of a prune call    */
+    uint8_t* member;       /* [cap] 16-byte aligned                                                     */
+    int32_t* dst;          /* [cap]                                                                     */
+    uint8_t* keep;         /* [cap]                                                                     */
+    int64_t* stats;        /* [FF_STAT_WORDS] device, zero-initialised                                  */
+    int64_t* stats_host;   /* [FF_STAT_WORDS] pinned host memory the DEVICE can write (hipHostMalloc)   */
+    void* ws;              /* ff_workspace_bytes(cap, .) bytes, zero-initialised                        */
+    size_t ws_bytes;
+    /* ---- library state (zero-initialise; read-only for the owner) ---- */
+    int64_t seq;           /* number of the last merge call (echoed by the device)                      */
+    int64_t order_len;     /* length of the sequence `order`/`inv` describe; 0 = none                   */
+    int64_t dirty;         /* a call died half-way: workspace + stats are reset by the next call        */
+    int64_t in_flight;     /* 1 between ff_ctx_merge_begin and ff_ctx_merge_finish                      */
+    int64_t swaps;         /* number of order <-> order_next exchanges so far (owner mirrors its views) */
+} ff_ctx_t;
+
+/* Inputs of one merge call (main.py:104-138).  The same structure goes to begin and finish; the
+ * output fields (hidden_out, aux[].dst, mask_out) are only read by finish, so the host may allocate
+ * them while the similarity pass of begin is running. */
+typedef struct ff_merge_call {
+    const void* hidden;          /* [L, d] T                                                            */
+    const void* addend;          /* optional [L, d] T: rows are T(hidden + addend)                      */
+    void* hidden_out;            /* [L_cap, d] T                                                        */
+    const int64_t* patch_type;   /* [L]                                                                 */
+    int64_t dtype, L, d, L_cap, patch_num;
+    int64_t order_valid;         /* != 0: patch_type is what the context's `order` was built for (the
+                                    previous merge call's compacted patch_type, untouched since)        */
+    double threshold, sub, ratio_lb;   /* as ff_plan_merge                                              */
+    int64_t force_k;             /* < 0: the threshold / budget policy above; >= 0: top-k with this k
+                                    (the fixed-sparsity baseline, as ff_merge_finish_topk)              */
+    int64_t fold;                /* FF_FOLD_SEQUENTIAL (main.py) or FF_FOLD_MEAN (baseline)             */
+    int64_t hint_pre, hint_frames;     /* frame-major layout hint, as ff_merge_begin                    */
+    ff_stream_t stream;
+    int64_t n_aux;
+    ff_aux_t aux[FF_MAX_AUX];
+    const void* mask;            /* optional [L, L] attention mask of mask_elem_bytes per element       */
+    void* mask_out;              /* [L_cap, L_cap]                                                      */
+    int64_t mask_elem_bytes;
+} ff_merge_call_t;
+
+/* What the host needs from the call (everything else stays on the device). */
+typedef struct ff_merge_result {
+    int64_t nv, ftn, count, branch, k, l_out;
+    int64_t error;       /* FF_ERR_BIT_* of the device-side checks (0 on success)                       */
+    int64_t unhinted;    /* 1: the layout hint did not describe patch_type; the call was repeated
+                            through K0 inside ff_ctx_merge_finish (stop hinting for this sample)        */
+    int64_t wait_ns;     /* time ff_ctx_merge_finish spent polling for the result block (diagnostics)   */
+} ff_merge_result_t;
+
+/* begin: (reset if dirty) + K0 unless order_valid/hinted + K1.  Enqueues only.
+ * finish: plan + K4 (+ mask gather), then WAITS - polling the pinned result block, which the plan
+ * kernel publishes before K4 starts - until L_out is known, and advances the context (order swap).
+ * The poll spins on host memory without any HIP call; FFI layers should release their interpreter
+ * lock around it (ctypes.CDLL does).  If nothing is published within ~1 ms the stream is queried
+ * every ~50 us and a failed or drained stream ends the wait with FF_ERR_DEVICE / the hipError_t.
+ * A FF_ERR_BIT_LAYOUT result is handled inside finish: workspace reset, the whole call repeated
+ * with hint_frames = 0, result->unhinted = 1.
+ * ff_ctx_merge = begin + finish (outputs allocated up front). */
+int ff_ctx_merge_begin(ff_ctx_t* ctx, const ff_merge_call_t* call);
+int ff_ctx_merge_finish(ff_ctx_t* ctx, const ff_merge_call_t* call, ff_merge_result_t* result);
+int ff_ctx_merge(ff_ctx_t* ctx, const ff_merge_call_t* call, ff_merge_result_t* result);
+
+/* One prune call (main.py:61-101) on the context's scratch: arguments as ff_prune_step.  Nothing is
+ * waited for (the output length S - n_img + k is the caller's arithmetic). */
+typedef struct ff_prune_call {
+    const void* hidden;
+    const void* addend;
+    void* hidden_out;            /* [L_cap, d]                                                          */
+    const void* attn_w;          /* [H, num, S] of w_dtype, or the [S] importance when H * num == 1     */
+    int64_t dtype, S, d, L_cap, w_dtype, H, num;
+    int64_t tables_ready;        /* the importance's producer filled the select tables in ctx->ws       */
+    int64_t start, n_img, k;
+    ff_stream_t stream;
+    int64_t n_aux;
+    ff_aux_t aux[FF_MAX_AUX];
+    const void* mask;
+    void* mask_out;
+    int64_t mask_elem_bytes;
+} ff_prune_call_t;
+int ff_ctx_prune(ff_ctx_t* ctx, const ff_prune_call_t* call);
+
+/* The caller replaced patch_type / starts a new sample: forget the order (and reset the workspace
+ * if a call died half-way).  Enqueues at most two memsets on `stream`. */
+int ff_ctx_reset(ff_ctx_t* ctx, ff_stream_t stream);
+
+/* Marks the workspace as holding select tables a producer outside the context filled (or may have
+ * filled) - ff_last_query_attention with sel_ws = ctx->ws: if the matching ff_ctx_prune never comes,
+ * the next call resets the workspace. */
+void ff_ctx_expect_tables(ff_ctx_t* ctx);
+
+/* sizeof() of the structures above as THIS library was compiled (0: ff_ctx_t, 1: ff_merge_call_t,
+ * 2: ff_merge_result_t, 3: ff_prune_call_t, 4: ff_aux_t), so a binding can verify its own layout. */
+size_t ff_abi_sizeof(int which);
 
 #ifdef __cplusplus
 }

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(_lib.LIB_PATH)
     for name in declared_functions():
         assert hasattr(lib, name), name
-    assert _lib.load().ff_abi_version() == _lib.ABI_VERSION == 6
+    assert _lib.load().ff_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_stat_enum_matches_binding():
@@ -68,6 +68,64 @@ def test_argument_validation_without_gpu():
     # empty problems are a no-op
     assert lib.ff_build_order(16, 0, 4, 16, None, 16, 16, 1 << 24, None) == 0
     assert lib.ff_pair_similarity(16, 1, 0, 64, 16, 16, 16, 16, None) == 0
+
+
+def test_context_structures_match_the_header():
+    """ff_ctx_t / ff_merge_call_t / ff_prune_call_t / ff_merge_result_t: the ctypes mirrors have the library's
+    sizes, every member is 8 bytes wide and in the header's order, and the packed-struct formats the host fills
+    them with land on the right offsets."""
+    lib = _lib.load()
+    for which, cls in enumerate((_lib.FFCtx, _lib.FFMergeCall, _lib.FFMergeResult, _lib.FFPruneCall, _lib.FFAux)):
+        assert lib.ff_abi_sizeof(which) == C.sizeof(cls), cls.__name__
+    assert lib.ff_abi_sizeof(99) == 0
+    text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    for cname, cls in (("ff_ctx", _lib.FFCtx), ("ff_merge_call", _lib.FFMergeCall), ("ff_merge_result", _lib.FFMergeResult),
+                       ("ff_prune_call", _lib.FFPruneCall)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s_t;" % (cname, cname), text, flags=re.S).group(1)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            # "int64_t dtype, L, d" / "int32_t* order" / "ff_aux_t aux[FF_MAX_AUX]" / "const void* hidden"
+            first, *rest = decl.split(",")
+            names.append(re.findall(r"([A-Za-z_0-9]+)(?:\[[A-Z_]+\])?$", first.strip())[0])
+            names += [r.strip().lstrip("*") for r in rest]
+        assert names == [f[0] for f in cls._fields_], cname
+        for fname, ftype in cls._fields_:
+            assert C.sizeof(ftype) % 8 == 0, (cname, fname)
+    assert _lib.MERGE_CALL_HEAD.size == _lib.FFMergeCall.aux.offset == _lib.FFMergeCall.n_aux.offset + 8
+    assert _lib.FFMergeCall.hidden_out.offset == 16
+    assert _lib.MERGE_CALL_MASK_OFFSET == _lib.FFMergeCall.mask.offset
+    assert _lib.PRUNE_CALL_HEAD.size == _lib.FFPruneCall.aux.offset
+    assert _lib.PRUNE_CALL_MASK_OFFSET == _lib.FFPruneCall.mask.offset
+    assert _lib.MERGE_RESULT.size == C.sizeof(_lib.FFMergeResult)
+    assert _lib.AUX_ENTRY.size == C.sizeof(_lib.FFAux) == 32
+
+
+def test_context_calls_validate_before_any_hip_call():
+    lib = _lib.load()
+    ctx, call, res = _lib.FFCtx(), _lib.FFMergeCall(), _lib.FFMergeResult()
+    a = C.addressof
+    assert lib.ff_ctx_merge_begin(None, a(call)) == -1
+    assert lib.ff_ctx_merge_begin(a(ctx), None) == -1
+    assert lib.ff_ctx_merge_begin(a(ctx), a(call)) == -1           # a zeroed context names no scratch
+    assert lib.ff_ctx_merge_finish(a(ctx), a(call), None) == -1
+    for f in ("order", "order_next", "inv", "inv_next", "sim", "member", "dst", "keep", "stats", "stats_host", "ws"):
+        setattr(ctx, f, 4096)
+    ctx.cap = 1024
+    call.L = 2048
+    assert lib.ff_ctx_merge_begin(a(ctx), a(call)) == -1           # longer than the scratch
+    call.L = 512
+    assert lib.ff_ctx_merge_begin(a(ctx), a(call)) == -4           # workspace smaller than ff_workspace_bytes(cap)
+    ctx.ws_bytes = lib.ff_workspace_bytes(1024, 1)
+    assert lib.ff_ctx_merge_finish(a(ctx), a(call), a(res)) == _lib.ERR_STATE     # finish without begin
+    pc = _lib.FFPruneCall()
+    pc.S = 4096
+    assert lib.ff_ctx_prune(a(ctx), a(pc)) == -1
+    assert lib.ff_ctx_prune(a(ctx), None) == -1
+    assert lib.ff_ctx_reset(None, None) == -1
+    assert len(lib.ff_error_string(_lib.ERR_DEVICE)) > 4 and len(lib.ff_error_string(_lib.ERR_STATE)) > 4
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
