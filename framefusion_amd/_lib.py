@@ -194,13 +194,14 @@ def check(rc: int, what: str):
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
 
 
 def stream_ptr() -> int:
-    """hipStream_t of PyTorch's current stream on the current device (the raw getter is ~10x cheaper
+    """hipStream_t of PyTorch's current stream on the current device (the raw getters are ~10x cheaper
     than building a torch.cuda.Stream object; same value)."""
-    if _raw_stream is not None:
-        return _raw_stream(torch.cuda.current_device())
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 

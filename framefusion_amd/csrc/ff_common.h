@@ -235,6 +235,7 @@ __device__ inline int block_excl_scan(int v, int* scratch, int& total) {
 // values, kT16Copies copies of a 65536-bin table indexed by the key's top 16 bits, laid out DOWN from
 // the END of the workspace (slice g ends at ws_end - g * kT16SliceInts): both locations depend on
 // neither L nor the call, so "zero on entry" survives calls of different lengths.
+constexpr int kMaxDevices = 64;                   // host-side per-device caches (function attributes, occupancy)
 constexpr int kSelSlice = 4096;
 constexpr int kL0Copies = 16;
 constexpr int kL0Stride = 260;                    // 256 bins + count + pad

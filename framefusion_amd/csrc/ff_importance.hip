@@ -418,6 +418,147 @@ __global__ __launch_bounds__(256) void k_lq_mfma(const void* __restrict__ q, con
     }
 }
 
+// ---- k_lq_mfma2: the same scores with K staged through LDS ------------------------------------------------
+// k_lq_mfma above feeds the A operand straight from memory: lane (key, half) reads 16 bytes of ITS key's row,
+// so one wave-load touches 32 rows x 32 bytes - 32 cache lines for 1 KiB, every line visited by 4 different
+// instructions.  It ran at 3.1 TB/s (23 us for 72 MB at the 72B shape).  Here a wave streams its keys the way
+// they lie in memory - one wave-load = 1 KiB of CONTIGUOUS key rows, 16 bytes per lane - parks them in a
+// wave-private LDS buffer (no barrier: a wave's LDS operations execute in order) and reads the MFMA operand
+// back with ds_read_b128.  The LDS image of a key row is XOR-swizzled by the key index (16-byte chunk c of key
+// k sits at chunk c ^ swz(k)) so that the 16 lanes of a read phase - 16 different keys, same chunk - hit 16
+// different bank groups; writes (one key row = consecutive lanes) stay conflict-free under the same map.
+// A wave owns kLq2Sub sub-tiles of 32 keys (one MFMA block), the loads of sub-tile j + 1 in flight while j is
+// multiplied and rounded; softmax statistics are kept ONLINE per lane (running max, rescaled sum) over the
+// wave's keys and combined over the 4 waves at the end: one (max, sum) per row per 512-key tile - half the
+// statistics of the 256-key tiles above for the finish kernel to fold.
+constexpr int kLq2Sub = 4;                           // sub-tiles of 32 keys per wave
+constexpr int kLq2KeysPerWave = 32 * kLq2Sub;        // 128
+constexpr int kLq2Keys = 4 * kLq2KeysPerWave;        // 512 keys per workgroup = one statistics tile
+
+template <int CH> __device__ inline int lq_swz(int key) { return CH >= 16 ? (key & 15) : ((key >> 1) & (CH - 1)); }
+
+template <int DT, int NK>
+__global__ __launch_bounds__(256) void k_lq_mfma2(const void* __restrict__ q, const void* __restrict__ k, int H, int H_kv,
+                                                  int num, int S, float scale, int causal, int pitch,
+                                                  void* __restrict__ scores, float2* __restrict__ tstats, int tiles) {
+    using A = Act<DT>;
+    static_assert(A::kBytes == 2, "16-bit activations");
+    constexpr int kRowsPad = 32;
+    constexpr uint32_t row_bytes = NK * 32u;                          // dh * 2
+    constexpr int CH = NK * 2;                                        // 16-byte chunks per key row
+    constexpr int NL = NK;                                            // wave-loads (1 KiB each) per 32-key sub-tile
+    constexpr uint32_t sub_bytes = 32u * row_bytes;
+    __shared__ __attribute__((aligned(16))) unsigned char kbuf[4][sub_bytes];
+    __shared__ float2 wstat[4][kRowsPad];
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const int hk = blockIdx.y, group = H / H_kv, rows = group * num;
+    const int r0 = blockIdx.z * kRowsPad, rows_here = min(kRowsPad, rows - r0);
+    const int tile = blockIdx.x;
+    const int col = lane & 31, half = lane >> 5;
+    // B fragments: my query row's 8 values of every 16-dim step (zeros for the padding rows)
+    mfma_ab_t bfrag[NK];
+    {
+        const __amdgpu_buffer_rsrc_t qrs = make_rsrc((const char*)q + (size_t)(hk * rows + r0) * row_bytes,
+                                                     (uint32_t)rows_here * row_bytes);
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+            const uint4 v = buf_load16(qrs, (uint32_t)col * row_bytes + (uint32_t)kk * 32u + (uint32_t)half * 16u);
+            bfrag[kk] = __builtin_bit_cast(mfma_ab_t, v);
+        }
+    }
+    // this kv head's keys (2^31 bytes at most per head: checked by the launcher)
+    const __amdgpu_buffer_rsrc_t krs = make_rsrc((const char*)k + (size_t)hk * S * row_bytes, (uint32_t)S * row_bytes);
+    const int key_w = tile * kLq2Keys + w * kLq2KeysPerWave;           // first key of this wave
+    // where my 16 bytes of wave-load i go: linear offset i * 1024 + lane * 16 inside the sub-tile
+    uint32_t lds_off[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const uint32_t off = (uint32_t)i * 1024u + (uint32_t)lane * 16u;
+        const int kl = (int)(off / row_bytes), c = (int)((off % row_bytes) >> 4);
+        lds_off[i] = (uint32_t)kl * row_bytes + (uint32_t)((c ^ lq_swz<CH>(kl)) << 4);
+    }
+    unsigned char* mine = kbuf[w];
+    auto fetch = [&](uint4* dst, int j) {
+        const uint32_t base = (uint32_t)(key_w + j * 32) * row_bytes + (uint32_t)lane * 16u;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) dst[i] = buf_load16<2>(krs, base + (uint32_t)i * 1024u);        // keys past S: zeros
+    };
+    const int n = (r0 + col) % num;
+    float m_run = -INFINITY, e_run = 0.f;
+    auto consume = [&](const uint4* src, int j) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) *(uint4*)(mine + lds_off[i]) = src[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        mfma_cd_t acc;
+#pragma unroll
+        for (int x = 0; x < 16; ++x) acc[x] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+            const int c = kk * 2 + half;
+            const uint4 a = *(const uint4*)(mine + (uint32_t)col * row_bytes + (uint32_t)((c ^ lq_swz<CH>(col)) << 4));
+            if constexpr (DT == FF_BF16)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_ab_t, a), bfrag[kk], acc, 0, 0, 0);
+            else
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(__attribute__((ext_vector_type(8))) _Float16, a),
+                                                            __builtin_bit_cast(__attribute__((ext_vector_type(8))) _Float16, bfrag[kk]),
+                                                            acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();        // (the next sub-tile's writes come after these reads in program order)
+        // staged rounding + the causal bias; scores out as T, key-major
+        const int key0 = key_w + j * 32;
+        float v[16], m = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int s_key = key0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float x = A::rnd(acc[r]);
+            x = A::rnd(x * scale);
+            if (causal && s_key > S - num + n) x = A::rnd(x + (-INFINITY));
+            if (s_key >= S || col >= rows_here) x = -INFINITY;
+            else A::store1(scores, (int64_t)s_key * pitch + hk * rows + r0 + col, x);
+            v[r] = x;
+            m = fmaxf(m, x);
+        }
+        if (m > -INFINITY) {
+            const float mn = fmaxf(m_run, m);
+            float e = m_run > -INFINITY ? e_run * expf(m_run - mn) : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) e += expf(v[r] - mn);
+            m_run = mn;
+            e_run = e;
+        }
+    };
+    uint4 b0[NL], b1[NL];
+    fetch(b0, 0);
+#pragma unroll
+    for (int j = 0; j < kLq2Sub; j += 2) {
+        if (key_w + (j + 1) * 32 < S) fetch(b1, j + 1);
+        if (key_w + j * 32 < S) consume(b0, j);
+        if (j + 2 < kLq2Sub && key_w + (j + 2) * 32 < S) fetch(b0, j + 2);
+        if (key_w + (j + 1) * 32 < S) consume(b1, j + 1);
+    }
+    // the two halves of a column, then the four waves: (max, sum of exp relative to it) of the row over this tile
+    {
+        const float mo = __shfl_xor(m_run, 32, kWave), eo = __shfl_xor(e_run, 32, kWave);
+        const float mn = fmaxf(m_run, mo);
+        e_run = (m_run > -INFINITY ? e_run * expf(m_run - mn) : 0.f) + (mo > -INFINITY ? eo * expf(mo - mn) : 0.f);
+        m_run = mn;
+    }
+    if (half == 0) wstat[w][col] = make_float2(m_run, e_run);
+    __syncthreads();
+    if (tid < rows_here) {
+        float M = -INFINITY, sum = 0.f;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) M = fmaxf(M, wstat[x][tid].x);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const float2 ms = wstat[x][tid];
+            sum += ms.y > 0.f ? ms.y * expf(ms.x - M) : 0.f;
+        }
+        tstats[(size_t)(hk * rows + r0 + tid) * tiles + tile] = make_float2(M, sum);
+    }
+}
+
 // KG lanes share a key (each takes every KG-th 16-byte word of its score row): KG x the waves for the
 // exp / divide work, the partial means meet through DPP.
 template <int DT, int KG>
@@ -550,19 +691,18 @@ static int launch_lq(const void* q, const void* k, int64_t H, int64_t H_kv, int6
     const int pitch = (int)(pitch_bytes / kB);
     float2* tstats = (float2*)((char*)ws + S * pitch_bytes);
     if constexpr (kB == 2) {
-        // matrix-core scores for the head sizes of real models
-        const dim3 mgrid((unsigned)tiles, (unsigned)H_kv, (unsigned)((rows + 31) / 32));
-        bool done = true;
-#define FF_LQ_MFMA(NK)                                                                                                    \
-    hipLaunchKernelGGL((k_lq_mfma<DT, NK>), mgrid, dim3(256), 0, st, q, k, (int)H, (int)H_kv, (int)num, (int)S, (float)scale, \
-                       causal, pitch, scores, tstats, tiles)
-        if (dh == 64) FF_LQ_MFMA(4);
-        else if (dh == 128) FF_LQ_MFMA(8);
-        else if (dh == 256) FF_LQ_MFMA(16);
-        else done = false;
+        // matrix-core scores for the head sizes of real models (statistics per 512-key tile)
+        if ((dh == 64 || dh == 128 || dh == 256) && S * dh * kB < (1ll << 31)) {
+            const int tiles2 = (int)((S + kLq2Keys - 1) / kLq2Keys);
+            const dim3 mgrid((unsigned)tiles2, (unsigned)H_kv, (unsigned)((rows + 31) / 32));
+#define FF_LQ_MFMA(NK)                                                                                                     \
+    hipLaunchKernelGGL((k_lq_mfma2<DT, NK>), mgrid, dim3(256), 0, st, q, k, (int)H, (int)H_kv, (int)num, (int)S, (float)scale, \
+                       causal, pitch, scores, tstats, tiles2)
+            if (dh == 64) FF_LQ_MFMA(4);
+            else if (dh == 128) FF_LQ_MFMA(8);
+            else FF_LQ_MFMA(16);
 #undef FF_LQ_MFMA
-        if (done) {
-            return launch_lq_finish<DT>(scores, tstats, rows_total, pitch, tiles, S, weights, importance, lo, hi, l0, t16_end, st);
+            return launch_lq_finish<DT>(scores, tstats, rows_total, pitch, tiles2, S, weights, importance, lo, hi, l0, t16_end, st);
         }
     }
     const dim3 grid((unsigned)tiles, (unsigned)H_kv, (unsigned)((rows + kLqRows - 1) / kLqRows));

@@ -15,6 +15,8 @@
 // order with a rounding to the activation dtype T after EVERY add, then one rounded divide by
 // T(n+1) - the order CPU index_add_ applies; fp32-accumulate-then-round differs on ~23 % of
 // elements by more than 1e-3 relative.
+#include <atomic>
+
 #include "ff_common.h"
 
 namespace ff {
@@ -332,15 +334,22 @@ __global__ __launch_bounds__(256) void k_gather_mask(const char* __restrict__ ma
 //    A prime count staggers the workgroups over the frames whatever the frame count is.
 template <int DT, bool kAdd>
 static int merge_places() {
-    static const int places = [] {
-        int dev = 0, per_cu = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_merge_compact<DT, kAdd>, kMergeThreads, 0) != hipSuccess ||
-            per_cu < 1)
-            return 2048;
-        return per_cu * prop.multiProcessorCount;
-    }();
+    // workgroups of this instantiation the CURRENT device holds at once (cached per device: several
+    // replicas on several GPUs may share the process)
+    static std::atomic<int> cache[kMaxDevices];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 2048;
+    if (dev >= 0 && dev < kMaxDevices) {
+        const int got = cache[dev].load(std::memory_order_relaxed);
+        if (got > 0) return got;
+    }
+    int per_cu = 0, places = 2048;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_merge_compact<DT, kAdd>, kMergeThreads, 0) == hipSuccess &&
+        per_cu >= 1)
+        places = per_cu * prop.multiProcessorCount;
+    if (dev >= 0 && dev < kMaxDevices) cache[dev].store(places, std::memory_order_relaxed);
     return places;
 }
 static int merge_slots(int dtype, bool add, int64_t L, int ny) {

@@ -12,6 +12,8 @@
 // 64-token step from the duplicate fix-up (LDS atomics give unique but unordered slots).
 // When they fit beside the histograms, the bin ids of all positions are staged in LDS as uint16:
 // patch_type is then read once, coalesced, with all 16 waves' loads in flight together.
+#include <atomic>
+
 #include "ff_common.h"
 
 namespace ff {
@@ -350,15 +352,18 @@ extern "C" int ff_build_order(const int64_t* patch_type, int64_t L, int64_t patc
     const size_t lds = (size_t)n_seg * bins * sizeof(int) + fixed + (in_regs ? key_lds : 0);
     int seg_len = (int)((L + n_seg - 1) / n_seg);
     seg_len = (seg_len + ff::kWave - 1) / ff::kWave * ff::kWave;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the dynamic LDS limit is an attribute of the function ON a device: cached per device
+    static std::atomic<bool> attr_set[ff::kMaxDevices];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ff::kMaxDevices) dev = -1;
+    if (dev < 0 || !attr_set[dev].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute((const void*)ff::k_build_order<true>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)ff::k_build_order<false>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        if (dev >= 0) attr_set[dev].store(true, std::memory_order_release);
     }
     // pass 1 (slice facts) + pass 2 (closed form on every workgroup, or the sort on workgroup 0)
     ff::OrderRow* rows = (ff::OrderRow*)((char*)ws + ff::plan_ws_front_bytes(L));

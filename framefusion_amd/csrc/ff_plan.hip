@@ -26,6 +26,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "ff_common.h"
 
 namespace ff {
@@ -630,7 +632,7 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan(
     }
 }
 
-// ---- k_plan_fast: the same plan for 16-bit values of at most 65 536 tokens ------------------------------
+// ---- k_plan_fast: the same plan for 16-bit values of at most 163 840 tokens -----------------------------
 // The general kernel above is bound by instruction issue (16 waves on one CU walk ~2 500 instructions
 // each: register-chunk selection, shuffle scans through LDS, divergent branches).  Here a workgroup of
 // kFastThreads threads owns kFastThreads slots and as many positions - ONE of each per thread, loaded in
@@ -645,10 +647,11 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan(
 #endif
 constexpr int kFastThreads = FF_FAST_THREADS;
 constexpr int kFastSpan = kFastThreads;            // slots / positions per workgroup
-constexpr int kFastMaxL = 65536;                   // kRowSlicesLds slices
+constexpr int kFastSlicesBig = 40;                 // second instantiation: 40 slices = 163 840 tokens (256 frames x 576 = 147 456)
+constexpr int kFastMaxL = kFastSlicesBig * 4096;   // (the level-1 rows of every slice sit in LDS: 16 or 40 KB per workgroup)
 constexpr int kTiePer = kSelSlice / kFastThreads;  // slots per thread in the tie-slot search
 
-template <int DT>
+template <int DT, int RS>
 __global__ __launch_bounds__(kFastThreads) void k_plan_fast(
     const void* __restrict__ values, int cap, PlanParams pp, const int* __restrict__ l0, int* t16_end,
     int64_t* __restrict__ stats, const int32_t* __restrict__ inv, int L,
@@ -656,11 +659,11 @@ __global__ __launch_bounds__(kFastThreads) void k_plan_fast(
     unsigned long long* agg, uint32_t* tagword, int64_t* host_mapped, int64_t seq) {
     using A = Act<DT>;
     static_assert(A::kBytes == 2, "16-bit values only");
-    constexpr int NW = kFastThreads / kWave, NQ = kFastThreads / 256, kSpec = kRowSlicesLds / NQ;
+    constexpr int NW = kFastThreads / kWave, NQ = kFastThreads / 256, kSpec = RS / NQ;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    int (*rows)[256] = (int (*)[256])lds_raw;                                  // [kRowSlicesLds][256] level-1 rows
-    int (*part)[256] = (int (*)[256])(lds_raw + kRowSlicesLds * 256 * 4);       // [NQ][256] partial column sums
-    int* scratch = (int*)(lds_raw + (kRowSlicesLds + NQ) * 256 * 4);           // [2 * NW]
+    int (*rows)[256] = (int (*)[256])lds_raw;                                  // [RS][256] level-1 rows
+    int (*part)[256] = (int (*)[256])(lds_raw + RS * 256 * 4);       // [NQ][256] partial column sums
+    int* scratch = (int*)(lds_raw + (RS + NQ) * 256 * 4);           // [2 * NW]
     int* bcast = scratch + 2 * NW;                                              // [16]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = tid & 255, q = tid >> 8;
     const int i0 = blockIdx.x * kFastSpan + tid;        // my position and my slot
@@ -819,7 +822,8 @@ __global__ __launch_bounds__(kFastThreads) void k_plan_fast(
             pick(bcast[4], p1, above);
             const int rem = bcast[4] - above;
             // the slice that holds the rem-th entry equal to the k-th key (entries per slice = rows[g][p1])
-            const int ties = lane < kRowSlicesLds ? rows[lane][p1] : 0;
+            static_assert(RS <= kWave, "one lane per slice in the tie-slice search");
+            const int ties = lane < RS ? rows[lane][p1] : 0;
             const int tincl = wave_incl_scan_dpp(ties);
             const int hit = __ffsll((long long)__ballot(tincl >= rem)) - 1;
             const int before_hit = __builtin_amdgcn_readlane(tincl - ties, hit);
@@ -1102,17 +1106,27 @@ static int launch_plan(const void* values, PlanParams pp, bool have_tables, int6
                            (const int64_t*)stats, (const int*)l0, t16_end, lv);
     if constexpr (kLevels == 2) {
         if (L <= kFastMaxL) {
-            static bool attr_set[3] = {false, false, false};
-            const size_t lds = (size_t)(kRowSlicesLds + kFastThreads / 256) * 256 * 4 + (2 * (kFastThreads / kWave) + 16) * 4;
-            if (!attr_set[DT]) {
-                hipError_t e = hipFuncSetAttribute((const void*)k_plan_fast<DT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                   156 * 1024);
+            // per-device, per-instantiation: the dynamic LDS limit is an attribute of the function ON a device
+            static std::atomic<bool> attr_set[kMaxDevices][3][2];
+            const bool big = L > (int64_t)kRowSlicesLds * kSelSlice;
+            const int rs = big ? kFastSlicesBig : kRowSlicesLds;
+            const size_t lds = (size_t)(rs + kFastThreads / 256) * 256 * 4 + (2 * (kFastThreads / kWave) + 16) * 4;
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = -1;
+            if (dev < 0 || !attr_set[dev][DT][big].load(std::memory_order_acquire)) {
+                const void* fn = big ? (const void*)k_plan_fast<DT, kFastSlicesBig> : (const void*)k_plan_fast<DT, kRowSlicesLds>;
+                hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
                 if (e != hipSuccess) return (int)e;
-                attr_set[DT] = true;
+                if (dev >= 0) attr_set[dev][DT][big].store(true, std::memory_order_release);
             }
-            hipLaunchKernelGGL(k_plan_fast<DT>, dim3(cdiv(L, kFastSpan)), dim3(kFastThreads), lds, st, values, (int)cap, pp,
-                               (const int*)l0, t16_end, stats, inv, (int)L, member, keep, dst, ws_agg(ws), ws_tag(ws),
-                               host_mapped, seq);
+            if (big)
+                hipLaunchKernelGGL((k_plan_fast<DT, kFastSlicesBig>), dim3(cdiv(L, kFastSpan)), dim3(kFastThreads), lds, st, values,
+                                   (int)cap, pp, (const int*)l0, t16_end, stats, inv, (int)L, member, keep, dst, ws_agg(ws),
+                                   ws_tag(ws), host_mapped, seq);
+            else
+                hipLaunchKernelGGL((k_plan_fast<DT, kRowSlicesLds>), dim3(cdiv(L, kFastSpan)), dim3(kFastThreads), lds, st, values,
+                                   (int)cap, pp, (const int*)l0, t16_end, stats, inv, (int)L, member, keep, dst, ws_agg(ws),
+                                   ws_tag(ws), host_mapped, seq);
             int rc0 = (int)hipGetLastError();
             if (rc0) return rc0;
             if (!have_tables) return zero_tables(ws, ws_bytes, L, st);

@@ -380,11 +380,13 @@ class FrameFusion(nn.Module):
             addend_ptr = addend.data_ptr()
 
         ptype = self.patch_type
-        if ptype.device != device or ptype.dtype != torch.int64 or not ptype.is_contiguous():
-            ptype = ptype.to(device=device, dtype=torch.int64).contiguous()
-            self.patch_type = ptype
-        if ptype.numel() != L:
-            raise FrameFusionHipError(f"patch_type has {ptype.numel()} entries for a sequence of {L}")
+        if self.__dict__.get("_ptype_checked") != (self._ptype_gen, L, device):
+            if ptype.device != device or ptype.dtype != torch.int64 or not ptype.is_contiguous():
+                ptype = ptype.to(device=device, dtype=torch.int64).contiguous()
+                self.patch_type = ptype
+            if ptype.numel() != L:
+                raise FrameFusionHipError(f"patch_type has {ptype.numel()} entries for a sequence of {L}")
+            self._ptype_checked = (self._ptype_gen, L, device)
 
         sub = self._compute_pruning_ratio(self.sparsity_list, self.cost)           # main.py:109
         sc, stream = self._scratch_for(device, L)

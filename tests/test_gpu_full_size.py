@@ -255,3 +255,30 @@ def test_merge_workgroup_slot_counts(frames):
     assert ho.shape[1] < L
     assert torch.equal(pg.cpu(), po)
     assert same_bits(hg.cpu(), ho)
+
+
+@pytest.mark.parametrize("F,P,pre,post", [(128, 576, 14, 20),          # Qwen2-VL example length (BASELINE configs[2]): 73 762
+                                          (256, 576, 14, 20),          # 147 490: the largest the fast plan kernel is sized for
+                                          (128, 512, 0, 0),            # 65 536 exactly: last length of the 16-slice instantiation
+                                          (128, 512, 1, 0),            # 65 537: first of the 40-slice one
+                                          (320, 512, 0, 0),            # 163 840: its last
+                                          (320, 512, 0, 1)])           # 163 841: first of the general plan kernel
+@pytest.mark.parametrize("p_change", [0.2, 0.55])
+def test_plan_kernel_size_classes(F, P, pre, post, p_change):
+    """The plan kernel comes in three size classes (ff_plan.hip: k_plan_fast with 16 or 40 slices of level-1 rows in
+    LDS, k_plan beyond 163 840 tokens).  A whole cascade (top-k regime, and threshold regime + prune) on either
+    side of every boundary and at 128 / 256 frames x 576 tokens, bit-exact against the oracle on the dyadic grid."""
+    d = 128
+    h, pt = video_tokens(F, P, d, p_change=p_change, sigma=0.3, sigma_hi=1.6, seed=F + pre, pre=pre, post=post, grid=0.125)
+    L = h.shape[1]
+    assert L == pre + F * P + post
+    want, _ = harness.run_cascade(orc.OracleFrameFusion(0.3, 0.6, 0.1), h.clone(), pt.clone(), P,
+                                  torch.arange(L)[None], None, layers=3, heads=2, num=1, start=pre, n_visual=F * P)
+    got, _ = harness.run_cascade(ffa.FrameFusion(0.3, 0.6, 0.1), h.to(DEV), pt.to(DEV), P,
+                                 torch.arange(L, device=DEV)[None], None, layers=3, heads=2, num=1, start=pre, n_visual=F * P)
+    assert len(got) == len(want) and got[-1]["finish_merging"]
+    for a, b in zip(got, want):
+        assert (a["tag"], a["length"], a["finish_merging"], a["finish_pruning"], a["sparsity"]) == \
+               (b["tag"], b["length"], b["finish_merging"], b["finish_pruning"], b["sparsity"]), a["tag"]
+        assert torch.equal(a["pos"].cpu(), b["pos"]), a["tag"]
+        assert same_bits(a["hidden"].cpu(), b["hidden"]), a["tag"]
