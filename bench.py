@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--oversubscribe", action="store_true",
                     help="allow more ranks than GPUs (rank r -> GPU r %% device_count; gloo only: RCCL refuses two ranks "
                          "on one device) - exercises the N > 1 path on a 1-GPU box")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="form the process group even for one rank: the broadcast / all_gather / all_reduce of the report then "
+                         "run through the backend (RCCL) on a 1-GPU box")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip cpu_baseline and eager_gpu_baseline")
     ap.add_argument("--no-extra", action="store_true", help="skip extra.configs (C3 / C5 / 7B shape)")
     ap.add_argument("--cpu-calls", type=int, default=5)
@@ -90,7 +93,9 @@ def main():
         sys.exit(2)
     dev = torch.device("cuda", local % n_dev)
     torch.cuda.set_device(dev)
-    dist = dp.init(args.backend, dev)
+    if args.force_dist and world == 1:
+        os.environ.setdefault("MASTER_PORT", str(dp.free_port()))
+    dist = dp.init(args.backend, dev, force=args.force_dist)
     # rank 0's workload description is THE workload: broadcast over RCCL before anything is generated
     cfg = dp.broadcast_config(dist, dict(seed=args.seed, frames=args.frames, patches=args.patches, dim=args.dim,
                                          p_change=args.p_change, steps=args.steps, warmup=args.warmup), dev)
@@ -135,6 +140,7 @@ def main():
         achieved = alg[dominant] / (dense_us * 1e-6) / 1e9
         ms_per_step = t_max / args.steps * 1e3
         headline = (F, P, d) == (FRAMES, PATCHES, DIM)
+        traffic, traffic_source = profiled_traffic(dominant) if headline else (None, None)
         result = {
             "metric": BASELINE_METRIC,
             "value": tok_all / t_max,
@@ -161,7 +167,7 @@ def main():
                        "parallelism": f"dp{world} (independent samples)"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": profiled_traffic(dominant) if headline else None,
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes": alg[dominant], "kernel_us": dense_us,
                          "kernel_us_own_event_pair": kernel_us[dominant]},
             "kernels_us": kernel_us,
@@ -169,7 +175,17 @@ def main():
                               "frac": alg["step"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
         if world == 1 and headline and not args.no_extra:
-            result["extra"] = {"configs": extra_configs(dev)}
+            # the same step with prepare() fed the way the reference's packers do it: start / end index as 1-element
+            # DEVICE tensors (llava_video/modeling_llava_video.py:332-333), read back once inside prepare()
+            start_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+            end_dev = start_dev + L - 1
+
+            def step_packer():
+                flip[0] ^= 1
+                ff.prepare(ptype, P, start_dev, end_dev, L, L)
+                return ff(hidden_alt if flip[0] else hidden, [cos, sin], None)[0]
+            result["extra"] = {"packer_scalars_step_us": step_spread(step_packer, 40), "configs": extra_configs(dev)}
+            assert ff.last_call["L_out"] == L_out
         if not args.no_cpu_baseline and world == 1:         # reported at N = 1 only (other ranks would wait)
             result["cpu_baseline"], result["eager_gpu_baseline"] = baselines(hidden, ptype, cos, sin, P, L, L_out,
                                                                               args.cpu_calls, ms_per_step)
@@ -271,24 +287,38 @@ def stage_times(ff, _lib, hidden, hidden_alt, ptype, cos, sin, P, L, d, info, de
 
 
 def profiled_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/rNN_pmc_*):
-    2 x FETCH_SIZE (gfx950 counts 64 B per 128-B request for 16 B/lane streams, MI355X_MICROARCH.md
-    section HBM) + WRITE_SIZE, both reported in KiB.  None when no profile is committed."""
+    """(bytes, source): HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/rNN_pmc_*):
+    2 x FETCH_SIZE (gfx950 counts 64 B per 128-B request for 16 B/lane streams, MI355X_MICROARCH.md section HBM) +
+    WRITE_SIZE, both reported in KiB.  The passes are separate rocprofv3 runs (tools/prof_round.sh), not this run:
+    `source` names the files and the build they profiled (profiles/rNN_pmc_meta.json: hash of the kernel sources,
+    commit); when that build is not the one running now the number is withheld (None) instead of reported stale."""
     import glob
+    from framefusion_amd import _lib
     pat = {"merge_compact": "k_merge_compact", "similarity": "k_pair_similarity"}[kernel]
+    metas = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_meta.json")))
+    if not metas:
+        return None, {"error": "no profiles/r*_pmc_meta.json (run tools/prof_round.sh)"}
+    meta = json.load(open(metas[-1]))
+    tag = os.path.basename(metas[-1]).split("_pmc_meta")[0]
+    source = {"files": [f"profiles/{tag}_pmc_fetch_summary.csv", f"profiles/{tag}_pmc_write_summary.csv"],
+              "profiled_source_hash": meta.get("source_hash"), "profiled_commit": meta.get("commit"),
+              "running_source_hash": _lib.source_hash()}
+    if meta.get("source_hash") != _lib.source_hash():
+        source["stale"] = "the kernel sources changed since the PMC passes: traffic withheld"
+        return None, source
     total = 0.0
     for kind, scale in (("fetch", 2.0), ("write", 1.0)):
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{kind}_summary.csv")))
-        if not files:
-            return None
+        path = os.path.join(ROOT, "profiles", f"{tag}_pmc_{kind}_summary.csv")
+        if not os.path.exists(path):
+            return None, source
         val = None
-        for line in open(files[-1]):
+        for line in open(path):
             if pat in line:
                 val = float(line.strip().split(",")[-1])
         if val is None:
-            return None
+            return None, source
         total += scale * val * 1024.0
-    return total
+    return total, source
 
 
 def cascade(ffa, dev, F, P, d, p_change, thr, pre, post, heads, kv_heads, num, mrope, sigma_hi=1.6, reps=6, seed=1234):
@@ -307,12 +337,11 @@ def cascade(ffa, dev, F, P, d, p_change, thr, pre, post, heads, kv_heads, num, m
     elt, pe_outer = 2, (3 if mrope else 1)
     times, calls, bytes_alg = [], [], 0
     k_of = {L: k_full}                              # the layer's keys at the current sequence length
-    for rep in range(reps + 2):
+    def one_prefill():
+        nonlocal calls, bytes_alg
         ff.prepare(pt, P, pre, pre + F * P - 1, F * P, L)
         h, pe = h0, [t for t in pe0]
         calls, bytes_alg = [], 0
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
         while not (ff.finish_merging and ff.finish_pruning) and len(calls) < 30:
             n_in = h.shape[1]
             w = None
@@ -324,14 +353,30 @@ def cascade(ffa, dev, F, P, d, p_change, thr, pre, post, heads, kv_heads, num, m
             h, pe, _ = ff(h, pe, None, w)
             calls.append((ff.last_call["kind"], n_in, h.shape[1]))
             bytes_alg += merge_bytes(n_in, h.shape[1], d, elt, HEAD_DIM, pe_outer)
+
+    for rep in range(reps + 2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        one_prefill()
         torch.cuda.synchronize()
         if rep >= 2:
             times.append((time.perf_counter() - t0) * 1e6)
+    # the same cascade issued back to back (no idle GPU in front of a call, no drain behind it): what a prefill pays
+    # when the calls sit between other kernels of the model
+    n_b2b = 4 * reps
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_b2b):
+        one_prefill()
+    torch.cuda.synchronize()
+    us_b2b = (time.perf_counter() - t0) * 1e6 / n_b2b
     us = statistics.median(times)
     L_final = calls[-1][2]
     return {"tokens_in": L, "tokens_out": L_final, "calls": [f"{k}:{a}->{b}" for k, a, b in calls], "us": us,
+            "us_back_to_back": us_b2b,
             "tokens_reduced_per_s": (L - L_final) / (us * 1e-6), "algorithmic_bytes": bytes_alg,
-            "hbm_frac": bytes_alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+            "hbm_frac": bytes_alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "hbm_frac_back_to_back": bytes_alg / (us_b2b * 1e-6) / 1e9 / HBM_PEAK_GBS}
 
 
 def extra_configs(dev):

@@ -103,6 +103,7 @@ _vp, _i64, _i32, _f64, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_siz
 # name -> (restype, argtypes); mirrors include/framefusion_hip.h one to one
 PROTOTYPES = {
     "ff_abi_version": (C.c_int, []),
+    "ff_source_hash": (C.c_char_p, []),
     "ff_error_string": (C.c_char_p, [_i32]),
     "ff_workspace_bytes": (_sz, [_i64, _i64]),
     "ff_build_order": (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -112,9 +113,11 @@ PROTOTYPES = {
     "ff_plan_prune": (_i32, [_vp, _i32, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ff_merge_compact": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _vp, _i32, _vp, _vp, C.POINTER(FFAux), _i32,
                                 _vp]),
-    "ff_gather_mask": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "ff_gather_mask": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "ff_gather_tokens_by_index": (_i32, [_vp, _i64, _i64, C.POINTER(FFAux), _i32, _vp]),
+    "ff_gather_tokens_by_mask": (_i32, [_vp, _i64, _i64, _vp, _vp, C.POINTER(FFAux), _i32, _vp]),
     "ff_head_mean": (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _vp]),
-    "ff_last_query_attention": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _i64, _i64, _f64, _i32, _vp, _vp, _i64, _i64,
+    "ff_last_query_attention": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _i64, _i64, _f64, _i32, _vp, _vp, _vp, _i64, _i64,
                                        _vp, _sz, _vp, _sz, _vp]),
     "ff_last_query_workspace_bytes": (_sz, [_i32, _i64, _i64, _i64, _i64]),
     "ff_merge_begin": (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _i64, _i32, _f64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _sz,
@@ -143,18 +146,53 @@ PROTOTYPES = {
 _lib = None
 
 
-def build(verbose: bool = False) -> str:
-    """Compile the HIP sources in csrc/ for gfx950 (hipcc cross-compiles without a GPU)."""
+HASHED_SOURCES = ("ff_abi.hip", "ff_order.hip", "ff_similarity.hip", "ff_plan.hip", "ff_merge.hip", "ff_importance.hip",
+                  "ff_layout.hip", "ff_common.h", "../../include/framefusion_hip.h", "Makefile")
+
+
+def source_hash() -> str:
+    """What csrc/Makefile bakes into the library as ff_source_hash(): the first 16 hex digits of the SHA-256 over
+    the sources, concatenated in the order `$(sort ...)` gives them.  None when the sources are not there."""
+    import hashlib
+    h = hashlib.sha256()
+    try:
+        for name in sorted(HASHED_SOURCES):
+            with open(os.path.join(CSRC, name), "rb") as f:
+                h.update(f.read())
+    except OSError:
+        return None
+    return h.hexdigest()[:16]
+
+
+def build(verbose: bool = False, force: bool = False) -> str:
+    """Compile the HIP sources in csrc/ for gfx950 (hipcc cross-compiles without a GPU).  `force`: recompile every
+    file (`make -B`) - what __graft_entry__.build() does, so that "it built" means "these sources compile"."""
     if not os.path.isdir(CSRC):
         raise FrameFusionHipError(f"{CSRC} not found")
-    res = subprocess.run(["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 1))],
-                         capture_output=True, text=True)
+    cmd = ["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 1))] + (["-B"] if force else [])
+    res = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or res.returncode:
         print(res.stdout[-4000:])
         print(res.stderr[-4000:])
     if res.returncode:
         raise FrameFusionHipError("building libframefusion_hip.so failed (see output above)")
     return LIB_PATH
+
+
+def _open_checked():
+    """CDLL of the in-tree library, after checking that it was built from the sources that sit next to it."""
+    lib = C.CDLL(LIB_PATH)
+    want = source_hash()
+    if want is not None:
+        try:
+            fn = lib.ff_source_hash
+            fn.restype = C.c_char_p
+            got = fn().decode()
+        except AttributeError:
+            got = "(a library from before the stamp)"
+        if got != want:
+            return None, got, want
+    return lib, None, want
 
 
 def load():
@@ -170,7 +208,14 @@ def load():
                 f"{LIB_PATH} is missing and could not be built ({e}): run `python -c 'import __graft_entry__ as g; "
                 f"g.build()'` (or `make -C {CSRC}`). framefusion_amd has no CPU/eager fallback.") from e
     try:
-        lib = C.CDLL(LIB_PATH)
+        lib, got, want = _open_checked()
+        if lib is None:
+            # a stale binary (sources edited since it was built): rebuild once, never run it
+            build()
+            lib, got, want = _open_checked()
+            if lib is None:
+                raise FrameFusionHipError(f"{LIB_PATH} was built from other sources (its stamp {got}, the sources' {want}) "
+                                          f"and rebuilding did not change that")
     except OSError as e:  # pragma: no cover
         raise FrameFusionHipError(f"cannot load {LIB_PATH}: {e}") from e
     for name, (res, args) in PROTOTYPES.items():

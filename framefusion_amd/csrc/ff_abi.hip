@@ -2,6 +2,7 @@
 // K0 -> K1 -> K2+K3 -> K4 from a single host call (one FrameFusion.forward merge call,
 // framefusion/main.py:104-138).
 #include "ff_common.h"
+#include "ff_source_hash.h"
 
 namespace ff {
 int launch_plan_merge(const void* sim, int dtype, const int32_t* order, const int32_t* inv, int64_t L, double thr,
@@ -13,6 +14,7 @@ int launch_plan_prune(const void* imp, int dtype, int64_t S, int64_t start, int6
                       bool have_tables, hipStream_t st);
 size_t plan_ws_front_bytes(int64_t L);
 size_t plan_ws_tail_bytes(int64_t L);
+int32_t* ws_scratch_ints(void* ws, int64_t L);
 int* ws_l0(void* ws);
 int* ws_t16_end(void* ws, size_t ws_bytes);
 void table_regions(void* ws, size_t ws_bytes, int64_t L, void** a, size_t* a_bytes, void** b, size_t* b_bytes);
@@ -30,6 +32,7 @@ int launch_head_mean(const void* attn_w, int dtype, int64_t H, int64_t num, int6
 }  // namespace ff
 
 extern "C" int ff_abi_version(void) { return FF_ABI_VERSION; }
+extern "C" const char* ff_source_hash(void) { return FF_SOURCE_HASH; }
 
 extern "C" const char* ff_error_string(int code) {
     switch (code) {
@@ -298,7 +301,9 @@ static int ctx_finish_enqueue(ff_ctx_t* c, const ff_merge_call_t* a) {
                           c->inv_next, c->ws, c->ws_bytes, a->stream);
     if (rc) return rc;
     c->dirty = 0;
-    if (a->mask) rc = ff_gather_mask(a->mask, a->mask_out, a->mask_elem_bytes, a->L, a->L_cap, c->dst, a->stream);
+    if (a->mask)
+        rc = ff_gather_mask(a->mask, a->mask_out, a->mask_elem_bytes, a->L, a->L_cap, c->dst, c->stats,
+                            ff::ws_scratch_ints(c->ws, c->cap), a->stream);
     return rc;
 }
 
@@ -376,6 +381,8 @@ extern "C" int ff_ctx_prune(ff_ctx_t* c, const ff_prune_call_t* a) {
                        c->stats, a->aux, (int)a->n_aux, c->ws, c->ws_bytes, a->stream);
     if (rc) return rc;
     c->dirty = 0;
-    if (a->mask) rc = ff_gather_mask(a->mask, a->mask_out, a->mask_elem_bytes, a->S, a->L_cap, c->dst, a->stream);
+    if (a->mask)
+        rc = ff_gather_mask(a->mask, a->mask_out, a->mask_elem_bytes, a->S, a->L_cap, c->dst, c->stats,
+                            ff::ws_scratch_ints(c->ws, c->cap), a->stream);
     return rc;
 }

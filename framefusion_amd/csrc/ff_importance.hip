@@ -23,7 +23,7 @@ constexpr int kRowsPerBlock = 8;
 template <int DT>
 __global__ __launch_bounds__(256) void k_lq_scores(const void* __restrict__ q, const void* __restrict__ k,
                                                    int H, int H_kv, int num, int S, int dh, float scale,
-                                                   int causal, float* __restrict__ scores) {
+                                                   int causal, const void* __restrict__ bias, float* __restrict__ scores) {
     using A = Act<DT>;
     constexpr int E = A::kPer16;
     extern __shared__ __attribute__((aligned(16))) float q_lds[];   // [rows_here][dh]
@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256) void k_lq_scores(const void* __restrict__ q, c
             float v = A::rnd(acc[r]);
             v = A::rnd(v * scale);
             if (causal && s > S - num + n) v = A::rnd(v + (-INFINITY));
+            if (bias) v = A::rnd(v + A::load1(bias, (int64_t)n * S + s));
             scores[((int64_t)h * num + n) * S + s] = v;
         }
     }
@@ -255,7 +256,7 @@ __device__ inline float group_sum(float v) {
 
 template <int DT, int LPK>
 __global__ __launch_bounds__(256) void k_lq_tile(const void* __restrict__ q, const void* __restrict__ k, int H, int H_kv,
-                                                 int num, int S, float scale, int causal, int pitch,
+                                                 int num, int S, float scale, int causal, const void* __restrict__ bias, int pitch,
                                                  void* __restrict__ scores, float2* __restrict__ tstats, int tiles) {
     using A = Act<DT>;
     constexpr int KPW = kWave / LPK;                 // keys per wave-load
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(256) void k_lq_tile(const void* __restrict__ q, con
                 float v = A::rnd(sc[tid][r]);
                 v = A::rnd(v * scale);
                 if (causal && s_key > S - num + n) v = A::rnd(v + (-INFINITY));
+                if (bias) v = A::rnd(v + A::load1(bias, (int64_t)n * S + s_key));
                 sc[tid][r] = v;
                 A::store1(scores, (int64_t)s_key * pitch + hk * rows + r0 + r, v);
             }
@@ -330,14 +332,14 @@ __global__ __launch_bounds__(256) void k_lq_tile(const void* __restrict__ q, con
 typedef short mfma_ab_t __attribute__((ext_vector_type(8)));
 typedef float mfma_cd_t __attribute__((ext_vector_type(16)));
 
-template <int DT, int NK>
-__global__ __launch_bounds__(256) void k_lq_mfma(const void* __restrict__ q, const void* __restrict__ k, int H, int H_kv,
-                                                 int num, int S, float scale, int causal, int pitch,
+template <int DT, int NK, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_lq_mfma(const void* __restrict__ q, const void* __restrict__ k, int H, int H_kv,
+                                                 int num, int S, float scale, int causal, const void* __restrict__ bias, int pitch,
                                                  void* __restrict__ scores, float2* __restrict__ tstats, int tiles) {
     using A = Act<DT>;
     static_assert(A::kBytes == 2, "16-bit activations");
     constexpr int kRowsPad = 32;
-    __shared__ float2 wstat[4][kRowsPad];
+    __shared__ float2 wstat[WAVES][kRowsPad];
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     const int hk = blockIdx.y, group = H / H_kv, rows = group * num;
     const int r0 = blockIdx.z * kRowsPad, rows_here = min(kRowsPad, rows - r0);
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(256) void k_lq_mfma(const void* __restrict__ q, con
         }
     }
     const __amdgpu_buffer_rsrc_t krs = make_rsrc((const char*)k + (size_t)hk * S * row_bytes, (uint32_t)S * row_bytes);
-    const int key0 = tile * kLqKeys + w * 64;
+    const int key0 = tile * (64 * WAVES) + w * 64;
     mfma_cd_t acc[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -388,6 +390,7 @@ __global__ __launch_bounds__(256) void k_lq_mfma(const void* __restrict__ q, con
             float x = A::rnd(acc[b][r]);
             x = A::rnd(x * scale);
             if (causal && s_key > S - num + n) x = A::rnd(x + (-INFINITY));
+            if (bias && s_key < S) x = A::rnd(x + A::load1(bias, (int64_t)n * S + s_key));
             if (s_key >= S || col >= rows_here) x = -INFINITY;
             else A::store1(scores, (int64_t)s_key * pitch + hk * rows + r0 + col, x);
             v[b][r] = x;
@@ -408,9 +411,9 @@ __global__ __launch_bounds__(256) void k_lq_mfma(const void* __restrict__ q, con
     if (tid < rows_here) {
         float M = -INFINITY, sum = 0.f;
 #pragma unroll
-        for (int x = 0; x < 4; ++x) M = fmaxf(M, wstat[x][tid].x);
+        for (int x = 0; x < WAVES; ++x) M = fmaxf(M, wstat[x][tid].x);
 #pragma unroll
-        for (int x = 0; x < 4; ++x) {
+        for (int x = 0; x < WAVES; ++x) {
             const float2 ms = wstat[x][tid];
             sum += ms.y > 0.f ? ms.y * expf(ms.x - M) : 0.f;
         }
@@ -418,149 +421,6 @@ __global__ __launch_bounds__(256) void k_lq_mfma(const void* __restrict__ q, con
     }
 }
 
-// ---- k_lq_mfma2: the same scores with K staged through LDS ------------------------------------------------
-// k_lq_mfma above feeds the A operand straight from memory: lane (key, half) reads 16 bytes of ITS key's row,
-// so one wave-load touches 32 rows x 32 bytes - 32 cache lines for 1 KiB, every line visited by 4 different
-// instructions.  It ran at 3.1 TB/s (23 us for 72 MB at the 72B shape).  Here a wave streams its keys the way
-// they lie in memory - one wave-load = 1 KiB of CONTIGUOUS key rows, 16 bytes per lane - parks them in a
-// wave-private LDS buffer (no barrier: a wave's LDS operations execute in order) and reads the MFMA operand
-// back with ds_read_b128.  The LDS image of a key row is XOR-swizzled by the key index (16-byte chunk c of key
-// k sits at chunk c ^ swz(k)) so that the 16 lanes of a read phase - 16 different keys, same chunk - hit 16
-// different bank groups; writes (one key row = consecutive lanes) stay conflict-free under the same map.
-// A wave owns kLq2Sub sub-tiles of 32 keys (one MFMA block), the loads of sub-tile j + 1 in flight while j is
-// multiplied and rounded; softmax statistics are kept ONLINE per lane (running max, rescaled sum) over the
-// wave's keys and combined over the 4 waves at the end: one (max, sum) per row per 512-key tile - half the
-// statistics of the 256-key tiles above for the finish kernel to fold.
-constexpr int kLq2Sub = 4;                           // sub-tiles of 32 keys per wave
-constexpr int kLq2KeysPerWave = 32 * kLq2Sub;        // 128
-constexpr int kLq2Keys = 4 * kLq2KeysPerWave;        // 512 keys per workgroup = one statistics tile
-
-template <int CH> __device__ inline int lq_swz(int key) { return CH >= 16 ? (key & 15) : ((key >> 1) & (CH - 1)); }
-
-template <int DT, int NK>
-__global__ __launch_bounds__(256) void k_lq_mfma2(const void* __restrict__ q, const void* __restrict__ k, int H, int H_kv,
-                                                  int num, int S, float scale, int causal, int pitch,
-                                                  void* __restrict__ scores, float2* __restrict__ tstats, int tiles) {
-    using A = Act<DT>;
-    static_assert(A::kBytes == 2, "16-bit activations");
-    constexpr int kRowsPad = 32;
-    constexpr uint32_t row_bytes = NK * 32u;                          // dh * 2
-    constexpr int CH = NK * 2;                                        // 16-byte chunks per key row
-    constexpr int NL = NK;                                            // wave-loads (1 KiB each) per 32-key sub-tile
-    constexpr uint32_t sub_bytes = 32u * row_bytes;
-    __shared__ __attribute__((aligned(16))) unsigned char kbuf[4][sub_bytes];
-    __shared__ float2 wstat[4][kRowsPad];
-    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
-    const int hk = blockIdx.y, group = H / H_kv, rows = group * num;
-    const int r0 = blockIdx.z * kRowsPad, rows_here = min(kRowsPad, rows - r0);
-    const int tile = blockIdx.x;
-    const int col = lane & 31, half = lane >> 5;
-    // B fragments: my query row's 8 values of every 16-dim step (zeros for the padding rows)
-    mfma_ab_t bfrag[NK];
-    {
-        const __amdgpu_buffer_rsrc_t qrs = make_rsrc((const char*)q + (size_t)(hk * rows + r0) * row_bytes,
-                                                     (uint32_t)rows_here * row_bytes);
-#pragma unroll
-        for (int kk = 0; kk < NK; ++kk) {
-            const uint4 v = buf_load16(qrs, (uint32_t)col * row_bytes + (uint32_t)kk * 32u + (uint32_t)half * 16u);
-            bfrag[kk] = __builtin_bit_cast(mfma_ab_t, v);
-        }
-    }
-    // this kv head's keys (2^31 bytes at most per head: checked by the launcher)
-    const __amdgpu_buffer_rsrc_t krs = make_rsrc((const char*)k + (size_t)hk * S * row_bytes, (uint32_t)S * row_bytes);
-    const int key_w = tile * kLq2Keys + w * kLq2KeysPerWave;           // first key of this wave
-    // where my 16 bytes of wave-load i go: linear offset i * 1024 + lane * 16 inside the sub-tile
-    uint32_t lds_off[NL];
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-        const uint32_t off = (uint32_t)i * 1024u + (uint32_t)lane * 16u;
-        const int kl = (int)(off / row_bytes), c = (int)((off % row_bytes) >> 4);
-        lds_off[i] = (uint32_t)kl * row_bytes + (uint32_t)((c ^ lq_swz<CH>(kl)) << 4);
-    }
-    unsigned char* mine = kbuf[w];
-    auto fetch = [&](uint4* dst, int j) {
-        const uint32_t base = (uint32_t)(key_w + j * 32) * row_bytes + (uint32_t)lane * 16u;
-#pragma unroll
-        for (int i = 0; i < NL; ++i) dst[i] = buf_load16<2>(krs, base + (uint32_t)i * 1024u);        // keys past S: zeros
-    };
-    const int n = (r0 + col) % num;
-    float m_run = -INFINITY, e_run = 0.f;
-    auto consume = [&](const uint4* src, int j) {
-#pragma unroll
-        for (int i = 0; i < NL; ++i) *(uint4*)(mine + lds_off[i]) = src[i];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        mfma_cd_t acc;
-#pragma unroll
-        for (int x = 0; x < 16; ++x) acc[x] = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < NK; ++kk) {
-            const int c = kk * 2 + half;
-            const uint4 a = *(const uint4*)(mine + (uint32_t)col * row_bytes + (uint32_t)((c ^ lq_swz<CH>(col)) << 4));
-            if constexpr (DT == FF_BF16)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_ab_t, a), bfrag[kk], acc, 0, 0, 0);
-            else
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(__attribute__((ext_vector_type(8))) _Float16, a),
-                                                            __builtin_bit_cast(__attribute__((ext_vector_type(8))) _Float16, bfrag[kk]),
-                                                            acc, 0, 0, 0);
-        }
-        __builtin_amdgcn_wave_barrier();        // (the next sub-tile's writes come after these reads in program order)
-        // staged rounding + the causal bias; scores out as T, key-major
-        const int key0 = key_w + j * 32;
-        float v[16], m = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int s_key = key0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            float x = A::rnd(acc[r]);
-            x = A::rnd(x * scale);
-            if (causal && s_key > S - num + n) x = A::rnd(x + (-INFINITY));
-            if (s_key >= S || col >= rows_here) x = -INFINITY;
-            else A::store1(scores, (int64_t)s_key * pitch + hk * rows + r0 + col, x);
-            v[r] = x;
-            m = fmaxf(m, x);
-        }
-        if (m > -INFINITY) {
-            const float mn = fmaxf(m_run, m);
-            float e = m_run > -INFINITY ? e_run * expf(m_run - mn) : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) e += expf(v[r] - mn);
-            m_run = mn;
-            e_run = e;
-        }
-    };
-    uint4 b0[NL], b1[NL];
-    fetch(b0, 0);
-#pragma unroll
-    for (int j = 0; j < kLq2Sub; j += 2) {
-        if (key_w + (j + 1) * 32 < S) fetch(b1, j + 1);
-        if (key_w + j * 32 < S) consume(b0, j);
-        if (j + 2 < kLq2Sub && key_w + (j + 2) * 32 < S) fetch(b0, j + 2);
-        if (key_w + (j + 1) * 32 < S) consume(b1, j + 1);
-    }
-    // the two halves of a column, then the four waves: (max, sum of exp relative to it) of the row over this tile
-    {
-        const float mo = __shfl_xor(m_run, 32, kWave), eo = __shfl_xor(e_run, 32, kWave);
-        const float mn = fmaxf(m_run, mo);
-        e_run = (m_run > -INFINITY ? e_run * expf(m_run - mn) : 0.f) + (mo > -INFINITY ? eo * expf(mo - mn) : 0.f);
-        m_run = mn;
-    }
-    if (half == 0) wstat[w][col] = make_float2(m_run, e_run);
-    __syncthreads();
-    if (tid < rows_here) {
-        float M = -INFINITY, sum = 0.f;
-#pragma unroll
-        for (int x = 0; x < 4; ++x) M = fmaxf(M, wstat[x][tid].x);
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            const float2 ms = wstat[x][tid];
-            sum += ms.y > 0.f ? ms.y * expf(ms.x - M) : 0.f;
-        }
-        tstats[(size_t)(hk * rows + r0 + tid) * tiles + tile] = make_float2(M, sum);
-    }
-}
-
-// KG lanes share a key (each takes every KG-th 16-byte word of its score row): KG x the waves for the
-// exp / divide work, the partial means meet through DPP.
 template <int DT, int KG>
 __global__ __launch_bounds__(256) void k_lq_finish(const void* __restrict__ scores, const float2* __restrict__ tstats,
                                                    int rows_total, int pitch, int tiles, int S, void* __restrict__ weights,
@@ -634,7 +494,7 @@ __global__ __launch_bounds__(256) void k_lq_finish(const void* __restrict__ scor
 
 template <int DT>
 static int launch_lq_general(const void* q, const void* k, int64_t H, int64_t H_kv, int64_t num, int64_t S, int64_t dh,
-                             double scale, int causal, void* weights, void* importance, void* ws, int64_t lo, int64_t hi,
+                             double scale, int causal, const void* bias, void* weights, void* importance, void* ws, int64_t lo, int64_t hi,
                              int* l0, int* t16_end, hipStream_t st) {
     float* scores = (float*)ws;
     float* probs = scores + H * num * S;
@@ -642,7 +502,7 @@ static int launch_lq_general(const void* q, const void* k, int64_t H, int64_t H_
     const size_t lds = (size_t)kRowsPerBlock * dh * sizeof(float);
     hipLaunchKernelGGL(k_lq_scores<DT>, dim3((unsigned)((S + 255) / 256), (unsigned)H_kv,
                                              (unsigned)((rows + kRowsPerBlock - 1) / kRowsPerBlock)),
-                       dim3(256), lds, st, q, k, (int)H, (int)H_kv, (int)num, (int)S, (int)dh, (float)scale, causal,
+                       dim3(256), lds, st, q, k, (int)H, (int)H_kv, (int)num, (int)S, (int)dh, (float)scale, causal, bias,
                        scores);
     hipLaunchKernelGGL(k_lq_softmax<DT>, dim3((unsigned)(H * num)), dim3(256), 0, st, scores, (int)S, probs, weights);
     if (importance)
@@ -678,37 +538,42 @@ size_t lq_ws_bytes(int dtype, int64_t H, int64_t num, int64_t S, int64_t dh) {
 
 template <int DT>
 static int launch_lq(const void* q, const void* k, int64_t H, int64_t H_kv, int64_t num, int64_t S, int64_t dh,
-                     double scale, int causal, void* weights, void* importance, void* ws, int64_t lo, int64_t hi,
+                     double scale, int causal, const void* bias, void* weights, void* importance, void* ws, int64_t lo, int64_t hi,
                      int* l0, int* t16_end, hipStream_t st) {
     constexpr int kB = Act<DT>::kBytes;
     const int64_t lpk = dh * kB / 16;
     const bool tiled = (dh * kB) % 16 == 0 && lpk >= 1 && lpk <= 64 && (lpk & (lpk - 1)) == 0 && H * num <= 4096;
-    if (!tiled) return launch_lq_general<DT>(q, k, H, H_kv, num, S, dh, scale, causal, weights, importance, ws, lo, hi, l0, t16_end, st);
+    if (!tiled) return launch_lq_general<DT>(q, k, H, H_kv, num, S, dh, scale, causal, bias, weights, importance, ws, lo, hi, l0, t16_end, st);
     const int rows = (int)((H / H_kv) * num), rows_total = (int)(H * num);
     const int tiles = (int)((S + kLqKeys - 1) / kLqKeys);
     void* scores = ws;
     const int64_t pitch_bytes = ((int64_t)rows_total * kB + 15) & ~(int64_t)15;
     const int pitch = (int)(pitch_bytes / kB);
-    float2* tstats = (float2*)((char*)ws + S * pitch_bytes);
+    float2* tstats = (float2*)((char*)scores + S * pitch_bytes);
     if constexpr (kB == 2) {
-        // matrix-core scores for the head sizes of real models (statistics per 512-key tile)
-        if ((dh == 64 || dh == 128 || dh == 256) && S * dh * kB < (1ll << 31)) {
-            const int tiles2 = (int)((S + kLq2Keys - 1) / kLq2Keys);
-            const dim3 mgrid((unsigned)tiles2, (unsigned)H_kv, (unsigned)((rows + 31) / 32));
-#define FF_LQ_MFMA(NK)                                                                                                     \
-    hipLaunchKernelGGL((k_lq_mfma2<DT, NK>), mgrid, dim3(256), 0, st, q, k, (int)H, (int)H_kv, (int)num, (int)S, (float)scale, \
-                       causal, pitch, scores, tstats, tiles2)
+        // matrix-core scores for the head sizes of real models.  4 waves (256 keys) per workgroup = per statistics tile:
+        // wider workgroups would mean fewer tiles for the finish kernel to fold (72B shape: 16.5 us at 256 keys per tile,
+        // 12.3 at 512, 9.9 at 1024) but cost this kernel more than that (23.8 -> 38.5 -> 42.5 us); 2 waves: 23.7 + 24.5
+        // (profiles/r03_k5_experiments.txt)
+        if (dh == 64 || dh == 128 || dh == 256) {
+            const int64_t zg = (rows + 31) / 32;
+            constexpr int waves = 4;
+            const int tiles_m = (int)((S + 64 * waves - 1) / (64 * waves));
+            const dim3 mgrid((unsigned)tiles_m, (unsigned)H_kv, (unsigned)zg);
+#define FF_LQ_MFMA(NK)                                                                                                         \
+    hipLaunchKernelGGL((k_lq_mfma<DT, NK, waves>), mgrid, dim3(64 * waves), 0, st, q, k, (int)H, (int)H_kv, (int)num, (int)S,   \
+                       (float)scale, causal, bias, pitch, scores, tstats, tiles_m)
             if (dh == 64) FF_LQ_MFMA(4);
             else if (dh == 128) FF_LQ_MFMA(8);
             else FF_LQ_MFMA(16);
 #undef FF_LQ_MFMA
-            return launch_lq_finish<DT>(scores, tstats, rows_total, pitch, tiles2, S, weights, importance, lo, hi, l0, t16_end, st);
+            return launch_lq_finish<DT>(scores, tstats, rows_total, pitch, tiles_m, S, weights, importance, lo, hi, l0, t16_end, st);
         }
     }
     const dim3 grid((unsigned)tiles, (unsigned)H_kv, (unsigned)((rows + kLqRows - 1) / kLqRows));
 #define FF_LQ_TILE(LPK)                                                                                                   \
     hipLaunchKernelGGL((k_lq_tile<DT, LPK>), grid, dim3(256), 0, st, q, k, (int)H, (int)H_kv, (int)num, (int)S, (float)scale, \
-                       causal, pitch, scores, tstats, tiles)
+                       causal, bias, pitch, scores, tstats, tiles)
     switch ((int)lpk) {
         case 1: FF_LQ_TILE(1); break;
         case 2: FF_LQ_TILE(2); break;
@@ -744,7 +609,7 @@ extern "C" size_t ff_last_query_workspace_bytes(int dtype, int64_t H, int64_t nu
 
 extern "C" int ff_last_query_attention(const void* q_last, const void* k, int dtype, int64_t H, int64_t H_kv,
                                        int64_t num, int64_t S, int64_t dh, double scale, int causal,
-                                       void* weights, void* importance, int64_t sel_lo, int64_t sel_hi, void* sel_ws,
+                                       const void* bias, void* weights, void* importance, int64_t sel_lo, int64_t sel_hi, void* sel_ws,
                                        size_t sel_ws_bytes, void* ws, size_t ws_bytes, ff_stream_t stream) {
     if (!q_last || !k || !ws || H < 1 || H_kv < 1 || num < 1 || S < 1 || dh < 1) return FF_ERR_ARG;
     if (H % H_kv) return FF_ERR_ARG;
@@ -765,8 +630,8 @@ extern "C" int ff_last_query_attention(const void* q_last, const void* k, int dt
     }
     hipStream_t st = (hipStream_t)stream;
     switch (dtype) {
-        case FF_F32: return ff::launch_lq<FF_F32>(q_last, k, H, H_kv, num, S, dh, scale, causal, weights, importance, ws, sel_lo, sel_hi, l0, t16_end, st);
-        case FF_BF16: return ff::launch_lq<FF_BF16>(q_last, k, H, H_kv, num, S, dh, scale, causal, weights, importance, ws, sel_lo, sel_hi, l0, t16_end, st);
-        default: return ff::launch_lq<FF_F16>(q_last, k, H, H_kv, num, S, dh, scale, causal, weights, importance, ws, sel_lo, sel_hi, l0, t16_end, st);
+        case FF_F32: return ff::launch_lq<FF_F32>(q_last, k, H, H_kv, num, S, dh, scale, causal, bias, weights, importance, ws, sel_lo, sel_hi, l0, t16_end, st);
+        case FF_BF16: return ff::launch_lq<FF_BF16>(q_last, k, H, H_kv, num, S, dh, scale, causal, bias, weights, importance, ws, sel_lo, sel_hi, l0, t16_end, st);
+        default: return ff::launch_lq<FF_F16>(q_last, k, H, H_kv, num, S, dh, scale, causal, bias, weights, importance, ws, sel_lo, sel_hi, l0, t16_end, st);
     }
 }

@@ -304,23 +304,66 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
     if (open_r >= 0) flush();
 }
 
-// out[r, c] = mask[i_r, i_c]: one workgroup per kept input row, threads over input columns.
-__global__ __launch_bounds__(256) void k_gather_mask(const char* __restrict__ mask, char* __restrict__ out,
-                                                     int elem_bytes, int L, int64_t L_cap,
-                                                     const int32_t* __restrict__ dst) {
-    const int i = blockIdx.x;
-    const int r = dst[i];
-    if (r < 0) return;
-    for (int c = threadIdx.x; c < L; c += blockDim.x) {
-        const int rc = dst[c];
-        if (rc < 0) continue;
-        const char* s = mask + ((int64_t)i * L + c) * elem_bytes;
-        char* d = out + ((int64_t)r * L_cap + rc) * elem_bytes;
-        if (elem_bytes == 2) *(uint16_t*)d = *(const uint16_t*)s;
-        else if (elem_bytes == 4) *(uint32_t*)d = *(const uint32_t*)s;
-        else if (elem_bytes == 1) *d = *s;
-        else *(uint64_t*)d = *(const uint64_t*)s;
+// ---- square attention-mask gather (main.py:137-138, 99-100): out[r, c] = mask[src[r], src[c]] ----------------
+// Round 2 ran one workgroup per INPUT row with a dst[] lookup per input element: L^2 index reads and 2-byte scattered
+// stores (2.7 GB of traffic for a bf16 mask at 37 k tokens).  Two levels now: k_invert_dst turns dst[] (row of every
+// kept position) into src[] (position of every output row) once, then one workgroup per OUTPUT row walks the output
+// columns - src[] read as whole words, the mask row gathered through it (ascending, mostly neighbouring elements),
+// 16-byte stores.  What is left is the mask itself: L_out^2 elements written, the kept part of L_out rows read.
+__global__ __launch_bounds__(256) void k_invert_dst(const int32_t* __restrict__ dst, int L, int32_t* __restrict__ src) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < L) {
+        const int r = dst[i];
+        if (r >= 0) src[r] = i;
     }
+}
+
+template <int EB>
+__global__ __launch_bounds__(256) void k_gather_mask(const char* __restrict__ mask, char* __restrict__ out, int L, int64_t L_cap,
+                                                     const int32_t* __restrict__ src, const int64_t* __restrict__ stats) {
+    constexpr int V = 16 / EB;                               // elements per 16-byte store
+    const int L_out = (int)stats[FF_STAT_LOUT];
+    const int r = blockIdx.x;
+    if (r >= L_out) return;
+    const char* row_in = mask + (int64_t)src[r] * L * EB;
+    char* row_out = out + (int64_t)r * L_cap * EB;
+    const bool wide = (((uintptr_t)row_out | (uintptr_t)((int64_t)L_cap * EB)) & 15) == 0;
+    for (int c0 = threadIdx.x * V; c0 < L_out; c0 += 256 * V) {
+        if (wide && c0 + V <= L_out) {
+            int idx[V];
+#pragma unroll
+            for (int e = 0; e < V; e += 4) {
+                const int4 w = *(const int4*)(src + c0 + e);     // (src is 16-byte aligned, c0 a multiple of V >= 4... V = 2: below)
+                idx[e] = w.x; idx[e + 1] = w.y; idx[e + 2] = w.z; idx[e + 3] = w.w;
+            }
+            uint32_t pk[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                if constexpr (EB == 1) pk[e >> 2] |= (uint32_t)(uint8_t)row_in[idx[e]] << (8 * (e & 3));
+                else if constexpr (EB == 2) pk[e >> 1] |= (uint32_t)((const uint16_t*)row_in)[idx[e]] << (16 * (e & 1));
+                else pk[e] = ((const uint32_t*)row_in)[idx[e]];
+            }
+            *(uint4*)(row_out + (int64_t)c0 * EB) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        } else {
+            for (int e = 0; e < V && c0 + e < L_out; ++e) {
+                const int c = src[c0 + e];
+                if constexpr (EB == 1) row_out[c0 + e] = row_in[c];
+                else if constexpr (EB == 2) ((uint16_t*)row_out)[c0 + e] = ((const uint16_t*)row_in)[c];
+                else ((uint32_t*)row_out)[c0 + e] = ((const uint32_t*)row_in)[c];
+            }
+        }
+    }
+}
+
+// 8-byte elements (fp64 masks): two per 16-byte store
+__global__ __launch_bounds__(256) void k_gather_mask8(const char* __restrict__ mask, char* __restrict__ out, int L, int64_t L_cap,
+                                                      const int32_t* __restrict__ src, const int64_t* __restrict__ stats) {
+    const int L_out = (int)stats[FF_STAT_LOUT];
+    const int r = blockIdx.x;
+    if (r >= L_out) return;
+    const uint64_t* row_in = (const uint64_t*)(mask + (int64_t)src[r] * L * 8);
+    uint64_t* row_out = (uint64_t*)(out + (int64_t)r * L_cap * 8);
+    for (int c = threadIdx.x; c < L_out; c += 256) row_out[c] = row_in[src[c]];
 }
 
 // Slots per workgroup, chosen per launch (measured at 64 x 576 x 4096, K4 in the step; 32 was the fixed value):
@@ -428,12 +471,96 @@ extern "C" int ff_merge_compact(const void* hidden, void* hidden_out, int dtype,
 }
 
 extern "C" int ff_gather_mask(const void* mask, void* out, int64_t elem_bytes, int64_t L, int64_t L_cap,
-                              const int32_t* dst, ff_stream_t stream) {
-    if (!mask || !out || !dst || L < 0 || L_cap < 0) return FF_ERR_ARG;
+                              const int32_t* dst, const int64_t* stats, int32_t* scratch, ff_stream_t stream) {
+    if (!mask || !out || !dst || !stats || !scratch || L < 0 || L_cap < 0) return FF_ERR_ARG;
     if (elem_bytes != 1 && elem_bytes != 2 && elem_bytes != 4 && elem_bytes != 8) return FF_ERR_ARG;
     if (L >= (1ll << 31)) return FF_ERR_UNSUPPORTED;
+    if ((uintptr_t)scratch & 15) return FF_ERR_ALIGN;
     if (L == 0) return FF_OK;
-    hipLaunchKernelGGL(ff::k_gather_mask, dim3((unsigned)L), dim3(256), 0, (hipStream_t)stream, (const char*)mask,
-                       (char*)out, (int)elem_bytes, (int)L, L_cap, dst);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(ff::k_invert_dst, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, st, dst, (int)L, scratch);
+    const char* m = (const char*)mask;
+    char* o = (char*)out;
+    switch ((int)elem_bytes) {
+        case 1: hipLaunchKernelGGL(ff::k_gather_mask<1>, dim3((unsigned)L), dim3(256), 0, st, m, o, (int)L, L_cap, scratch, stats); break;
+        case 2: hipLaunchKernelGGL(ff::k_gather_mask<2>, dim3((unsigned)L), dim3(256), 0, st, m, o, (int)L, L_cap, scratch, stats); break;
+        case 4: hipLaunchKernelGGL(ff::k_gather_mask<4>, dim3((unsigned)L), dim3(256), 0, st, m, o, (int)L, L_cap, scratch, stats); break;
+        default: hipLaunchKernelGGL(ff::k_gather_mask8, dim3((unsigned)L), dim3(256), 0, st, m, o, (int)L, L_cap, scratch, stats);
+    }
+    return (int)hipGetLastError();
+}
+
+// ---- stand-alone token gathers for the reference's public position handlers (main.py:142-178) -------------------
+// position_embedding_handler_at_pruning(pe, keep_indexs): pe[..., keep_indexs, :] - rows in the order of an index
+// tensor; position_embedding_handler_at_merging(pe, token_mask): pe[..., token_mask[0], :] - compaction by a boolean
+// row.  The hot path never calls them (its merge kernel gathers the position tensors on the way); they exist so that
+// code written against the reference's method surface keeps working.
+namespace ff {
+__global__ __launch_bounds__(256) void k_rows_by_index(AuxPack aux, const int64_t* __restrict__ index, int n, int L) {
+    const int r = blockIdx.x * kMergeWaves * 4 + wave_id() * 4 + (lane_id() >> 4);
+    const int sub = lane_id() & 15;
+    if (r >= n) return;
+    int64_t i = index[r];
+    if (i < 0) i += L;                                       // torch indexing accepts negative indices
+    if (i < 0 || i >= L) return;
+    for (int x = 0; x < aux.n; ++x) {
+        const ff_aux_t& ax = aux.a[x];
+        for (int64_t ou = 0; ou < ax.outer; ++ou)
+            copy_row((const char*)ax.src + (ou * L + i) * ax.row_bytes, (char*)ax.dst + (ou * n + r) * ax.row_bytes,
+                     ax.row_bytes, sub, 16);
+    }
+}
+__global__ __launch_bounds__(256) void k_rows_by_dst(AuxPack aux, const int32_t* __restrict__ dst, int L, int64_t L_cap) {
+    const int i = blockIdx.x * kMergeWaves * 4 + wave_id() * 4 + (lane_id() >> 4);
+    const int sub = lane_id() & 15;
+    if (i >= L) return;
+    const int r = dst[i];
+    if (r < 0) return;
+    for (int x = 0; x < aux.n; ++x) {
+        const ff_aux_t& ax = aux.a[x];
+        for (int64_t ou = 0; ou < ax.outer; ++ou)
+            copy_row((const char*)ax.src + (ou * L + i) * ax.row_bytes, (char*)ax.dst + (ou * L_cap + r) * ax.row_bytes,
+                     ax.row_bytes, sub, 16);
+    }
+}
+int launch_scan_keep(const uint8_t* keep, int64_t L, int32_t* dst, int64_t* stats, hipStream_t st);
+}  // namespace ff
+
+static int pack_aux(const ff_aux_t* aux_host, int n_aux, ff::AuxPack& pack) {
+    if (n_aux < 1 || n_aux > FF_MAX_AUX || !aux_host) return FF_ERR_ARG;
+    pack.n = n_aux;
+    for (int x = 0; x < FF_MAX_AUX; ++x) pack.a[x] = x < n_aux ? aux_host[x] : ff_aux_t{nullptr, nullptr, 0, 0};
+    for (int x = 0; x < n_aux; ++x)
+        if (!pack.a[x].src || !pack.a[x].dst || pack.a[x].row_bytes < 2 || (pack.a[x].row_bytes & 1) || pack.a[x].outer < 1)
+            return FF_ERR_ARG;
+    return FF_OK;
+}
+
+extern "C" int ff_gather_tokens_by_index(const int64_t* index, int64_t n, int64_t L, const ff_aux_t* aux_host, int n_aux,
+                                         ff_stream_t stream) {
+    if (n < 0 || L < 0 || (n > 0 && !index)) return FF_ERR_ARG;
+    if (n >= (1ll << 31) || L >= (1ll << 31)) return FF_ERR_UNSUPPORTED;
+    ff::AuxPack pack;
+    int rc = pack_aux(aux_host, n_aux, pack);
+    if (rc) return rc;
+    if (n == 0) return FF_OK;
+    const unsigned blocks = (unsigned)((n + ff::kMergeWaves * 4 - 1) / (ff::kMergeWaves * 4));
+    hipLaunchKernelGGL(ff::k_rows_by_index, dim3(blocks), dim3(ff::kMergeThreads), 0, (hipStream_t)stream, pack, index, (int)n, (int)L);
+    return (int)hipGetLastError();
+}
+
+extern "C" int ff_gather_tokens_by_mask(const uint8_t* keep, int64_t L, int64_t L_cap, int32_t* dst, int64_t* stats,
+                                        const ff_aux_t* aux_host, int n_aux, ff_stream_t stream) {
+    if (!keep || !dst || !stats || L < 0 || L_cap < 0) return FF_ERR_ARG;
+    if (L >= (1ll << 31) - 65536) return FF_ERR_UNSUPPORTED;
+    if (((uintptr_t)keep & 15) || ((uintptr_t)dst & 15)) return FF_ERR_ALIGN;
+    ff::AuxPack pack;
+    int rc = pack_aux(aux_host, n_aux, pack);
+    if (rc) return rc;
+    if (L == 0) return FF_OK;
+    rc = ff::launch_scan_keep(keep, L, dst, stats, (hipStream_t)stream);
+    if (rc) return rc;
+    const unsigned blocks = (unsigned)((L + ff::kMergeWaves * 4 - 1) / (ff::kMergeWaves * 4));
+    hipLaunchKernelGGL(ff::k_rows_by_dst, dim3(blocks), dim3(ff::kMergeThreads), 0, (hipStream_t)stream, pack, dst, (int)L, L_cap);
     return (int)hipGetLastError();
 }

@@ -1036,10 +1036,15 @@ int* ws_t16_end(void* ws, size_t ws_bytes) { return (int*)((char*)ws + (ws_bytes
 static uint32_t* ws_tag(void* ws) { return (uint32_t*)((int*)ws + kL0Ints); }
 static unsigned long long* ws_agg(void* ws) { return (unsigned long long*)((int*)ws + kL0Ints + 16); }
 static int* ws_levels(void* ws) { return (int*)ws + kWsFixedInts; }
+int32_t* ws_scratch_ints(void* ws, int64_t L);
 static int32_t* ws_inv(void* ws, int64_t L) {
     const size_t G = (size_t)((L + kSelSlice - 1) / kSelSlice) + 1;
     return (int32_t*)(((uintptr_t)(ws_levels(ws) + 2 * G * 256) + 15) & ~(uintptr_t)15);
 }
+
+// [L] ints of the workspace that only the stand-alone plan entry points use (their inverse order): free scratch
+// for the fused step's followers (the attention-mask gather)
+int32_t* ws_scratch_ints(void* ws, int64_t L) { return ws_inv(ws, L); }
 
 __global__ __launch_bounds__(256) void k_invert(const int32_t* __restrict__ order, int L, int32_t* __restrict__ inv) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1185,6 +1190,12 @@ int launch_plan_prune(const void* imp, int dtype, int64_t S, int64_t start, int6
         case FF_BF16: return launch_plan<FF_BF16>(imp, pp, have_tables, S, S, nullptr, member, keep, dst, stats, ws, ws_bytes, nullptr, 0, st);
         default: return launch_plan<FF_F16>(imp, pp, have_tables, S, S, nullptr, member, keep, dst, stats, ws, ws_bytes, nullptr, 0, st);
     }
+}
+
+// dst[] (row of every kept position, -1 else) + stats[LOUT / MERGED] from keep bytes (0 / 1)
+int launch_scan_keep(const uint8_t* keep, int64_t L, int32_t* dst, int64_t* stats, hipStream_t st) {
+    hipLaunchKernelGGL(k_scan, dim3(cdiv(L, kScanSpan)), dim3(kScanThreads), 0, st, keep, (int)L, dst, stats);
+    return (int)hipGetLastError();
 }
 
 int launch_plan_from_index(const int64_t* merge_index, int64_t n_merge, const int32_t* order, int64_t L,

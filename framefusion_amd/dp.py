@@ -55,20 +55,24 @@ def launch_ranks(n_ranks: int, script: str, argv: Sequence[str]) -> None:
     os.execvpe(cmd[0], cmd, env)
 
 
-def init(backend: str = "nccl", device: Optional[torch.device] = None):
-    """Join the process group (no-op for a single process). Returns the dist module or None."""
+def init(backend: str = "nccl", device: Optional[torch.device] = None, force: bool = False):
+    """Join the process group (no-op for a single process unless `force`: a one-rank group, which still runs every
+    collective below through the backend - the way to exercise RCCL itself on a 1-GPU box).  Returns the dist module
+    or None."""
     world, rank, local = env_world()
-    if world <= 1:
+    if world <= 1 and not force:
         return None
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not dist.is_initialized():
+        kwargs = {}
+        if world <= 1:
+            kwargs.update(world_size=1, rank=0)
         if backend == "nccl" and device is not None:
-            dist.init_process_group(backend, device_id=device)
-        else:
-            dist.init_process_group(backend)
+            kwargs["device_id"] = device                 # binds the communicator to this rank's GPU up front
+        dist.init_process_group(backend, **kwargs)
     return dist
 
 

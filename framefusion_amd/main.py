@@ -560,6 +560,80 @@ class FrameFusion(nn.Module):
         self.last_call = dict(kind="prune", L_in=q_len, L_out=L_out, k=k, nv=q_len, scratch=sc, dtype=w.dtype)
         return out, rebuild(L_out), mask_out
 
+    # ---- the reference's public position handlers: main.py:142-178 ----------------------------------------------
+    def _handler_tensors(self, position_embeddings):
+        if type(position_embeddings) == list:
+            assert len(position_embeddings) == 2                                     # main.py:144,163
+            return [t if t.is_contiguous() else t.contiguous() for t in position_embeddings]
+        if type(position_embeddings) == torch.Tensor:
+            if position_embeddings.ndim != 2:
+                raise NotImplementedError("Only support 2D position embeddings")     # main.py:155,175
+            return [position_embeddings.contiguous()]
+        raise NotImplementedError("Only support list or tensor for position embeddings")   # main.py:157,177
+
+    @staticmethod
+    def _handler_aux(srcs, outs):
+        aux = (_lib.FFAux * _lib.MAX_AUX)()
+        for n, (s, o) in enumerate(zip(srcs, outs)):
+            if s.ndim == 2:
+                L, row, outer = s.shape[1], s.element_size(), s.shape[0]
+            else:
+                L, last = s.shape[-2], s.shape[-1]
+                row, outer = last * s.element_size(), s.numel() // (L * last)
+            aux[n] = _lib.FFAux(s.data_ptr(), o.data_ptr(), row, outer)
+        return aux
+
+    def position_embedding_handler_at_pruning(self, position_embeddings, keep_indexs):
+        """main.py:142-158: ``pe[..., keep_indexs, :]`` for the [cos, sin] list (3-D or 4-D, mutated in place like the
+        reference) or ``pe[:, keep_indexs]`` for a 2-D position tensor - one gather launch for the whole container."""
+        srcs = self._handler_tensors(position_embeddings)
+        _lib.require_gpu(srcs[0], "position_embedding_handler_at_pruning")
+        with torch.cuda.device(srcs[0].device):
+            idx = keep_indexs.to(device=srcs[0].device, dtype=torch.int64).contiguous()
+            n = idx.numel()
+            axis = -1 if srcs[0].ndim == 2 else -2
+            L = srcs[0].shape[axis]
+            outs = []
+            for t in srcs:
+                shape = list(t.shape)
+                shape[axis] = n
+                outs.append(torch.empty(shape, dtype=t.dtype, device=t.device))
+            _lib.check(_lib.load().ff_gather_tokens_by_index(idx.data_ptr(), n, L, self._handler_aux(srcs, outs), len(srcs),
+                                                             _lib.stream_ptr()), "ff_gather_tokens_by_index")
+        if type(position_embeddings) == list:
+            position_embeddings[0], position_embeddings[1] = outs
+            return position_embeddings
+        return outs[0]
+
+    def position_embedding_handler_at_merging(self, position_embeddings, token_mask):
+        """main.py:161-178: ``pe[..., token_mask[0], :]`` / ``pe[:, token_mask[0]]``.  The number of kept tokens is read
+        back (the reference's boolean indexing synchronises as well)."""
+        srcs = self._handler_tensors(position_embeddings)
+        _lib.require_gpu(srcs[0], "position_embedding_handler_at_merging")
+        dev = srcs[0].device
+        with torch.cuda.device(dev):
+            keep = token_mask[0].to(device=dev, dtype=torch.bool).contiguous()
+            axis = -1 if srcs[0].ndim == 2 else -2
+            L = srcs[0].shape[axis]
+            if keep.numel() != L:
+                raise IndexError(f"The shape of the mask [{keep.numel()}] does not match the {L} tokens of the position embeddings")
+            if keep.data_ptr() & 15:
+                keep = keep.clone()
+            dst = torch.empty(L, dtype=torch.int32, device=dev)
+            stats = torch.zeros(_lib.STAT_WORDS, dtype=torch.int64, device=dev)
+            outs = []
+            for t in srcs:
+                outs.append(torch.empty_like(t))                      # capacity L rows: narrowed once the count is known
+            _lib.check(_lib.load().ff_gather_tokens_by_mask(keep.data_ptr(), L, L, dst.data_ptr(), stats.data_ptr(),
+                                                            self._handler_aux(srcs, outs), len(srcs), _lib.stream_ptr()),
+                       "ff_gather_tokens_by_mask")
+            n = int(stats[_lib.STAT_LOUT])
+        outs = [o.narrow(o.ndim + axis, 0, n) for o in outs]
+        if type(position_embeddings) == list:
+            position_embeddings[0], position_embeddings[1] = outs
+            return position_embeddings
+        return outs[0]
+
     # ---- static parity entry points ---------------------------------------------------------------
     @staticmethod
     def compute_similarity_and_token_index_by_patch(hidden_states, token_patch_type, patch_num):

@@ -27,7 +27,7 @@ def get_attr_by_name(obj: Any, name: str) -> Any:
     return node
 
 
-def _launch_last_query(query, key, num, is_causal, scale, want_weights, want_importance, select=None):
+def _launch_last_query(query, key, num, is_causal, scale, want_weights, want_importance, select=None, bias=None):
     _lib.require_gpu(query, "scaled_dot_product_attention")
     if query.ndim != 4 or key.ndim != 4 or query.shape[0] != 1 or key.shape[0] != 1:
         raise FrameFusionHipError("expected query [1, H, L, dh] and key [1, H_kv, S, dh]")
@@ -50,7 +50,7 @@ def _launch_last_query(query, key, num, is_causal, scale, want_weights, want_imp
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     sel_lo, sel_hi, sel_ws, sel_bytes = select if select is not None else (0, 0, None, 0)
     rc = lib.ff_last_query_attention(q_last.data_ptr(), k.data_ptr(), code, H, H_kv, num, S, dh, float(factor),
-                                     1 if is_causal else 0,
+                                     1 if is_causal else 0, bias.data_ptr() if bias is not None else None,
                                      weights.data_ptr() if want_weights else None,
                                      importance.data_ptr() if want_importance else None,
                                      sel_lo, sel_hi, sel_ws, sel_bytes,
@@ -59,17 +59,30 @@ def _launch_last_query(query, key, num, is_causal, scale, want_weights, want_imp
     return weights, importance
 
 
+def _bias_from_mask(attn_mask, num, S, dtype, device):
+    """utils.py:32,40-44: attn_bias = zeros(L, S, dtype=T); bool mask -> -inf where False, else += mask (T(mask))."""
+    bias = torch.zeros(num, S, dtype=dtype, device=device)
+    if attn_mask.dtype == torch.bool:
+        bias.masked_fill_(attn_mask.to(device).logical_not(), float("-inf"))
+    else:
+        bias += attn_mask.to(device)
+    return bias
+
+
 def scaled_dot_product_attention(query, key, value, num=1, attn_mask=None, dropout_p=0.0,
                                  is_causal=False, scale=None, enable_gqa=False) -> torch.Tensor:
     """Reference utils.py:27-57: softmax attention weights [1, H, num, S] of the last ``num``
     queries.  ``key`` may carry H_kv < H heads whether or not ``enable_gqa`` is set (head h reads
-    kv head h // (H // H_kv), exactly what repeat_kv / repeat_interleave produce)."""
-    if attn_mask is not None:
-        raise FrameFusionHipError("attn_mask is not supported by the HIP importance kernel "
-                                  "(every reference call site passes attn_mask=None)")
+    kv head h // (H // H_kv), exactly what repeat_kv / repeat_interleave produce).  ``attn_mask``
+    (boolean or additive, broadcastable to [num, S], utils.py:40-44) becomes the T-valued bias the
+    score kernel adds; like the reference it cannot be combined with ``is_causal`` (utils.py:35)."""
     if dropout_p != 0.0:
         raise FrameFusionHipError("dropout_p must be 0 (prefill-time importance scoring)")
-    weights, _ = _launch_last_query(query, key, num, is_causal, scale, True, False)
+    bias = None
+    if attn_mask is not None:
+        assert not is_causal                                                        # utils.py:35
+        bias = _bias_from_mask(attn_mask, min(num, query.shape[2]), key.shape[2], query.dtype, query.device)
+    weights, _ = _launch_last_query(query, key, num, is_causal, scale, True, False, bias=bias)
     return weights
 
 

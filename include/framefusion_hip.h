@@ -73,6 +73,10 @@ enum {
 typedef void* ff_stream_t; /* hipStream_t */
 
 int ff_abi_version(void);
+/* first 16 hex digits of the SHA-256 over the library's sources (the .hip files, ff_common.h, this header and
+ * the Makefile, concatenated in sorted order) as they were when it was compiled: a host that has the sources
+ * next to the binary can tell a stale build from a current one. */
+const char* ff_source_hash(void);
 const char* ff_error_string(int code);
 
 /* Scratch bytes any entry point may need for a sequence of L tokens and `patch_num` patch types.
@@ -185,9 +189,23 @@ int ff_merge_compact(const void* hidden, void* hidden_out, int dtype, int64_t L,
                      ff_stream_t stream);
 
 /* Square attention-mask gather: out[r, c] = mask[src_r, src_c] for kept rows/cols
- * (main.py:137-138, 99-100). mask: [L, L] elements of elem_bytes; out: [L_cap, L_cap]. */
+ * (main.py:137-138, 99-100). mask: [L, L] elements of elem_bytes; out: [L_cap, L_cap]; dst: the plan's row of
+ * every position (-1 = dropped); stats: the plan's result block (FF_STAT_LOUT is read on the device);
+ * scratch: [L] int32, 16-byte aligned (receives the position of every output row).  Two launches. */
 int ff_gather_mask(const void* mask, void* out, int64_t elem_bytes, int64_t L, int64_t L_cap,
-                   const int32_t* dst, ff_stream_t stream);
+                   const int32_t* dst, const int64_t* stats, int32_t* scratch, ff_stream_t stream);
+
+/* Token gathers of the reference's public position handlers (stand-alone: the fused step gathers the position
+ * tensors inside its merge kernel).  aux as ff_merge_compact: every tensor viewed as [outer, L, row_bytes].
+ *   by index (position_embedding_handler_at_pruning, main.py:142-158: pe[..., keep_indexs, :]): output row r =
+ *     input row index[r] (negative indices count from the end, as in torch), outputs [outer, n, row_bytes];
+ *   by mask  (position_embedding_handler_at_merging, main.py:161-178: pe[..., token_mask[0], :]): keep = L bytes
+ *     0 / 1 (a torch.bool row), 16-byte aligned; dst [L] int32 (16-byte aligned) and stats [FF_STAT_WORDS] receive the
+ *     scan (row of every kept position, FF_STAT_LOUT = number kept); outputs [outer, L_cap, row_bytes]. */
+int ff_gather_tokens_by_index(const int64_t* index, int64_t n, int64_t L, const ff_aux_t* aux_host, int n_aux,
+                              ff_stream_t stream);
+int ff_gather_tokens_by_mask(const uint8_t* keep, int64_t L, int64_t L_cap, int32_t* dst, int64_t* stats,
+                             const ff_aux_t* aux_host, int n_aux, ff_stream_t stream);
 
 /* ---- importance (framefusion/utils.py:27-57 + main.py:69-70) -----------------------------------
  * Head/query mean of attention probabilities: attn_w [H, num, S] (T) -> importance [S] (T),
@@ -196,17 +214,22 @@ int ff_head_mean(const void* attn_w, int dtype, int64_t H, int64_t num, int64_t 
                  void* importance, ff_stream_t stream);
 
 /* Last-`num`-query attention probabilities with the reference's staged rounding:
- * p = T(softmax_fp32(T(T(q K^T) * scale) + causal_bias)).  q_last [H, num, dh], k [H_kv, S, dh]
+ * p = T(softmax_fp32(T(T(q K^T) * scale) + bias)).  q_last [H, num, dh], k [H_kv, S, dh]
  * (GQA: head h reads kv head h / (H/H_kv), the repeat_kv of modeling_qwen2.py:147 folded in),
  * weights [H, num, S] (may be NULL), importance [S] (may be NULL) = head_mean(weights).
+ * The bias of utils.py:32-44 is either the causal one (`causal` != 0: -inf above the diagonal of the last
+ * `num` rows, utils.py:34-38) or `bias` (optional, [num, S] of T, added to every head: the caller's
+ * attn_mask already turned into T values - 0 / -inf for a boolean mask, T(mask) for an additive one,
+ * utils.py:40-44) - the reference asserts that the two are not combined, so does the Python host.
  * sel_ws (optional, with importance): the workspace of the prune call that will consume the
  * importance - the select tables of importance[sel_lo, sel_hi) are accumulated on the way, and
  * ff_prune_step is then called with H = num = 1, attn_w = importance, tables_ready = 1.
- * ws: ff_last_query_workspace_bytes() bytes, 16-byte aligned (scores as T, key-major, + tile statistics).
+ * ws: ff_last_query_workspace_bytes() bytes, 16-byte aligned, no initialisation needed (scores as T, key-major,
+ * + tile statistics + row statistics).
  * Two launches when dh * sizeof(T) / 16 is a power of two (every real head size), else three. */
 size_t ff_last_query_workspace_bytes(int dtype, int64_t H, int64_t num, int64_t S, int64_t dh);
 int ff_last_query_attention(const void* q_last, const void* k, int dtype, int64_t H, int64_t H_kv,
-                            int64_t num, int64_t S, int64_t dh, double scale, int causal,
+                            int64_t num, int64_t S, int64_t dh, double scale, int causal, const void* bias,
                             void* weights, void* importance,
                             int64_t sel_lo, int64_t sel_hi, void* sel_ws, size_t sel_ws_bytes,
                             void* ws, size_t ws_bytes, ff_stream_t stream);

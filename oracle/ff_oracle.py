@@ -268,16 +268,23 @@ class OracleFrameFusion:
 # --------------------------------------------------------------------------------------
 # a9: attention probabilities of the last `num` queries (utils.py:27-57)
 # --------------------------------------------------------------------------------------
-def last_query_attention(query, key, num=1, is_causal=False, scale=None, enable_gqa=False):
+def last_query_attention(query, key, num=1, is_causal=False, scale=None, enable_gqa=False, attn_mask=None):
     """query [1, H, L, dh], key [1, Hk, S, dh] -> probabilities [1, H, num, S] in the activation
-    dtype: softmax(T(T(q K^T) * scale) + bias)."""
+    dtype: softmax(T(T(q K^T) * scale) + bias); bias = causal (utils.py:34-38) or the caller's attn_mask
+    (utils.py:40-44: -inf where a boolean mask is False, else the mask added into the T-typed bias)."""
     q = query[:, :, -num:, :]
     n_q, n_k = q.shape[-2], key.shape[-2]
     factor = 1 / math.sqrt(q.shape[-1]) if scale is None else scale
     bias = torch.zeros(n_q, n_k, dtype=q.dtype)
     if is_causal:
+        assert attn_mask is None                                                    # utils.py:35
         future = torch.ones(n_q, n_k, dtype=torch.bool).triu(diagonal=n_k - n_q + 1)
         bias.masked_fill_(future, float("-inf"))
+    if attn_mask is not None:
+        if attn_mask.dtype == torch.bool:
+            bias.masked_fill_(attn_mask.logical_not(), float("-inf"))
+        else:
+            bias += attn_mask
     if enable_gqa:
         key = key.repeat_interleave(q.shape[-3] // key.shape[-3], -3)
     w = q @ key.transpose(-2, -1) * factor

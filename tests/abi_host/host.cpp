@@ -1,6 +1,11 @@
 // A torch-free host of the C ABI: plain HIP runtime + libframefusion_hip.so, one merge step
 // (ff_merge_step) on a deterministic [L, d] bf16 input, results printed for tests/test_gpu_abi_host.py
 // to compare with the Python host on the same data.
+//   host F P d input.bin          one ff_merge_step, patch types as the only aux tensor
+//   host F P d input.bin full     two merge calls through the call context (ff_ctx_merge): the first with an
+//                                 `addend` (the residual add formed in the passes), M-RoPE style [3, L, 128] cos / sin
+//                                 aux tensors and the frame-major layout hint; the second on the compacted output with
+//                                 the maintained order (order_valid = 1)
 //   hipcc --offload-arch=gfx950 -O2 -I include tests/abi_host/host.cpp -L framefusion_amd -lframefusion_hip
 //         -Wl,-rpath,$PWD/framefusion_amd -o tests/abi_host/host
 #include <hip/hip_runtime.h>
@@ -18,6 +23,124 @@
 static uint16_t bf16_of(float f) {            // f is exactly representable (multiples of 1/8 in +-4)
     uint32_t b; memcpy(&b, &f, 4);
     return (uint16_t)(b >> 16);
+}
+
+
+static uint64_t fnv_words16(const std::vector<uint16_t>& v) {
+    uint64_t f = 1469598103934665603ull;
+    for (uint16_t x : v) { f ^= x; f *= 1099511628211ull; }
+    return f;
+}
+static uint64_t fnv_words64(const std::vector<int64_t>& v) {
+    uint64_t f = 1469598103934665603ull;
+    for (int64_t x : v) { f ^= (uint64_t)x; f *= 1099511628211ull; }
+    return f;
+}
+// addend row i, column c: a grid value the Python side recomputes (tests/test_gpu_abi_host.py: addend_of)
+static inline float addend_at(int i, int c) { return (float)((i * 31 + c * 17) % 17 - 8) * 0.125f; }
+// rotary-like table value for (plane, position, column), on the grid
+static inline float table_at(int which, int plane, int i, int c) { return (float)((which * 5 + plane * 7 + i * 3 + c) % 33 - 16) * 0.0625f; }
+
+static int full_mode(int F, int P, int d, int pre, int L, const std::vector<uint16_t>& h, const std::vector<int64_t>& pt,
+                     const char* path) {
+    const int dh = 128, planes = 3;
+    // hidden = base + addend exactly (all values multiples of 1/8 well inside bf16's exact range)
+    std::vector<uint16_t> base((size_t)L * d), add((size_t)L * d), tab[2];
+    for (int i = 0; i < L; ++i)
+        for (int c = 0; c < d; ++c) {
+            const uint32_t b = (uint32_t)h[(size_t)i * d + c] << 16;
+            float v; memcpy(&v, &b, 4);
+            const float a = addend_at(i, c);
+            base[(size_t)i * d + c] = bf16_of(v - a);
+            add[(size_t)i * d + c] = bf16_of(a);
+        }
+    for (int w = 0; w < 2; ++w) {
+        tab[w].resize((size_t)planes * L * dh);
+        for (int p = 0; p < planes; ++p)
+            for (int i = 0; i < L; ++i)
+                for (int c = 0; c < dh; ++c) tab[w][((size_t)p * L + i) * dh + c] = bf16_of(table_at(w, p, i, c));
+    }
+    void *dbase, *dadd, *dout, *dout2, *dpt, *dpt_out, *dpt_out2, *dtab[2], *dtab_out[2], *dtab_in2[2], *dtab_out2[2];
+    void *dorder, *dorder_next, *dinv, *dinv_next, *dsim, *dmember, *ddst, *dkeep, *dstats, *dws;
+    int64_t* stats_host;
+    const size_t wsb = ff_workspace_bytes(L, P), hb = (size_t)L * d * 2, tb = (size_t)planes * L * dh * 2;
+    CK(hipMalloc(&dbase, hb)); CK(hipMalloc(&dadd, hb)); CK(hipMalloc(&dout, hb)); CK(hipMalloc(&dout2, hb));
+    CK(hipMalloc(&dpt, L * 8)); CK(hipMalloc(&dpt_out, L * 8)); CK(hipMalloc(&dpt_out2, L * 8));
+    for (int w = 0; w < 2; ++w) { CK(hipMalloc(&dtab[w], tb)); CK(hipMalloc(&dtab_out[w], tb)); CK(hipMalloc(&dtab_in2[w], tb)); CK(hipMalloc(&dtab_out2[w], tb)); }
+    CK(hipMalloc(&dorder, L * 4)); CK(hipMalloc(&dorder_next, L * 4)); CK(hipMalloc(&dinv, L * 4)); CK(hipMalloc(&dinv_next, L * 4));
+    CK(hipMalloc(&dsim, L * 4)); CK(hipMalloc(&dmember, L)); CK(hipMalloc(&ddst, L * 4)); CK(hipMalloc(&dkeep, L));
+    CK(hipMalloc(&dstats, FF_STAT_WORDS * 8)); CK(hipMalloc(&dws, wsb));
+    CK(hipHostMalloc((void**)&stats_host, FF_STAT_WORDS * 8, hipHostMallocDefault));
+    memset(stats_host, 0, FF_STAT_WORDS * 8);
+    CK(hipMemcpy(dbase, base.data(), hb, hipMemcpyHostToDevice)); CK(hipMemcpy(dadd, add.data(), hb, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dpt, pt.data(), L * 8, hipMemcpyHostToDevice));
+    for (int w = 0; w < 2; ++w) CK(hipMemcpy(dtab[w], tab[w].data(), tb, hipMemcpyHostToDevice));
+    CK(hipMemset(dstats, 0, FF_STAT_WORDS * 8)); CK(hipMemset(dws, 0, wsb));
+    hipStream_t st; CK(hipStreamCreate(&st));
+
+    ff_ctx_t ctx; memset(&ctx, 0, sizeof ctx);
+    ctx.cap = L; ctx.order = (int32_t*)dorder; ctx.order_next = (int32_t*)dorder_next; ctx.inv = (int32_t*)dinv; ctx.inv_next = (int32_t*)dinv_next;
+    ctx.sim = dsim; ctx.member = (uint8_t*)dmember; ctx.dst = (int32_t*)ddst; ctx.keep = (uint8_t*)dkeep;
+    ctx.stats = (int64_t*)dstats; ctx.stats_host = stats_host; ctx.ws = dws; ctx.ws_bytes = wsb;
+
+    ff_merge_call_t call; memset(&call, 0, sizeof call);
+    ff_merge_result_t res[2];
+    call.hidden = dbase; call.addend = dadd; call.hidden_out = dout; call.patch_type = (const int64_t*)dpt;
+    call.dtype = FF_BF16; call.L = L; call.d = d; call.L_cap = L; call.patch_num = P; call.order_valid = 0;
+    call.threshold = 0.6015625; call.sub = 0.7; call.ratio_lb = 0.01; call.force_k = -1; call.fold = FF_FOLD_SEQUENTIAL;
+    call.hint_pre = pre; call.hint_frames = F; call.stream = st; call.n_aux = 3;
+    call.aux[0] = ff_aux_t{dpt, dpt_out, 8, 1};
+    call.aux[1] = ff_aux_t{dtab[0], dtab_out[0], dh * 2, planes};
+    call.aux[2] = ff_aux_t{dtab[1], dtab_out[1], dh * 2, planes};
+    FF(ff_ctx_merge(&ctx, &call, &res[0]));
+    const int64_t l1 = res[0].l_out;
+    std::vector<uint8_t> keep1(L);
+    CK(hipStreamSynchronize(st));
+    CK(hipMemcpy(keep1.data(), dkeep, L, hipMemcpyDeviceToHost));
+    // second call: the compacted sequence, its patch types and tables, the order the first call left (order_valid = 1)
+    ff_merge_call_t call2 = call;
+    call2.hidden = dout; call2.addend = nullptr; call2.hidden_out = dout2; call2.patch_type = (const int64_t*)dpt_out;
+    call2.L = l1; call2.L_cap = l1; call2.order_valid = 1; call2.hint_frames = 0; call2.sub = 0.55;
+    call2.aux[0] = ff_aux_t{dpt_out, dpt_out2, 8, 1};
+    call2.aux[1] = ff_aux_t{dtab_in2[0], dtab_out2[0], dh * 2, planes};
+    call2.aux[2] = ff_aux_t{dtab_in2[1], dtab_out2[1], dh * 2, planes};
+    // the first call wrote its tables as [planes, L_cap = L, dh]; the second call reads [planes, l1, dh] contiguous:
+    // repack plane by plane (a host that keeps capacity-strided views would pass them through its own gather)
+    for (int w = 0; w < 2; ++w)
+        for (int p = 0; p < planes; ++p)
+            CK(hipMemcpyAsync((char*)dtab_in2[w] + (size_t)p * l1 * dh * 2, (char*)dtab_out[w] + (size_t)p * L * dh * 2,
+                              (size_t)l1 * dh * 2, hipMemcpyDeviceToDevice, st));
+    const int64_t swaps_before = ctx.swaps;
+    FF(ff_ctx_merge(&ctx, &call2, &res[1]));
+    CK(hipStreamSynchronize(st));
+    const int64_t l2 = res[1].l_out;
+    std::vector<uint16_t> o1((size_t)l1 * d), o2((size_t)l2 * d), t2((size_t)planes * l2 * dh);
+    std::vector<int64_t> p2(l2);
+    std::vector<uint8_t> keep2(l1);
+    CK(hipMemcpy(o1.data(), dout, o1.size() * 2, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(keep2.data(), dkeep, l1, hipMemcpyDeviceToHost));
+    printf("L %d ORDER_REUSED %d\n", L, (int)(ctx.swaps == swaps_before + (l2 != l1) ? 1 : 0));
+    for (int c = 0; c < 2; ++c)
+        printf("CALL %d NV %lld FTN %lld COUNT %lld BRANCH %lld K %lld LOUT %lld UNHINTED %lld\n", c, (long long)res[c].nv, (long long)res[c].ftn,
+               (long long)res[c].count, (long long)res[c].branch, (long long)res[c].k, (long long)res[c].l_out, (long long)res[c].unhinted);
+    printf("HIDDEN1_FNV %016llx\n", (unsigned long long)fnv_words16(o1));
+    if (l2 != l1) {
+        CK(hipMemcpy(o2.data(), dout2, o2.size() * 2, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(p2.data(), dpt_out2, l2 * 8, hipMemcpyDeviceToHost));
+        printf("HIDDEN2_FNV %016llx\nPTYPE2_FNV %016llx\n", (unsigned long long)fnv_words16(o2), (unsigned long long)fnv_words64(p2));
+        for (int w = 0; w < 2; ++w) {
+            for (int p = 0; p < planes; ++p)
+                CK(hipMemcpy(t2.data() + (size_t)p * l2 * dh, (char*)dtab_out2[w] + (size_t)p * l1 * dh * 2, (size_t)l2 * dh * 2, hipMemcpyDeviceToHost));
+            printf("TABLE%d_FNV %016llx\n", w, (unsigned long long)fnv_words16(t2));
+        }
+    }
+    printf("KEEP1 "); for (int i = 0; i < L; ++i) putchar(keep1[i] ? '1' : '0'); putchar('\n');
+    printf("KEEP2 "); for (int i = 0; i < l1; ++i) putchar(keep2[i] ? '1' : '0'); putchar('\n');
+    FILE* f = fopen(path, "wb");
+    if (!f) return 5;
+    fwrite(h.data(), 2, h.size(), f);
+    fclose(f);
+    return 0;
 }
 
 int main(int argc, char** argv) {
@@ -48,6 +171,7 @@ int main(int argc, char** argv) {
         }
         if (vis) pt[i] = (i - pre) % P;
     }
+    if (argc > 5 && !strcmp(argv[5], "full")) return full_mode(F, P, d, pre, L, h, pt, argv[4]);
     void *dh, *dout, *dpt, *dorder, *dinv, *dsim, *dmember, *ddst, *dkeep, *dstats, *dws, *dpt_out;
     const size_t wsb = ff_workspace_bytes(L, P);
     CK(hipMalloc(&dh, h.size() * 2)); CK(hipMalloc(&dout, h.size() * 2)); CK(hipMalloc(&dpt, L * 8)); CK(hipMalloc(&dpt_out, L * 8));

@@ -64,7 +64,7 @@ def test_argument_validation_without_gpu():
     assert lib.ff_plan_prune(16, 1, 10, 2, 5, 2, 16, 16, 16, 16, 16, 64, None) == -4       # workspace too small
     assert lib.ff_merge_compact(None, None, 1, 10, 64, 10, None, None, 1, None, None, None, 0, None) == -1
     assert lib.ff_head_mean(None, 1, 4, 1, 10, None, None) == -1
-    assert lib.ff_last_query_attention(16, 16, 1, 6, 4, 1, 10, 64, 0.1, 1, 16, None, 0, 0, None, 0, 16, 1 << 20, None) == -1  # H % H_kv
+    assert lib.ff_last_query_attention(16, 16, 1, 6, 4, 1, 10, 64, 0.1, 1, None, 16, None, 0, 0, None, 0, 16, 1 << 20, None) == -1  # H % H_kv
     # empty problems are a no-op
     assert lib.ff_build_order(16, 0, 4, 16, None, 16, 16, 1 << 24, None) == 0
     assert lib.ff_pair_similarity(16, 1, 0, 64, 16, 16, 16, 16, None) == 0
@@ -126,6 +126,25 @@ def test_context_calls_validate_before_any_hip_call():
     assert lib.ff_ctx_prune(a(ctx), None) == -1
     assert lib.ff_ctx_reset(None, None) == -1
     assert len(lib.ff_error_string(_lib.ERR_DEVICE)) > 4 and len(lib.ff_error_string(_lib.ERR_STATE)) > 4
+
+
+def test_library_carries_the_hash_of_its_sources(monkeypatch, tmp_path):
+    """ff_source_hash(): the binary names the sources it was compiled from; load() refuses (rebuilds) a stale one."""
+    import shutil
+    lib = _lib.load()
+    assert lib.ff_source_hash().decode() == _lib.source_hash()
+    # a copy of the tree whose sources were edited after the build: the stamp no longer matches
+    inc = tmp_path / "include"
+    inc.mkdir()
+    shutil.copy(HEADER, inc / "framefusion_hip.h")
+    pkg = tmp_path / "pkg"
+    shutil.copytree(_lib.CSRC, pkg / "csrc", ignore=shutil.ignore_patterns("*.o"))
+    with open(pkg / "csrc" / "ff_common.h", "a") as f:
+        f.write("\n// edited\n")
+    monkeypatch.setattr(_lib, "CSRC", str(pkg / "csrc"))
+    assert _lib.source_hash() != lib.ff_source_hash().decode()
+    opened, got, want = _lib._open_checked()
+    assert opened is None and got == lib.ff_source_hash().decode() and want == _lib.source_hash()
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

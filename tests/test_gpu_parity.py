@@ -16,7 +16,7 @@ from framefusion_amd.synth import video_tokens, rotary_tables
 from oracle import ff_oracle as orc
 from tests import harness
 from tests.conftest import DT, from_bits, same_bits, Golden
-from tests.test_oracle_golden import make_pos, SIM_CASES, FWD_CASES, CAS_CASES, IMP_CASES
+from tests.test_oracle_golden import make_pos, SIM_CASES, FWD_CASES, CAS_CASES, IMP_CASES, MASK_CASES, load_mask
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -336,6 +336,45 @@ def test_importance_matrix_core_path(dtype, dh, H, Hk, num, S):
     assert torch.allclose(imp.reshape(-1).cpu().float(), torch.mean(want, dim=(1, 2))[0].float(), rtol=tol, atol=1e-30)
 
 
+@pytest.mark.parametrize("name", MASK_CASES)
+def test_importance_attn_mask_golden(golden, name):
+    """scaled_dot_product_attention(attn_mask=...) (utils.py:40-44) against the real reference's outputs."""
+    g = golden("importance_mask")
+    dtype = DT[str(g[f"{name}/dtype"])]
+    H, Hk, S, dh, num = (int(x) for x in g[f"{name}/meta"])
+    q = from_bits(g[f"{name}/q"], dtype)[None]
+    k = from_bits(g[f"{name}/k"], dtype)[None]
+    mask = load_mask(g, name)
+    w = ffa.scaled_dot_product_attention(dev(q), dev(k), None, num=num, attn_mask=dev(mask), enable_gqa=H != Hk)
+    want = from_bits(g[f"{name}/weights"], dtype)
+    tol = 2 ** -7 if dtype != torch.float32 else 2e-6
+    assert torch.allclose(w[0].cpu().float(), want.float(), rtol=tol, atol=1e-30)
+    with pytest.raises(AssertionError):
+        ffa.scaled_dot_product_attention(dev(q), dev(k), None, num=num, attn_mask=dev(mask), is_causal=True)
+
+
+@pytest.mark.parametrize("kind", ["bool", "add"])
+@pytest.mark.parametrize("dh,H,Hk,num,S", [(128, 28, 4, 4, 1111), (64, 8, 2, 1, 700), (128, 64, 8, 1, 5000)])
+def test_importance_attn_mask_matrix_core_path(kind, dh, H, Hk, num, S):
+    """The same on the MFMA score kernel (16-bit T, dh 64 / 128) at sizes with several tiles per row - the rows'
+    statistics folded by the last workgroup of every kv head - against the oracle on grid inputs."""
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(dh + S + num)
+    q = harness.snap(0.5 * torch.randn(1, H, num, dh, generator=g), dtype)
+    k = harness.snap(0.5 * torch.randn(1, Hk, S, dh, generator=g), dtype)
+    if kind == "bool":
+        mask = torch.rand(num, S, generator=g) < 0.6
+        mask[:, S // 2] = True
+    else:
+        mask = harness.snap(torch.randn(1, S, generator=g), dtype)
+        mask[:, 5] = float("-inf")
+    want = orc.last_query_attention(q, k, num=num, enable_gqa=True, attn_mask=mask)
+    for rep in range(3):                                    # the workspace (and its arrival counters) is reused call after call
+        got = ffa.scaled_dot_product_attention(dev(q), dev(k), None, num=num, attn_mask=dev(mask), enable_gqa=True)
+        assert torch.allclose(got.cpu().float(), want.float(), rtol=2 ** -7, atol=1e-30), rep
+        assert float((got.cpu().float() != want.float()).float().mean()) <= 2e-3, rep
+
+
 def test_importance_odd_head_size_general_path():
     """dh * sizeof(T) / 16 not a power of two (dh = 24 bf16 -> 3 lanes per key): the general kernels"""
     g = torch.Generator().manual_seed(5)
@@ -554,3 +593,141 @@ def test_layout_hint_from_the_scalars_the_packers_pass():
     assert f._layout_hint == (3, F + 2)
     hg, pg, _ = f(dev(h), dev(torch.arange(L)[None]), None)
     assert torch.equal(pg.cpu(), po) and same_bits(hg.cpu(), ho)
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference's public position handlers (main.py:142-178) and the attention-mask gather
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["qwen2", "mrope", "ids"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_position_handlers_match_torch_indexing(kind, dtype):
+    """position_embedding_handler_at_pruning / _at_merging are plain index / boolean-mask gathers along the token axis
+    (main.py:142-178): bit-identical to torch's own indexing, list containers mutated in place."""
+    L = 1237
+    g = torch.Generator().manual_seed(L)
+    if kind == "ids":
+        pe = torch.randint(0, 50000, (1, L), generator=g)
+    else:
+        shape = (3, 1, L, 48) if kind == "mrope" else (1, L, 48)
+        pe = [torch.randn(shape, generator=g).to(dtype), torch.randn(shape, generator=g).to(dtype)]
+    keep = torch.sort(torch.randperm(L, generator=g)[:400]).values
+    mask = torch.zeros(1, L, dtype=torch.bool)
+    mask[0, keep] = True
+    want = orc.gather_position_embeddings([t.clone() for t in pe] if isinstance(pe, list) else pe.clone(), keep)
+    f = ffa.FrameFusion()
+    for how in ("pruning", "merging"):
+        arg = [t.to(DEV) for t in pe] if isinstance(pe, list) else pe.to(DEV)
+        if how == "pruning":
+            got = f.position_embedding_handler_at_pruning(arg, keep.to(DEV))
+        else:
+            got = f.position_embedding_handler_at_merging(arg, mask.to(DEV))
+        if isinstance(pe, list):
+            assert got is arg                                              # the list is mutated in place (main.py:146-150)
+            for a, b in zip(got, want):
+                assert a.shape == b.shape and same_bits(a.cpu().contiguous(), b.contiguous()), (how, kind)
+        else:
+            assert torch.equal(got.cpu(), want), (how, kind)
+    # at_pruning follows the index tensor literally (any order, repeats, negative indices)
+    odd = torch.tensor([5, 5, L - 1, -1, 0, 17])
+    arg = [t.to(DEV) for t in pe] if isinstance(pe, list) else pe.to(DEV)
+    got = f.position_embedding_handler_at_pruning(arg, odd.to(DEV))
+    want = orc.gather_position_embeddings([t.clone() for t in pe] if isinstance(pe, list) else pe.clone(), odd)
+    for a, b in zip(got if isinstance(got, list) else [got], want if isinstance(want, list) else [want]):
+        assert torch.equal(a.cpu().float(), b.float())
+
+
+@pytest.mark.parametrize("mdtype", [torch.bfloat16, torch.float32, torch.bool, torch.float64])
+@pytest.mark.parametrize("L", [97, 640, 1531])
+def test_attention_mask_is_gathered_like_the_reference(mdtype, L):
+    """main.py:137-138 / 99-100: attention_mask[:, :, keep, :][:, :, :, keep] through the two-level gather kernel, every
+    element size, lengths whose output rows are and are not whole 16-byte words; merge call and prune call."""
+    F, P, d = (L - 7) // 10, 10, 64
+    h, pt = video_tokens(F, P, d, p_change=0.5, sigma=0.3, sigma_hi=1.6, seed=L, pre=3, post=L - 3 - F * P, grid=0.125)
+    assert h.shape[1] == L
+    g = torch.Generator().manual_seed(L + 1)
+    if mdtype == torch.bool:
+        mask = torch.rand(1, 1, L, L, generator=g) < 0.5
+    else:
+        mask = torch.randn(1, 1, L, L, generator=g).to(mdtype)
+    want, mo = harness.run_cascade(orc.OracleFrameFusion(0.3, 0.6, 0.1), h.clone(), pt.clone(), P, torch.arange(L)[None], mask.clone(),
+                                   layers=3, heads=2, num=1, start=3, n_visual=F * P)
+    got, mg = harness.run_cascade(ffa.FrameFusion(0.3, 0.6, 0.1), dev(h), dev(pt), P, dev(torch.arange(L)[None]), dev(mask),
+                                  layers=3, heads=2, num=1, start=3, n_visual=F * P)
+    assert [r["length"] for r in got] == [r["length"] for r in want] and got[-1]["finish_pruning"]
+    assert mg.shape == mo.shape and mg.dtype == mo.dtype
+    assert torch.equal(mg.cpu().to(torch.float64), mo.to(torch.float64))
+
+
+# ---------------------------------------------------------------------------------------------
+# the two documented deviations from the reference (DESIGN.md section 6), pinned: where exactly the HIP path and the
+# oracle (which mirrors the reference) part, and that nothing else does
+# ---------------------------------------------------------------------------------------------
+def test_deviation_run_lengths_beyond_256_are_exact_here():
+    """main.py:269-276 stores run lengths in the activation dtype: a run of 291 folded frames becomes bf16(291) = 292,
+    the reference then anchors the run one slot early.  The HIP path derives runs from the member flags (exact at any
+    length): it equals the oracle with exact integer run lengths bit for bit, has the reference's keep mask, and
+    differs from the stock oracle (which mirrors the reference) only in rows of patches that have a run longer than 256."""
+    F, P, d = 300, 4, 64
+    h, pt = video_tokens(F, P, d, p_change=0.0, sigma=0.3, seed=11, pre=2, post=2, grid=0.125)
+    h = h.clone()
+    for fr in range(40, F, 50):                              # patch 3 breaks every 50 frames: no long run there
+        h[0, 2 + fr * P + 3] = -h[0, 2 + fr * P + 3]
+    L = h.shape[1]
+
+    def run_oracle():
+        o = orc.OracleFrameFusion(0.02, 0.6, 0.0)
+        o.prepare(pt.clone(), P, 2, 2 + F * P - 1, F * P, L)
+        out = o.forward(h.clone(), torch.arange(L)[None], None)
+        flags = torch.zeros(F * P, dtype=torch.long)
+        flags[o.last_merge_idx] = 1
+        return o, out, flags
+    o_ref, (h_ref, p_ref, _), flags = run_oracle()
+    stock = orc.run_lengths
+    lens = stock(flags[None])[0]
+    order = o_ref.last_order.reshape(-1)
+    long_patches = set(int(pt[0, order[j]]) for j in torch.nonzero(lens > 256).reshape(-1).tolist())
+    assert long_patches and 3 not in long_patches            # the case is what it claims to be
+    orc.run_lengths = lambda fl: stock(fl.to(torch.long))                # exact integer run lengths
+    try:
+        o_exact, (h_exact, p_exact, _), _ = run_oracle()
+    finally:
+        orc.run_lengths = stock
+    f = ffa.FrameFusion(0.02, 0.6, 0.0)
+    f.prepare(dev(pt), P, 2, 2 + F * P - 1, F * P, L)
+    hg, pg, _ = f(dev(h), dev(torch.arange(L)[None]), None)
+    assert torch.equal(pg.cpu(), p_exact) and torch.equal(pg.cpu(), p_ref)          # the keep mask never depended on the lengths
+    assert same_bits(hg.cpu(), h_exact)
+    differ = (hg.cpu().view(torch.int16) != h_ref.view(torch.int16)).any(dim=-1)[0]
+    assert bool(differ.any())                                                       # the reference really is off here
+    differing_patches = set(int(pt[0, i]) for i in pg.cpu()[0][differ].tolist())
+    assert differing_patches <= long_patches                                        # ... and only there (text = -1 and patch 3 agree)
+
+
+def test_deviation_by_patch_slot_zero_never_folds():
+    """main.py:290: with a top-k larger than the number of valid pairs the reference selects IGNORE (-2) entries, slot 0
+    among them, whose "anchor" index -1 wraps to the LAST by-patch slot.  Only reachable when the threshold itself is
+    below -2 (count/ftn >= sub forces k <= count otherwise).  Here slot 0 is never a member: the first by-patch token
+    survives, everything else is the reference's."""
+    F, P, d = 2, 4, 64
+    h, pt = video_tokens(F, P, d, p_change=0.0, sigma=0.3, seed=3, pre=2, post=1, grid=0.125)
+    L = h.shape[1]
+    o = orc.OracleFrameFusion(0.3, -5.0, 0.0)
+    o.prepare(pt.clone(), P, 2, 2 + F * P - 1, F * P, L)
+    ho, po, _ = o.forward(h.clone(), torch.arange(L)[None], None)
+    assert o.last_merge_idx.tolist()[0] == 0 and o.last_merge_idx.numel() == 5          # k = 5 > 4 valid pairs: slot 0 selected
+    f = ffa.FrameFusion(0.3, -5.0, 0.0)
+    f.prepare(dev(pt), P, 2, 2 + F * P - 1, F * P, L)
+    hg, pg, _ = f(dev(h), dev(torch.arange(L)[None]), None)
+    first = int(o.last_order.reshape(-1)[0])                                             # sequence position of by-patch slot 0
+    assert f.last_call["branch"] == 1 and f.last_call["k"] == 5
+    assert sorted(pg.cpu()[0].tolist()) == sorted(po[0].tolist() + [first])              # one more survivor: that token
+    # every row the two have in common is bit-identical except the run the reference folded slot 0 into
+    last = int(o.last_order.reshape(-1)[-1])
+    for i in po[0].tolist():
+        a = hg.cpu()[0, int((pg.cpu()[0] == i).nonzero()[0])]
+        b = ho[0, int((po[0] == i).nonzero()[0])]
+        anchor_of_last_run = int(o.last_order.reshape(-1)[-2])
+        if i == anchor_of_last_run:
+            continue
+        assert same_bits(a[None, None], b[None, None]), i
+    assert last not in po[0].tolist()

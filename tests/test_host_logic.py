@@ -42,8 +42,16 @@ def test_constants_and_surface():
     for name in ("patch_type", "patch_num", "image_token_start_index", "image_token_end_index",
                  "image_token_length", "original_length"):
         assert hasattr(f, name)
-    for name in ("compute_similarity_and_token_index_by_patch", "merge_tokens_and_get_mask", "_compute_pruning_ratio"):
+    for name in ("compute_similarity_and_token_index_by_patch", "merge_tokens_and_get_mask", "_compute_pruning_ratio",
+                 "position_embedding_handler_at_pruning", "position_embedding_handler_at_merging"):     # main.py:142,161
         assert callable(getattr(ffa.FrameFusion, name))
+    # the handlers' container checks come before any device work (main.py:155-157, 175-177)
+    with pytest.raises(NotImplementedError, match="Only support 2D"):
+        f.position_embedding_handler_at_pruning(torch.zeros(1, 3, 2), torch.tensor([0]))
+    with pytest.raises(NotImplementedError, match="list or tensor"):
+        f.position_embedding_handler_at_merging((torch.zeros(1, 3, 2),) * 2, torch.ones(1, 3, dtype=torch.bool))
+    with pytest.raises(AssertionError):
+        f.position_embedding_handler_at_merging([torch.zeros(1, 3, 2)], torch.ones(1, 3, dtype=torch.bool))
 
 
 def test_no_cpu_fallback():

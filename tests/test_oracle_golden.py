@@ -150,6 +150,36 @@ def test_importance(golden, name):
     assert torch.allclose(imp.float(), from_bits(g[f"{name}/importance"], dtype).float(), rtol=2 ** -7, atol=1e-30)
 
 
+MASK_CASES = Golden("importance_mask").cases()
+
+
+def load_mask(g, name):
+    kind = str(g[f"{name}/mask_dtype"])
+    raw = g[f"{name}/mask"]
+    if kind == "bool":
+        return torch.from_numpy(raw.copy())
+    if kind == "fp32":
+        return torch.from_numpy(raw.copy())
+    return from_bits(raw, DT[kind])
+
+
+@pytest.mark.parametrize("name", MASK_CASES)
+def test_importance_with_attn_mask(golden, name):
+    """utils.py:40-44 (boolean / additive attn_mask): the oracle against what the real reference produced
+    (oracle/make_golden_mask.py)."""
+    g = golden("importance_mask")
+    dtype = DT[str(g[f"{name}/dtype"])]
+    H, Hk, S, dh, num = (int(x) for x in g[f"{name}/meta"])
+    q = from_bits(g[f"{name}/q"], dtype)[None]
+    k = from_bits(g[f"{name}/k"], dtype)[None]
+    w = orc.last_query_attention(q, k, num=num, enable_gqa=H != Hk, attn_mask=load_mask(g, name))
+    want = from_bits(g[f"{name}/weights"], dtype)
+    assert torch.allclose(w[0].float(), want.float(), rtol=2 ** -7, atol=1e-30)
+    assert float((w[0].float() != want.float()).float().mean()) <= 0.02
+    with pytest.raises(AssertionError):                                      # utils.py:35
+        orc.last_query_attention(q, k, num=num, is_causal=True, attn_mask=load_mask(g, name))
+
+
 def test_topk_tie_rule():
     x = torch.tensor([.5, .75, .75, .75, .25, .75])
     assert orc.topk_lowest_index(x, 3).tolist() == [1, 2, 3]
