@@ -66,3 +66,41 @@ def test_bench_refuses_to_run_without_a_gpu():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
                          capture_output=True, text=True, timeout=240, cwd=ROOT)
     assert res.returncode == 2 and "MI355X" in res.stderr
+
+
+def test_nccl_init_plumbing_without_a_gpu(monkeypatch):
+    """dp.init("nccl", device): what reaches torch.distributed (backend name, device_id=, the one-rank form, the
+    rendezvous + HSA_ENABLE_IPC_MODE_LEGACY defaults), checked by capturing the call - and the real call on this GPU-less
+    box fails where RCCL needs its device, not earlier (argument errors would surface before that)."""
+    import torch.distributed as dist
+    from framefusion_amd import dp
+    calls = []
+    monkeypatch.setattr(dist, "is_initialized", lambda: False)
+    monkeypatch.setattr(dist, "init_process_group", lambda backend, **kw: calls.append((backend, kw)))
+    for k in ("MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "1")
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    dev = torch.device("cuda", 1)
+    assert dp.init("nccl", dev) is dist
+    assert calls == [("nccl", {"device_id": dev})]                           # world / rank come from the launcher's env
+    assert os.environ["MASTER_ADDR"] == "127.0.0.1" and os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    calls.clear()
+    assert dp.init("gloo", dev) is dist and calls == [("gloo", {})]          # gloo: no device binding
+    calls.clear()
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    assert dp.init("nccl", dev) is None and calls == []                      # one process: no group ...
+    assert dp.init("nccl", dev, force=True) is dist                          # ... unless asked for: a one-rank RCCL group
+    assert calls == [("nccl", {"world_size": 1, "rank": 0, "device_id": dev})]
+    monkeypatch.undo()
+    if not torch.cuda.is_available():
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(dp.free_port()), PYTHONPATH=ROOT)
+        code = ("import torch; from framefusion_amd import dp\n"
+                "try:\n    dp.init('nccl', torch.device('cuda', 0), force=True); print('JOINED')\n"
+                "except Exception as e:\n    print('REFUSED', type(e).__name__, str(e)[:200])\n")
+        res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+        assert "REFUSED" in res.stdout and "JOINED" not in res.stdout, (res.stdout, res.stderr[-500:])
+        assert "TypeError" not in res.stdout                                 # it got as far as the backend itself

@@ -48,6 +48,18 @@ def test_two_ranks_over_rccl():
 
 
 @pytest.mark.timeout(900)
+def test_one_rank_group_over_rccl():
+    """What a 1-GPU box can show of the RCCL path: `--force-dist` forms a ONE-rank process group on the "nccl" backend
+    (dp.init(..., device_id=...) with HSA_ENABLE_IPC_MODE_LEGACY=0), and rank 0's config broadcast, the all_gather of the
+    per-rank records and the all_reduce of time / units all execute inside RCCL on the MI355X before the line is printed.
+    (Two ranks on one device are refused by RCCL itself: "Duplicate GPU detected".)"""
+    out = run_bench("--steps", "10", "--warmup", "3", "--force-dist", "--no-cpu-baseline", "--no-extra")
+    assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and out["collective_backend"] == "nccl"
+    assert [r["rank"] for r in out["per_rank"]] == [0] and out["per_rank"][0]["tokens_in"] == 64 * 576
+    assert 0 < out["per_rank"][0]["tokens_out"] < 64 * 576 and out["value"] > 0
+
+
+@pytest.mark.timeout(900)
 def test_two_ranks_sharing_one_gpu_over_gloo():
     out = run_bench("--gpus", "2", "--steps", "10", "--warmup", "3", "--backend", "gloo", "--oversubscribe")
     check_multi(out, 2)
