@@ -117,7 +117,7 @@ PROTOTYPES = {
     "ff_gather_tokens_by_index": (_i32, [_vp, _i64, _i64, C.POINTER(FFAux), _i32, _vp]),
     "ff_gather_tokens_by_mask": (_i32, [_vp, _i64, _i64, _vp, _vp, C.POINTER(FFAux), _i32, _vp]),
     "ff_head_mean": (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _vp]),
-    "ff_last_query_attention": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _i64, _i64, _f64, _i32, _vp, _vp, _vp, _i64, _i64,
+    "ff_last_query_attention": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f64, _i32, _vp, _vp, _vp, _i64, _i64,
                                        _vp, _sz, _vp, _sz, _vp]),
     "ff_last_query_workspace_bytes": (_sz, [_i32, _i64, _i64, _i64, _i64]),
     "ff_merge_begin": (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _i64, _i32, _f64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _sz,

@@ -20,9 +20,11 @@ namespace ff {
 // reads) - no cross-lane reduction, stores coalesced over s.
 constexpr int kRowsPerBlock = 8;
 
+struct KStrides { int64_t head, key; };          // bytes from one kv head / one key to the next
+
 template <int DT>
 __global__ __launch_bounds__(256) void k_lq_scores(const void* __restrict__ q, const void* __restrict__ k,
-                                                   int H, int H_kv, int num, int S, int dh, float scale,
+                                                   int64_t k_head_stride, int64_t k_key_stride, int H, int H_kv, int num, int S, int dh, float scale,
                                                    int causal, const void* __restrict__ bias, float* __restrict__ scores) {
     using A = Act<DT>;
     constexpr int E = A::kPer16;
@@ -40,7 +42,7 @@ __global__ __launch_bounds__(256) void k_lq_scores(const void* __restrict__ q, c
     __syncthreads();
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= S) return;
-    const char* krow = (const char*)k + ((int64_t)hk * S + s) * dh * A::kBytes;
+    const char* krow = (const char*)k + (int64_t)hk * k_head_stride + (int64_t)s * k_key_stride;
     float acc[kRowsPerBlock];
 #pragma unroll
     for (int r = 0; r < kRowsPerBlock; ++r) acc[r] = 0.f;
@@ -255,7 +257,7 @@ __device__ inline float group_sum(float v) {
 }
 
 template <int DT, int LPK>
-__global__ __launch_bounds__(256) void k_lq_tile(const void* __restrict__ q, const void* __restrict__ k, int H, int H_kv,
+__global__ __launch_bounds__(256) void k_lq_tile(const void* __restrict__ q, const void* __restrict__ k, int64_t k_head_stride, uint32_t k_key_stride, int H, int H_kv,
                                                  int num, int S, float scale, int causal, const void* __restrict__ bias, int pitch,
                                                  void* __restrict__ scores, float2* __restrict__ tstats, int tiles) {
     using A = Act<DT>;
@@ -274,13 +276,13 @@ __global__ __launch_bounds__(256) void k_lq_tile(const void* __restrict__ q, con
     }
     __syncthreads();
     const uint32_t row_bytes = (uint32_t)LPK * 16u;
-    const __amdgpu_buffer_rsrc_t krs = make_rsrc((const char*)k + (size_t)hk * S * row_bytes, (uint32_t)S * row_bytes);
+    const __amdgpu_buffer_rsrc_t krs = make_rsrc((const char*)k + (int64_t)hk * k_head_stride, (uint32_t)(S - 1) * k_key_stride + row_bytes);
     const int part = lane & (LPK - 1), slot = lane / LPK;
 #pragma unroll 2
     for (int it = 0; it < kWave / KPW; ++it) {
         const int key_local = w * kWave + it * KPW + slot;
         const int s_key = tile * kLqKeys + key_local;
-        const uint4 kv = buf_load16(krs, (uint32_t)s_key * row_bytes + (uint32_t)part * 16u);      // past S: zeros
+        const uint4 kv = s_key < S ? buf_load16(krs, (uint32_t)s_key * k_key_stride + (uint32_t)part * 16u) : make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < kLqRows; ++r) {
             const float acc = group_sum<LPK>(dot16<DT>(kv, q_lds[r][part], 0.f));
@@ -333,7 +335,7 @@ typedef short mfma_ab_t __attribute__((ext_vector_type(8)));
 typedef float mfma_cd_t __attribute__((ext_vector_type(16)));
 
 template <int DT, int NK, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void k_lq_mfma(const void* __restrict__ q, const void* __restrict__ k, int H, int H_kv,
+__global__ __launch_bounds__(64 * WAVES) void k_lq_mfma(const void* __restrict__ q, const void* __restrict__ k, int64_t k_head_stride, uint32_t k_key_stride, int H, int H_kv,
                                                  int num, int S, float scale, int causal, const void* __restrict__ bias, int pitch,
                                                  void* __restrict__ scores, float2* __restrict__ tstats, int tiles) {
     using A = Act<DT>;
@@ -357,7 +359,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_lq_mfma(const void* __restrict__
             bfrag[kk] = __builtin_bit_cast(mfma_ab_t, v);
         }
     }
-    const __amdgpu_buffer_rsrc_t krs = make_rsrc((const char*)k + (size_t)hk * S * row_bytes, (uint32_t)S * row_bytes);
+    // (keys may be rows of a wider tensor - the [S, H_kv, dh] layout attention projections produce: any 16-byte
+    // aligned strides; the resource ends with the last key's row)
+    const __amdgpu_buffer_rsrc_t krs = make_rsrc((const char*)k + (int64_t)hk * k_head_stride, (uint32_t)(S - 1) * k_key_stride + row_bytes);
     const int key0 = tile * (64 * WAVES) + w * 64;
     mfma_cd_t acc[2];
 #pragma unroll
@@ -365,7 +369,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_lq_mfma(const void* __restrict__
         uint4 a[NK];
 #pragma unroll
         for (int kk = 0; kk < NK; ++kk)
-            a[kk] = buf_load16(krs, (uint32_t)(key0 + b * 32 + col) * row_bytes + (uint32_t)kk * 32u + (uint32_t)half * 16u);   // keys past S: zeros
+            a[kk] = key0 + b * 32 + col < S ? buf_load16(krs, (uint32_t)(key0 + b * 32 + col) * k_key_stride + (uint32_t)kk * 32u + (uint32_t)half * 16u)
+                                            : make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (int x = 0; x < 16; ++x) acc[b][x] = 0.f;
 #pragma unroll
@@ -493,7 +498,7 @@ __global__ __launch_bounds__(256) void k_lq_finish(const void* __restrict__ scor
 }
 
 template <int DT>
-static int launch_lq_general(const void* q, const void* k, int64_t H, int64_t H_kv, int64_t num, int64_t S, int64_t dh,
+static int launch_lq_general(const void* q, const void* k, KStrides ks, int64_t H, int64_t H_kv, int64_t num, int64_t S, int64_t dh,
                              double scale, int causal, const void* bias, void* weights, void* importance, void* ws, int64_t lo, int64_t hi,
                              int* l0, int* t16_end, hipStream_t st) {
     float* scores = (float*)ws;
@@ -502,7 +507,7 @@ static int launch_lq_general(const void* q, const void* k, int64_t H, int64_t H_
     const size_t lds = (size_t)kRowsPerBlock * dh * sizeof(float);
     hipLaunchKernelGGL(k_lq_scores<DT>, dim3((unsigned)((S + 255) / 256), (unsigned)H_kv,
                                              (unsigned)((rows + kRowsPerBlock - 1) / kRowsPerBlock)),
-                       dim3(256), lds, st, q, k, (int)H, (int)H_kv, (int)num, (int)S, (int)dh, (float)scale, causal, bias,
+                       dim3(256), lds, st, q, k, ks.head, ks.key, (int)H, (int)H_kv, (int)num, (int)S, (int)dh, (float)scale, causal, bias,
                        scores);
     hipLaunchKernelGGL(k_lq_softmax<DT>, dim3((unsigned)(H * num)), dim3(256), 0, st, scores, (int)S, probs, weights);
     if (importance)
@@ -537,13 +542,13 @@ size_t lq_ws_bytes(int dtype, int64_t H, int64_t num, int64_t S, int64_t dh) {
 }
 
 template <int DT>
-static int launch_lq(const void* q, const void* k, int64_t H, int64_t H_kv, int64_t num, int64_t S, int64_t dh,
+static int launch_lq(const void* q, const void* k, KStrides ks, int64_t H, int64_t H_kv, int64_t num, int64_t S, int64_t dh,
                      double scale, int causal, const void* bias, void* weights, void* importance, void* ws, int64_t lo, int64_t hi,
                      int* l0, int* t16_end, hipStream_t st) {
     constexpr int kB = Act<DT>::kBytes;
     const int64_t lpk = dh * kB / 16;
     const bool tiled = (dh * kB) % 16 == 0 && lpk >= 1 && lpk <= 64 && (lpk & (lpk - 1)) == 0 && H * num <= 4096;
-    if (!tiled) return launch_lq_general<DT>(q, k, H, H_kv, num, S, dh, scale, causal, bias, weights, importance, ws, lo, hi, l0, t16_end, st);
+    if (!tiled) return launch_lq_general<DT>(q, k, ks, H, H_kv, num, S, dh, scale, causal, bias, weights, importance, ws, lo, hi, l0, t16_end, st);
     const int rows = (int)((H / H_kv) * num), rows_total = (int)(H * num);
     const int tiles = (int)((S + kLqKeys - 1) / kLqKeys);
     void* scores = ws;
@@ -561,7 +566,7 @@ static int launch_lq(const void* q, const void* k, int64_t H, int64_t H_kv, int6
             const int tiles_m = (int)((S + 64 * waves - 1) / (64 * waves));
             const dim3 mgrid((unsigned)tiles_m, (unsigned)H_kv, (unsigned)zg);
 #define FF_LQ_MFMA(NK)                                                                                                         \
-    hipLaunchKernelGGL((k_lq_mfma<DT, NK, waves>), mgrid, dim3(64 * waves), 0, st, q, k, (int)H, (int)H_kv, (int)num, (int)S,   \
+    hipLaunchKernelGGL((k_lq_mfma<DT, NK, waves>), mgrid, dim3(64 * waves), 0, st, q, k, ks.head, (uint32_t)ks.key, (int)H, (int)H_kv, (int)num, (int)S,   \
                        (float)scale, causal, bias, pitch, scores, tstats, tiles_m)
             if (dh == 64) FF_LQ_MFMA(4);
             else if (dh == 128) FF_LQ_MFMA(8);
@@ -572,7 +577,7 @@ static int launch_lq(const void* q, const void* k, int64_t H, int64_t H_kv, int6
     }
     const dim3 grid((unsigned)tiles, (unsigned)H_kv, (unsigned)((rows + kLqRows - 1) / kLqRows));
 #define FF_LQ_TILE(LPK)                                                                                                   \
-    hipLaunchKernelGGL((k_lq_tile<DT, LPK>), grid, dim3(256), 0, st, q, k, (int)H, (int)H_kv, (int)num, (int)S, (float)scale, \
+    hipLaunchKernelGGL((k_lq_tile<DT, LPK>), grid, dim3(256), 0, st, q, k, ks.head, (uint32_t)ks.key, (int)H, (int)H_kv, (int)num, (int)S, (float)scale, \
                        causal, bias, pitch, scores, tstats, tiles)
     switch ((int)lpk) {
         case 1: FF_LQ_TILE(1); break;
@@ -608,8 +613,8 @@ extern "C" size_t ff_last_query_workspace_bytes(int dtype, int64_t H, int64_t nu
 }
 
 extern "C" int ff_last_query_attention(const void* q_last, const void* k, int dtype, int64_t H, int64_t H_kv,
-                                       int64_t num, int64_t S, int64_t dh, double scale, int causal,
-                                       const void* bias, void* weights, void* importance, int64_t sel_lo, int64_t sel_hi, void* sel_ws,
+                                       int64_t num, int64_t S, int64_t dh, int64_t k_head_stride, int64_t k_key_stride,
+                                       double scale, int causal, const void* bias, void* weights, void* importance, int64_t sel_lo, int64_t sel_hi, void* sel_ws,
                                        size_t sel_ws_bytes, void* ws, size_t ws_bytes, ff_stream_t stream) {
     if (!q_last || !k || !ws || H < 1 || H_kv < 1 || num < 1 || S < 1 || dh < 1) return FF_ERR_ARG;
     if (H % H_kv) return FF_ERR_ARG;
@@ -628,10 +633,17 @@ extern "C" int ff_last_query_attention(const void* q_last, const void* k, int dt
         l0 = ff::ws_l0(sel_ws);
         t16_end = ff::ws_t16_end(sel_ws, sel_ws_bytes);
     }
+    // key layout: 0 / 0 = contiguous [H_kv, S, dh]; else element strides (e.g. dh and H_kv * dh for the [S, H_kv, dh]
+    // layout a k_proj output has before any copy)
+    if ((k_head_stride == 0) != (k_key_stride == 0) || k_head_stride < 0 || k_key_stride < 0) return FF_ERR_ARG;
+    ff::KStrides ks{(k_head_stride ? k_head_stride : S * dh) * esz, (k_key_stride ? k_key_stride : dh) * esz};
+    if ((ks.head & 15) || (ks.key & 15)) return FF_ERR_ALIGN;
+    if (ks.key < dh * esz) return FF_ERR_ARG;
+    if ((S - 1) * ks.key + dh * esz >= (1ll << 32)) return FF_ERR_UNSUPPORTED;     // one kv head must fit a buffer resource
     hipStream_t st = (hipStream_t)stream;
     switch (dtype) {
-        case FF_F32: return ff::launch_lq<FF_F32>(q_last, k, H, H_kv, num, S, dh, scale, causal, bias, weights, importance, ws, sel_lo, sel_hi, l0, t16_end, st);
-        case FF_BF16: return ff::launch_lq<FF_BF16>(q_last, k, H, H_kv, num, S, dh, scale, causal, bias, weights, importance, ws, sel_lo, sel_hi, l0, t16_end, st);
-        default: return ff::launch_lq<FF_F16>(q_last, k, H, H_kv, num, S, dh, scale, causal, bias, weights, importance, ws, sel_lo, sel_hi, l0, t16_end, st);
+        case FF_F32: return ff::launch_lq<FF_F32>(q_last, k, ks, H, H_kv, num, S, dh, scale, causal, bias, weights, importance, ws, sel_lo, sel_hi, l0, t16_end, st);
+        case FF_BF16: return ff::launch_lq<FF_BF16>(q_last, k, ks, H, H_kv, num, S, dh, scale, causal, bias, weights, importance, ws, sel_lo, sel_hi, l0, t16_end, st);
+        default: return ff::launch_lq<FF_F16>(q_last, k, ks, H, H_kv, num, S, dh, scale, causal, bias, weights, importance, ws, sel_lo, sel_hi, l0, t16_end, st);
     }
 }

@@ -138,12 +138,12 @@ class _Scratch:
         self._swaps = int(self.ctx.swaps)
 
     # ---- the call blocks ----
-    def put_aux(self, block, offset, pairs, L):
+    def put_aux(self, block, offset, pairs, L, room=_lib.MAX_AUX):
         """Describe (src, out) tensor pairs as ff_aux_t entries; returns their number."""
         n = 0
         pack = _lib.AUX_ENTRY.pack_into
         for s, o in pairs:
-            if n >= _lib.MAX_AUX:
+            if n >= room:
                 raise FrameFusionHipError("too many auxiliary tensors")
             if s.ndim == 2:         # [B, L] ids
                 row, outer = s.element_size(), s.shape[0]
@@ -327,23 +327,30 @@ class FrameFusion(nn.Module):
         (sources, outputs, rebuild(L_out) -> new container)."""
         if type(position_embeddings) == list:
             assert len(position_embeddings) == 2
-            srcs, outs = [], []
-            for t in position_embeddings:
-                shape = t.shape
-                if t.ndim not in (3, 4) or shape[-2] != L:
-                    raise FrameFusionHipError(f"position embedding of shape {tuple(shape)} does not have "
+            a, b = position_embeddings
+            shape = a.shape
+            for t in (a, b):
+                if t.ndim not in (3, 4) or t.shape[-2] != L:
+                    raise FrameFusionHipError(f"position embedding of shape {tuple(t.shape)} does not have "
                                               f"{L} tokens on its second-to-last axis")
-                if not t.is_contiguous():
-                    t = t.contiguous()
-                srcs.append(t)
-                outs.append(torch.empty(shape[:-2] + (L_cap, shape[-1]), dtype=t.dtype, device=t.device))
+            if not a.is_contiguous():
+                a = a.contiguous()
+            if not b.is_contiguous():
+                b = b.contiguous()
+            out_shape = shape[:-2] + (L_cap, shape[-1])
+            if b.shape == shape and b.dtype == a.dtype:
+                both = torch.empty((2,) + out_shape, dtype=a.dtype, device=a.device)     # cos and sin: one allocation
+                outs = [both[0], both[1]]
+            else:
+                outs = [torch.empty(out_shape, dtype=a.dtype, device=a.device),
+                        torch.empty(b.shape[:-2] + (L_cap, b.shape[-1]), dtype=b.dtype, device=b.device)]
+            ax = len(shape) - 2
 
             def rebuild(L_out):
-                ax = outs[0].ndim - 2
                 position_embeddings[0] = outs[0].narrow(ax, 0, L_out)
                 position_embeddings[1] = outs[1].narrow(ax, 0, L_out)
                 return position_embeddings
-            return srcs, outs, rebuild
+            return [a, b], outs, rebuild
         if type(position_embeddings) == torch.Tensor:
             if position_embeddings.ndim != 2:
                 raise NotImplementedError("Only support 2D position embeddings")
@@ -412,7 +419,8 @@ class FrameFusion(nn.Module):
         out = torch.empty((1, L_cap, d), dtype=dtype, device=device)
         ptype_out = torch.empty((1, L_cap), dtype=torch.int64, device=device)
         srcs, outs, rebuild = self._aux_for_positions(position_embeddings, L, L_cap)
-        n_aux = sc.put_aux(call, _lib.MERGE_CALL_AUX_OFFSET, zip([ptype.view(1, L)] + srcs, [ptype_out] + outs), L)
+        _lib.AUX_ENTRY.pack_into(call, _lib.MERGE_CALL_AUX_OFFSET, ptype.data_ptr(), ptype_out.data_ptr(), 8, 1)    # patch types
+        n_aux = 1 + sc.put_aux(call, _lib.MERGE_CALL_AUX_OFFSET + 32, zip(srcs, outs), L, room=_lib.MAX_AUX - 1)
         _PACK_PTR.pack_into(call, 16, out.data_ptr())
         _PACK_I64.pack_into(call, _lib.MERGE_CALL_AUX_OFFSET - 8, n_aux)
         mask_out = None

@@ -41,7 +41,16 @@ def _launch_last_query(query, key, num, is_causal, scale, want_weights, want_imp
     if code is None or key.dtype != query.dtype:
         raise FrameFusionHipError(f"unsupported dtypes {query.dtype} / {key.dtype}")
     q_last = query[0, :, -num:, :].contiguous()
-    k = key[0].contiguous()
+    # the keys as they are: [H_kv, S, dh] contiguous, or the transposed view of a k_proj output ([S, H_kv, dh] in
+    # memory: what transformers' attention hands over before the cache concatenates anything) - any layout with
+    # contiguous rows and 16-byte aligned strides is read in place, a copy of K is the exception
+    k = key[0]
+    esz = k.element_size()
+    sh, ss, sd = k.stride()
+    if (sd != 1 or (sh * esz) & 15 or (ss * esz) & 15 or ss < dh or k.data_ptr() & 15
+            or ((S - 1) * ss + dh) * esz >= (1 << 32) or (H_kv > 1 and sh < dh)):
+        k = k.contiguous()
+        sh, ss = S * dh, dh
     factor = 1 / math.sqrt(dh) if scale is None else scale
     dev = query.device
     weights = torch.empty(1, H, num, S, dtype=query.dtype, device=dev) if want_weights else None
@@ -49,7 +58,7 @@ def _launch_last_query(query, key, num, is_causal, scale, want_weights, want_imp
     ws_bytes = int(lib.ff_last_query_workspace_bytes(code, H, num, S, dh))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     sel_lo, sel_hi, sel_ws, sel_bytes = select if select is not None else (0, 0, None, 0)
-    rc = lib.ff_last_query_attention(q_last.data_ptr(), k.data_ptr(), code, H, H_kv, num, S, dh, float(factor),
+    rc = lib.ff_last_query_attention(q_last.data_ptr(), k.data_ptr(), code, H, H_kv, num, S, dh, sh, ss, float(factor),
                                      1 if is_causal else 0, bias.data_ptr() if bias is not None else None,
                                      weights.data_ptr() if want_weights else None,
                                      importance.data_ptr() if want_importance else None,

@@ -214,7 +214,10 @@ int ff_head_mean(const void* attn_w, int dtype, int64_t H, int64_t num, int64_t 
                  void* importance, ff_stream_t stream);
 
 /* Last-`num`-query attention probabilities with the reference's staged rounding:
- * p = T(softmax_fp32(T(T(q K^T) * scale) + bias)).  q_last [H, num, dh], k [H_kv, S, dh]
+ * p = T(softmax_fp32(T(T(q K^T) * scale) + bias)).  q_last [H, num, dh] contiguous; k: S keys of dh elements for
+ * each of H_kv heads, key (hk, s) at element offset hk * k_head_stride + s * k_key_stride (both 0: contiguous
+ * [H_kv, S, dh]; dh and H_kv * dh: the [S, H_kv, dh] layout a k_proj output has before transpose + copy; strides in
+ * elements, 16-byte aligned in bytes, one head's span below 4 GiB)
  * (GQA: head h reads kv head h / (H/H_kv), the repeat_kv of modeling_qwen2.py:147 folded in),
  * weights [H, num, S] (may be NULL), importance [S] (may be NULL) = head_mean(weights).
  * The bias of utils.py:32-44 is either the causal one (`causal` != 0: -inf above the diagonal of the last
@@ -229,7 +232,8 @@ int ff_head_mean(const void* attn_w, int dtype, int64_t H, int64_t num, int64_t 
  * Two launches when dh * sizeof(T) / 16 is a power of two (every real head size), else three. */
 size_t ff_last_query_workspace_bytes(int dtype, int64_t H, int64_t num, int64_t S, int64_t dh);
 int ff_last_query_attention(const void* q_last, const void* k, int dtype, int64_t H, int64_t H_kv,
-                            int64_t num, int64_t S, int64_t dh, double scale, int causal, const void* bias,
+                            int64_t num, int64_t S, int64_t dh, int64_t k_head_stride, int64_t k_key_stride,
+                            double scale, int causal, const void* bias,
                             void* weights, void* importance,
                             int64_t sel_lo, int64_t sel_hi, void* sel_ws, size_t sel_ws_bytes,
                             void* ws, size_t ws_bytes, ff_stream_t stream);

@@ -64,7 +64,7 @@ def test_argument_validation_without_gpu():
     assert lib.ff_plan_prune(16, 1, 10, 2, 5, 2, 16, 16, 16, 16, 16, 64, None) == -4       # workspace too small
     assert lib.ff_merge_compact(None, None, 1, 10, 64, 10, None, None, 1, None, None, None, 0, None) == -1
     assert lib.ff_head_mean(None, 1, 4, 1, 10, None, None) == -1
-    assert lib.ff_last_query_attention(16, 16, 1, 6, 4, 1, 10, 64, 0.1, 1, None, 16, None, 0, 0, None, 0, 16, 1 << 20, None) == -1  # H % H_kv
+    assert lib.ff_last_query_attention(16, 16, 1, 6, 4, 1, 10, 64, 0, 0, 0.1, 1, None, 16, None, 0, 0, None, 0, 16, 1 << 20, None) == -1  # H % H_kv
     # empty problems are a no-op
     assert lib.ff_build_order(16, 0, 4, 16, None, 16, 16, 1 << 24, None) == 0
     assert lib.ff_pair_similarity(16, 1, 0, 64, 16, 16, 16, 16, None) == 0

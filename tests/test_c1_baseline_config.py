@@ -4,6 +4,7 @@ reference's merge call.  tests/golden/c1.npz was produced by the REAL reference 
 give the same kept-token indices; activations and similarities are fp32 sums in another order, so they
 are compared at 1e-5 relative (north-star bar for hidden_states: 1e-3)."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -13,6 +14,7 @@ from framefusion_amd.synth import video_tokens
 from oracle import ff_oracle as orc
 from tests.conftest import Golden
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEV = "cuda:0"
 CASES = ["topk", "thr", "low"]
 
@@ -62,7 +64,17 @@ def test_hip_matches_the_reference_on_c1(name):
         # the ratio is a count over ftn: identical unless a similarity sits within an ulp of the threshold
         assert f.sparsity_list == pytest.approx(g[f"{name}/sparsity"].tolist(), abs=2.0 / (F * P))
     assert unique
-    assert np.setxor1d(kept, want).size <= 2          # an fp32 ulp at the cut may swap one pair; normally 0
+    swapped = int(np.setxor1d(kept, want).size)
+    # the observed count goes on record (pytest -rP / -s shows it; tests/conftest.py collects it into
+    # gpurun_out/c1_swaps.txt): a regression from 0 to the tolerated 2 must be visible, not silent
+    print(f"C1 {name}: kept indices that differ from the reference's: {swapped} (tolerated: 2, expected: 0)")
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "c1_swaps.txt"), "a") as fh:
+            fh.write(f"{name} {swapped}\n")
+    except OSError:
+        pass
+    assert swapped <= 2                               # an fp32 ulp at the cut may swap one pair; normally 0
     if np.array_equal(kept, want):
         rows = hg[0, torch.from_numpy(g[f"{name}/rows_idx"]).to(DEV)].cpu().numpy()
         np.testing.assert_allclose(rows, g[f"{name}/rows"], rtol=1e-5, atol=1e-6)

@@ -375,6 +375,32 @@ def test_importance_attn_mask_matrix_core_path(kind, dh, H, Hk, num, S):
         assert float((got.cpu().float() != want.float()).float().mean()) <= 2e-3, rep
 
 
+@pytest.mark.parametrize("dtype,dh,H,Hk,num,S", [(torch.bfloat16, 128, 28, 4, 1, 3001), (torch.float16, 64, 8, 2, 4, 777),
+                                               (torch.float32, 32, 4, 2, 1, 300), (torch.bfloat16, 24, 6, 2, 1, 200)])
+def test_importance_reads_transposed_keys_in_place(dtype, dh, H, Hk, num, S, monkeypatch):
+    """What an attention module hands over during prefill is the transposed VIEW of its k_proj output ([S, H_kv, dh] in
+    memory, strides (dh, H_kv * dh, 1)): every K5 kernel reads it through its strides - same numbers as from a contiguous
+    copy, and no copy of K is made on the way."""
+    g = torch.Generator().manual_seed(S)
+    q = harness.snap(0.5 * torch.randn(1, H, num, dh, generator=g), dtype)
+    k_mem = harness.snap(0.5 * torch.randn(1, S, Hk, dh, generator=g), dtype)           # [1, S, H_kv, dh] as projected
+    k_view = dev(k_mem).transpose(1, 2)                                                 # [1, H_kv, S, dh], not contiguous
+    assert not k_view.is_contiguous()
+    want = ffa.scaled_dot_product_attention(dev(q), k_view.contiguous(), None, num=num, is_causal=True, enable_gqa=True)
+    copies = []
+    real = torch.Tensor.contiguous
+    monkeypatch.setattr(torch.Tensor, "contiguous", lambda t, *a, **kw: (copies.append(tuple(t.shape)) if not t.is_contiguous() else None, real(t, *a, **kw))[1])
+    got = ffa.scaled_dot_product_attention(dev(q), k_view, None, num=num, is_causal=True, enable_gqa=True)
+    imp = ffa.last_query_importance(dev(q), k_view, num=num, is_causal=True)
+    monkeypatch.undo()
+    assert all(len(shape) != 3 or shape[1] != S for shape in copies), copies                # K itself was never copied
+    assert same_bits(got.cpu(), want.cpu())
+    ref = orc.last_query_attention(q, k_mem.transpose(1, 2), num=num, is_causal=True, enable_gqa=True)
+    tol = {torch.bfloat16: 2 ** -7, torch.float16: 2 ** -10, torch.float32: 2e-6}[dtype]
+    assert torch.allclose(got.cpu().float(), ref.float(), rtol=tol, atol=1e-30)
+    assert torch.allclose(imp.reshape(-1).cpu().float(), torch.mean(ref, dim=(1, 2))[0].float(), rtol=tol, atol=1e-30)
+
+
 def test_importance_odd_head_size_general_path():
     """dh * sizeof(T) / 16 not a power of two (dh = 24 bf16 -> 3 lanes per key): the general kernels"""
     g = torch.Generator().manual_seed(5)
