@@ -170,7 +170,11 @@ def build(verbose: bool = False, force: bool = False) -> str:
     if not os.path.isdir(CSRC):
         raise FrameFusionHipError(f"{CSRC} not found")
     cmd = ["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 1))] + (["-B"] if force else [])
-    res = subprocess.run(cmd, capture_output=True, text=True)
+    # one build at a time: several ranks of one job may find the same stale binary at the same moment
+    import fcntl
+    with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        res = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or res.returncode:
         print(res.stdout[-4000:])
         print(res.stderr[-4000:])
@@ -179,20 +183,15 @@ def build(verbose: bool = False, force: bool = False) -> str:
     return LIB_PATH
 
 
-def _open_checked():
-    """CDLL of the in-tree library, after checking that it was built from the sources that sit next to it."""
-    lib = C.CDLL(LIB_PATH)
-    want = source_hash()
-    if want is not None:
-        try:
-            fn = lib.ff_source_hash
-            fn.restype = C.c_char_p
-            got = fn().decode()
-        except AttributeError:
-            got = "(a library from before the stamp)"
-        if got != want:
-            return None, got, want
-    return lib, None, want
+def file_stamp(path: str = None):
+    """The source hash baked into the library FILE (the bytes after the "FFSRCHASH:" marker), read without loading it."""
+    try:
+        with open(path or LIB_PATH, "rb") as f:
+            blob = f.read()
+    except OSError:
+        return None
+    at = blob.find(b"FFSRCHASH:")
+    return blob[at + 10:at + 26].decode("ascii", "replace") if at >= 0 else "(a library from before the stamp)"
 
 
 def load():
@@ -207,15 +206,18 @@ def load():
             raise FrameFusionHipError(
                 f"{LIB_PATH} is missing and could not be built ({e}): run `python -c 'import __graft_entry__ as g; "
                 f"g.build()'` (or `make -C {CSRC}`). framefusion_amd has no CPU/eager fallback.") from e
+    # a stale binary (sources edited since it was built, or a copy whose timestamps hide that from make) is rebuilt,
+    # never run: the stamp is read from the file BEFORE anything is loaded
+    want = source_hash()
+    if want is not None and file_stamp() != want:
+        build()
+        if file_stamp() != want:
+            build(force=True)
+        if file_stamp() != want:
+            raise FrameFusionHipError(f"{LIB_PATH} was built from other sources (its stamp {file_stamp()}, the sources' "
+                                      f"{want}) and rebuilding did not change that")
     try:
-        lib, got, want = _open_checked()
-        if lib is None:
-            # a stale binary (sources edited since it was built): rebuild once, never run it
-            build()
-            lib, got, want = _open_checked()
-            if lib is None:
-                raise FrameFusionHipError(f"{LIB_PATH} was built from other sources (its stamp {got}, the sources' {want}) "
-                                          f"and rebuilding did not change that")
+        lib = C.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover
         raise FrameFusionHipError(f"cannot load {LIB_PATH}: {e}") from e
     for name, (res, args) in PROTOTYPES.items():

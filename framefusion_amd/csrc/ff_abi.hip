@@ -32,7 +32,10 @@ int launch_head_mean(const void* attn_w, int dtype, int64_t H, int64_t num, int6
 }  // namespace ff
 
 extern "C" int ff_abi_version(void) { return FF_ABI_VERSION; }
-extern "C" const char* ff_source_hash(void) { return FF_SOURCE_HASH; }
+// (the marker lets a host read the stamp from the FILE, without loading it: a process that has already dlopen()ed a stale
+// copy gets the same handle back for the same path, however often the file is rebuilt)
+static const char kSourceStamp[] = "FFSRCHASH:" FF_SOURCE_HASH;
+extern "C" const char* ff_source_hash(void) { return kSourceStamp + 10; }
 
 extern "C" const char* ff_error_string(int code) {
     switch (code) {

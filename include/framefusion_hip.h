@@ -428,7 +428,11 @@ typedef struct ff_merge_result {
  * every ~50 us and a failed or drained stream ends the wait with FF_ERR_DEVICE / the hipError_t.
  * A FF_ERR_BIT_LAYOUT result is handled inside finish: workspace reset, the whole call repeated
  * with hint_frames = 0, result->unhinted = 1.
- * ff_ctx_merge = begin + finish (outputs allocated up front). */
+ * ff_ctx_merge = begin + finish (outputs allocated up front).
+ * Because finish waits on host memory it cannot be captured into a hipGraph (neither can anything that must learn
+ * L_out before it continues); the capturable form of the same three launches is ff_merge_step / ff_merge_begin +
+ * ff_merge_finish with stats_host_mapped = NULL (profiles/r02_hipgraph.txt: a replay costs more than the direct
+ * launches). */
 int ff_ctx_merge_begin(ff_ctx_t* ctx, const ff_merge_call_t* call);
 int ff_ctx_merge_finish(ff_ctx_t* ctx, const ff_merge_call_t* call, ff_merge_result_t* result);
 int ff_ctx_merge(ff_ctx_t* ctx, const ff_merge_call_t* call, ff_merge_result_t* result);

@@ -113,3 +113,35 @@ def test_two_threads_two_instances():
     assert not errors, errors
     for got, want in zip(results, wants):
         check(got, want)
+
+
+def test_two_gpus_in_one_process_from_two_threads():
+    """The reference's demo layout (llava_video_compare.py:217-223, 310-313): two replicas on two GPUs, one thread each,
+    one process.  The library's host-side per-device caches (function attributes for dynamic LDS, the merge kernel's
+    occupancy) are keyed by device and the poll runs with the interpreter lock released, so the two prefills neither
+    share state nor serialise.  Needs two devices (skipped on the 1-GPU boxes of this pool)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    import threading
+    results, errors = {}, []
+
+    def work(dev_index, seed, p_change):
+        try:
+            dev = f"cuda:{dev_index}"
+            h, pt, P, pre, nvis = sample(seed, p_change)
+            pe = [t.to(dev) for t in rotary_tables(h.shape[1], 16, torch.bfloat16)]
+            with torch.cuda.device(dev):
+                got, _ = harness.run_cascade(ffa.FrameFusion(0.3, 0.6, 0.1), h.to(dev), pt.to(dev), P, pe, None, 3, 4, 1,
+                                             start=pre, n_visual=nvis)
+                torch.cuda.synchronize()
+            results[dev_index] = (got, oracle_cascade(h, pt, P, pre, nvis))
+        except Exception as e:                                    # pragma: no cover
+            errors.append((dev_index, repr(e)))
+    threads = [threading.Thread(target=work, args=(i, 40 + i, 0.3 + 0.3 * i)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(2):
+        check(*results[i])
