@@ -172,8 +172,10 @@ extern "C" int ff_prune_step(const void* hidden, const void* addend, void* hidde
     hipStream_t st = (hipStream_t)stream;
     const void* imp = attn_w;
     bool have_tables = tables_ready != 0;          // a [S] importance whose producer already filled the tables
-    if (H * num != 1) {
-        // head mean (main.py:69-70) + the select tables of its output in the same launch
+    if (H * num != 1 || !have_tables) {
+        // head mean (main.py:69-70) + the select tables of its output in the same launch.  A ready-made [S] importance
+        // without tables takes the same kernel (the mean of one row is the row): one launch instead of the stand-alone
+        // plan's memsets + table kernel (84.5 -> 59.2 us per prune call at the C3 shape, r03_k5_experiments.txt)
         int rc = ff::launch_head_mean(attn_w, w_dtype, H, num, S, importance, start, start + n_img, ff::ws_l0(ws),
                                       ff::ws_t16_end(ws, ws_bytes), st);
         if (rc) return rc;
