@@ -310,6 +310,9 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
 // kept position) into src[] (position of every output row) once, then one workgroup per OUTPUT row walks the output
 // columns - src[] read as whole words, the mask row gathered through it (ascending, mostly neighbouring elements),
 // 16-byte stores.  What is left is the mask itself: L_out^2 elements written, the kept part of L_out rows read.
+// (A variant that reads the input rows as whole aligned 16-byte chunks and stages the survivors of a 4 KiB segment in LDS
+// before aligned stores was built and measured: 243 / 1153 us against 171 / 847 us for this one at 12.5 k / 36.9 k tokens -
+// three barriers and two LDS atomics per 4 KiB cost more than the 2-byte gathers; profiles/r03_mask_gather.txt.)
 __global__ __launch_bounds__(256) void k_invert_dst(const int32_t* __restrict__ dst, int L, int32_t* __restrict__ src) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < L) {

@@ -365,6 +365,8 @@ class FrameFusion(nn.Module):
         if m.ndim != 4 or m.shape[0] != 1 or m.shape[1] != 1 or m.shape[2] != L or m.shape[3] != L:
             raise FrameFusionHipError(f"attention mask of shape {tuple(m.shape)} is not [1, 1, {L}, {L}]")
         m = m.contiguous()
+        if m.data_ptr() & 15:
+            m = m.clone()
         return m, torch.empty(1, 1, L_cap, L_cap, dtype=m.dtype, device=m.device)
 
     # ---- merge call: main.py:104-138 -------------------------------------------------------------
