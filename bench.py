@@ -185,7 +185,10 @@ def main():
                 flip[0] ^= 1
                 ff.prepare(ptype, P, start_dev, end_dev, L, L)
                 return ff(hidden_alt if flip[0] else hidden, [cos, sin], None)[0]
-            result["extra"] = {"packer_scalars_step_us": step_spread(step_packer, 40), "configs": extra_configs(dev)}
+            result["extra"] = {"packer_scalars_step_us": step_spread(step_packer, 40),
+                               "two_samples_per_gpu": two_samples_per_gpu(ffa, dev, F, P, d, args.p_change, args.seed,
+                                                                          max(20, min(args.steps, 100)), 10),
+                               "configs": extra_configs(dev)}
             assert ff.last_call["L_out"] == L_out
         if not args.no_cpu_baseline and world == 1:         # reported at N = 1 only (other ranks would wait)
             result["cpu_baseline"], result["eager_gpu_baseline"] = baselines(hidden, ptype, cos, sin, P, L, L_out,
@@ -320,6 +323,50 @@ def profiled_traffic(kernel):
             return None, source
         total += scale * val * 1024.0
     return total, source
+
+
+def two_samples_per_gpu(ffa, dev, F, P, d, p_change, seed, steps, warmup):
+    """Two independent samples on ONE GPU at the same time: two threads, each with its own FrameFusion instance, stream and
+    sample (the deployment the reference's demo uses for its replicas, llava_video_compare.py:217-223) - the result-block
+    poll runs in C with the interpreter lock released, so one sample's similarity / merge pass fills the other's plan-kernel
+    bubble and kernel ramps.  Whole-GPU throughput of `steps` steps per thread; NOT the headline (one sample per GPU)."""
+    import threading
+    from framefusion_amd.synth import video_tokens, rotary_tables
+    work = []
+    for t in range(2):
+        h, pt = video_tokens(F, P, d, p_change=p_change, sigma=SIGMA, seed=seed + 100 + t, dtype=torch.bfloat16, device=str(dev))
+        L = h.shape[1]
+        cos, sin = rotary_tables(L, HEAD_DIM, torch.bfloat16, device=str(dev))
+        work.append(dict(h=h, h2=h.clone(), pt=pt, cos=cos, sin=sin, L=L, ff=ffa.FrameFusion(COST, THRESHOLD, RATIO_LB),
+                         stream=torch.cuda.Stream(device=dev), out=None))
+    start, stop = threading.Barrier(3), threading.Barrier(3)
+
+    def run(w):
+        torch.cuda.set_device(dev)
+        with torch.cuda.stream(w["stream"]):
+            def step(i):
+                w["ff"].prepare(w["pt"], P, 0, w["L"], w["L"], w["L"])
+                return w["ff"](w["h2"] if i & 1 else w["h"], [w["cos"], w["sin"]], None)[0]
+            for i in range(warmup):
+                step(i)
+            w["stream"].synchronize()
+            start.wait()
+            for i in range(steps):
+                w["out"] = step(i)
+            w["stream"].synchronize()
+            stop.wait()
+    threads = [threading.Thread(target=run, args=(w,)) for w in work]
+    for th in threads:
+        th.start()
+    start.wait()
+    t0 = time.perf_counter()
+    stop.wait()
+    dt = time.perf_counter() - t0
+    for th in threads:
+        th.join()
+    reduced = sum(w["L"] - w["out"].shape[1] for w in work)
+    return {"samples_in_flight": 2, "steps_per_sample": steps, "us_per_pair_of_steps": dt / steps * 1e6,
+            "tokens_reduced_per_s": reduced * steps / dt}
 
 
 def cascade(ffa, dev, F, P, d, p_change, thr, pre, post, heads, kv_heads, num, mrope, sigma_hi=1.6, reps=6, seed=1234):
