@@ -75,6 +75,16 @@ def test_single_gpu_line_has_the_contract_fields():
     assert out["n_gpus"] == 1 and out["dtype"] == "bf16" and out["vs_baseline"] is None
     rf = out["roofline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0.3 < rf["frac"] < 1.0 and rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"])
+    # the traffic figure names where it comes from, and is withheld when the PMC passes are of another build
+    ts = rf["traffic_source"]
+    assert ts is not None and ("stale" in ts or "error" in ts or ts["profiled_source_hash"] == ts["running_source_hash"])
+    assert (rf["traffic"] is None) == ("stale" in ts or "error" in ts)
+    if rf["traffic"] is not None:
+        assert 0.8 < rf["traffic"] / rf["algorithmic_bytes"] < 1.3
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
     assert "workload" in out["config"] and "model" not in out["config"]
+    ex = out["extra"]
+    assert ex["two_samples_per_gpu"]["tokens_reduced_per_s"] > 0 and ex["packer_scalars_step_us"]["median"] > 0
+    seven_b = [c for c in ex["configs"] if "7B" in c["workload"]][0]
+    assert 0 < seven_b["us_back_to_back"] <= seven_b["us"] * 1.2
