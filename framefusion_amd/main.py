@@ -39,10 +39,6 @@ def _round_to(value: float, dtype: torch.dtype) -> float:
     return float(torch.tensor(value, dtype=dtype))
 
 
-def _to_int(x) -> int:
-    return int(x.item()) if isinstance(x, torch.Tensor) else int(x)
-
-
 _get_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
 _PACK_PTR = struct.Struct("=Q")
 _PACK_I64 = struct.Struct("=q")
