@@ -86,5 +86,5 @@ def test_single_gpu_line_has_the_contract_fields():
     assert "workload" in out["config"] and "model" not in out["config"]
     ex = out["extra"]
     assert ex["two_samples_per_gpu"]["tokens_reduced_per_s"] > 0 and ex["packer_scalars_step_us"]["median"] > 0
-    seven_b = [c for c in ex["configs"] if "7B" in c["workload"]][0]
+    seven_b = [c for c in ex["configs"] if "LLaVA-Video-7B" in c["workload"]][0]
     assert 0 < seven_b["us_back_to_back"] <= seven_b["us"] * 1.2
