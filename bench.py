@@ -60,6 +60,9 @@ def parse():
                          "run through the backend (RCCL) on a 1-GPU box")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip cpu_baseline and eager_gpu_baseline")
     ap.add_argument("--no-extra", action="store_true", help="skip extra.configs (C3 / C5 / 7B shape)")
+    ap.add_argument("--e2e", action="store_true",
+                    help="also run BASELINE.json configs[1] end to end: a random-weight Qwen2 LLM of LLaVA-Video-7B-Qwen2's shape, "
+                         "64 frames x 210 tokens prefilled dense / with this build / with the torch port of the reference (adds ~1 min)")
     ap.add_argument("--cpu-calls", type=int, default=12,
                     help="merge calls of the CPU oracle timed for cpu_baseline (~0.9 s each on the GPU box's host: ~11 s)")
     return ap.parse_args()
@@ -190,6 +193,8 @@ def main():
             result["extra"]["two_samples_per_gpu"] = two_samples_per_gpu(ffa, dev, F, P, d, args.p_change, args.seed,
                                                                          max(20, min(args.steps, 100)), 10)
             assert ff.last_call["L_out"] == L_out
+        if args.e2e and world == 1:
+            result.setdefault("extra", {})["e2e_prefill_7b"] = e2e_prefill(dev)
         if not args.no_cpu_baseline and world == 1:         # reported at N = 1 only (other ranks would wait)
             result["cpu_baseline"], result["eager_gpu_baseline"] = baselines(hidden, ptype, cos, sin, P, L, L_out,
                                                                               args.cpu_calls, ms_per_step)
@@ -456,6 +461,144 @@ def extra_configs(dev):
     r = cascade(ffa, dev, 64, 210, 3584, 0.2, THRESHOLD, 14, 20, 28, 4, 1, False, sigma_hi=None)
     out.append({"workload": "LLaVA-Video-7B real shape [1, 14+64x210+20, 3584] bf16, one merge call (top-k)", **r})
     return out
+
+
+class _EagerFrameFusion(torch.nn.Module):
+    """The torch port of the reference's FrameFusion (oracle/ff_oracle.py, here on GPU tensors) behind the attribute surface
+    the adapters use - the "reference eager" leg of e2e_prefill (baseline code: never part of the product path)."""
+    supports_residual = False
+
+    def __init__(self, oracle):
+        super().__init__()
+        self.__dict__["o"] = oracle
+        self.time_s = 0.0
+
+    def __getattr__(self, name):
+        return getattr(self.__dict__["o"], name)
+
+    def prepare(self, *a, **kw):
+        return self.o.prepare(*a, **kw)
+
+    def _expect_importance(self, *a, **kw):
+        return None, None
+
+    def forward(self, hidden_states, position_embeddings, attention_mask, self_attn_weights=None):
+        active = hidden_states.shape[1] > 1 and not (self.o.finish_merging and self.o.finish_pruning)
+        if active:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        out = self.o.forward(hidden_states, position_embeddings, attention_mask, self_attn_weights)
+        if active:
+            torch.cuda.synchronize()
+            self.time_s += time.perf_counter() - t0
+        return out
+
+
+def e2e_prefill(dev, frames=64, patches=210, pre=14, post=20, reps=3, regimes=((P_CHANGE, None), (0.5, 1.6))):
+    """BASELINE.json configs[1] end to end ("LLaVA-Video-7B-Qwen2, 64 frames, cost=0.3, 1xMI355X bf16 - HIP sim+merge vs
+    reference eager"): a random-weight Qwen2 decoder stack of that model's LLM shape (d = 3584, 28 layers, 28 / 4 heads,
+    MLP 18944; no checkpoint exists offline) prefills 14 + 64 x 210 + 20 synthetic tokens (a) dense, (b) patched with
+    apply_framefusion of THIS build, (c) with the same adapter driving the torch port of the reference's FrameFusion on the
+    GPU.  Wall time of the LLM prefill (synchronised), per-layer sequence lengths, and the time spent inside
+    FrameFusion.forward."""
+    from transformers import Qwen2Config, Qwen2ForCausalLM
+    from transformers.cache_utils import DynamicCache
+    import framefusion_amd as ffa
+    from framefusion_amd.models.qwen2 import register_hf_qwen2
+    from framefusion_amd.synth import video_tokens
+    from oracle import ff_oracle as orc
+    d = 3584
+    cfg = Qwen2Config(vocab_size=1024, hidden_size=d, intermediate_size=18944, num_hidden_layers=28, num_attention_heads=28,
+                      num_key_value_heads=4, max_position_embeddings=32768, rope_theta=1000000.0)
+    cfg._attn_implementation = "sdpa"
+    torch.manual_seed(0)
+    with torch.device(dev):
+        model = Qwen2ForCausalLM(cfg).to(torch.bfloat16).eval()
+    n_vis = frames * patches
+    L = pre + n_vis + post
+    state = {}
+
+    def prefill(prepare):
+        times, lengths = [], None
+        for _ in range(reps + 1):
+            if prepare is not None:
+                prepare()
+            cache = DynamicCache(config=cfg)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                out = model.model(inputs_embeds=state["emb"], past_key_values=cache, use_cache=True)
+            torch.cuda.synchronize()
+            times.append((time.perf_counter() - t0) * 1e3)
+            lengths = getattr(model.model, "framefusion_lengths", None) or [out.last_hidden_state.shape[1]] * cfg.num_hidden_layers
+            del cache, out
+        return statistics.median(times[1:]), lengths
+
+    def runs(lengths):                 # [a, a, a, b, b] -> "3 x a, 2 x b"
+        out, i = [], 0
+        while i < len(lengths):
+            j = i
+            while j < len(lengths) and lengths[j] == lengths[i]:
+                j += 1
+            out.append(f"{j - i} x {lengths[i]}")
+            i = j
+        return ", ".join(out)
+
+    state["emb"], _ = video_tokens(frames, patches, d, p_change=P_CHANGE, sigma=SIGMA, seed=1234, pre=pre, post=post,
+                                   dtype=torch.bfloat16, device=str(dev))
+    dense_ms, _ = prefill(None)
+    register_hf_qwen2()
+    ffa.apply_framefusion(model, cost=COST, similarity_lower_bound=THRESHOLD, ratio_lower_bound=RATIO_LB)
+    hip_ff = model.framefusion
+    eager = _EagerFrameFusion(orc.OracleFrameFusion(COST, THRESHOLD, RATIO_LB))
+
+    def install(obj):
+        model.framefusion = obj
+        model.model.framefusion = obj
+        for layer in model.model.layers:
+            layer.framefusion = obj
+            layer.self_attn.framefusion = obj
+    results = []
+    for p_change, sigma_hi in regimes:
+        emb, pt = video_tokens(frames, patches, d, p_change=p_change, sigma=SIGMA, sigma_hi=sigma_hi, seed=1234, pre=pre, post=post,
+                               dtype=torch.bfloat16, device=str(dev))
+        state["emb"] = emb
+        install(hip_ff)
+        hip_ms, hip_lengths = prefill(lambda: hip_ff.prepare(pt, patches, pre, pre + n_vis - 1, n_vis, L))
+        # wall time of the FrameFusion.forward calls of this build (each bracketed by synchronise: launch-from-idle and drain
+        # included - an upper bound of what they add to the prefill)
+        calls = []
+        inner = hip_ff.forward
+
+        def timed(*a, **kw):
+            active = a[0].shape[1] > 1 and not (hip_ff.finish_merging and hip_ff.finish_pruning)
+            if active:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            r = inner(*a, **kw)
+            if active:
+                torch.cuda.synchronize()
+                calls.append((time.perf_counter() - t0) * 1e3)
+            return r
+        hip_ff.forward = timed
+        prefill(lambda: (calls.clear(), hip_ff.prepare(pt, patches, pre, pre + n_vis - 1, n_vis, L)))
+        hip_ff_ms, hip_ff_calls = sum(calls), len(calls)
+        del hip_ff.forward                      # back to the class's forward
+        install(eager)
+
+        def prep_eager():
+            eager.time_s = 0.0
+            eager.prepare(pt, patches, pre, pre + n_vis - 1, n_vis, L)
+        eager_ms, eager_lengths = prefill(prep_eager)
+        results.append({"p_change": p_change, "hip_prefill_ms": hip_ms, "eager_reference_prefill_ms": eager_ms,
+                        "prefill_speedup_vs_dense": dense_ms / hip_ms, "prefill_speedup_vs_eager_reference": eager_ms / hip_ms,
+                        "framefusion_calls": hip_ff_calls, "hip_ms_inside_framefusion": hip_ff_ms,
+                        "eager_ms_inside_framefusion": eager.time_s * 1e3,
+                        "mean_kept_fraction_over_layers": sum(hip_lengths) / (len(hip_lengths) * L),
+                        "lengths_hip": runs(hip_lengths), "lengths_eager": runs(eager_lengths)})
+    return {"workload": f"Qwen2 LLM of LLaVA-Video-7B-Qwen2's shape (d={d}, 28 layers, 28/4 heads, MLP 18944, random weights), prefill "
+                        f"of {pre}+{frames}x{patches}+{post} = {L} synthetic tokens, cost={COST}, thr={THRESHOLD}",
+            "dense_prefill_ms": dense_ms, "regimes": results}
 
 
 def baselines(hidden, ptype, cos, sin, P, L, L_out, calls, hip_ms):
