@@ -60,9 +60,10 @@ def parse():
                          "run through the backend (RCCL) on a 1-GPU box")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip cpu_baseline and eager_gpu_baseline")
     ap.add_argument("--no-extra", action="store_true", help="skip extra.configs (C3 / C5 / 7B shape)")
-    ap.add_argument("--e2e", action="store_true",
-                    help="also run BASELINE.json configs[1] end to end: a random-weight Qwen2 LLM of LLaVA-Video-7B-Qwen2's shape, "
-                         "64 frames x 210 tokens prefilled dense / with this build / with the torch port of the reference (adds ~1 min)")
+    ap.add_argument("--e2e", nargs="?", const="7b", default=None, choices=sorted(E2E_SHAPES) + ["all"],
+                    help="also run BASELINE.json configs[1] (7b) / configs[4] (72b) end to end: a random-weight Qwen2 LLM of that "
+                         "LLaVA-Video model's shape, 64 frames prefilled dense / with this build / with the torch port of the reference "
+                         "(7b adds ~1 min, 72b ~3 min and 150 GB of HBM)")
     ap.add_argument("--cpu-calls", type=int, default=12,
                     help="merge calls of the CPU oracle timed for cpu_baseline (~0.9 s each on the GPU box's host: ~11 s)")
     return ap.parse_args()
@@ -194,7 +195,8 @@ def main():
                                                                          max(20, min(args.steps, 100)), 10)
             assert ff.last_call["L_out"] == L_out
         if args.e2e and world == 1:
-            result.setdefault("extra", {})["e2e_prefill_7b"] = e2e_prefill(dev)
+            for shape in (sorted(E2E_SHAPES) if args.e2e == "all" else [args.e2e]):
+                result.setdefault("extra", {})[f"e2e_prefill_{shape}"] = e2e_prefill(dev, shape)
         if not args.no_cpu_baseline and world == 1:         # reported at N = 1 only (other ranks would wait)
             result["cpu_baseline"], result["eager_gpu_baseline"] = baselines(hidden, ptype, cos, sin, P, L, L_out,
                                                                               args.cpu_calls, ms_per_step)
@@ -494,7 +496,13 @@ class _EagerFrameFusion(torch.nn.Module):
         return out
 
 
-def e2e_prefill(dev, frames=64, patches=210, pre=14, post=20, reps=3, regimes=((P_CHANGE, None), (0.5, 1.6))):
+E2E_SHAPES = {   # name: (d, layers, heads, kv heads, MLP, patches per frame, reps)
+    "7b": (3584, 28, 28, 4, 18944, 210, 3),          # LLaVA-Video-7B-Qwen2 (BASELINE configs[1]); 14 x 15 tokens per frame
+    "72b": (8192, 80, 64, 8, 29568, 576, 1),         # LLaVA-Video-72B's LLM (configs[4]): 145 GB of bf16 weights on ONE MI355X
+}
+
+
+def e2e_prefill(dev, shape="7b", frames=64, pre=14, post=20, regimes=((P_CHANGE, None), (0.5, 1.6))):
     """BASELINE.json configs[1] end to end ("LLaVA-Video-7B-Qwen2, 64 frames, cost=0.3, 1xMI355X bf16 - HIP sim+merge vs
     reference eager"): a random-weight Qwen2 decoder stack of that model's LLM shape (d = 3584, 28 layers, 28 / 4 heads,
     MLP 18944; no checkpoint exists offline) prefills 14 + 64 x 210 + 20 synthetic tokens (a) dense, (b) patched with
@@ -507,13 +515,18 @@ def e2e_prefill(dev, frames=64, patches=210, pre=14, post=20, reps=3, regimes=((
     from framefusion_amd.models.qwen2 import register_hf_qwen2
     from framefusion_amd.synth import video_tokens
     from oracle import ff_oracle as orc
-    d = 3584
-    cfg = Qwen2Config(vocab_size=1024, hidden_size=d, intermediate_size=18944, num_hidden_layers=28, num_attention_heads=28,
-                      num_key_value_heads=4, max_position_embeddings=32768, rope_theta=1000000.0)
+    d, n_layers, n_heads, n_kv, mlp, patches, reps = E2E_SHAPES[shape]
+    cfg = Qwen2Config(vocab_size=1024, hidden_size=d, intermediate_size=mlp, num_hidden_layers=n_layers, num_attention_heads=n_heads,
+                      num_key_value_heads=n_kv, max_position_embeddings=65536, rope_theta=1000000.0)
     cfg._attn_implementation = "sdpa"
     torch.manual_seed(0)
-    with torch.device(dev):
-        model = Qwen2ForCausalLM(cfg).to(torch.bfloat16).eval()
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)          # (the 72B stack is 145 GB in bf16: it must never exist in fp32)
+    try:
+        with torch.device(dev):
+            model = Qwen2ForCausalLM(cfg).eval()
+    finally:
+        torch.set_default_dtype(prev)
     n_vis = frames * patches
     L = pre + n_vis + post
     state = {}
@@ -596,8 +609,10 @@ def e2e_prefill(dev, frames=64, patches=210, pre=14, post=20, reps=3, regimes=((
                         "eager_ms_inside_framefusion": eager.time_s * 1e3,
                         "mean_kept_fraction_over_layers": sum(hip_lengths) / (len(hip_lengths) * L),
                         "lengths_hip": runs(hip_lengths), "lengths_eager": runs(eager_lengths)})
-    return {"workload": f"Qwen2 LLM of LLaVA-Video-7B-Qwen2's shape (d={d}, 28 layers, 28/4 heads, MLP 18944, random weights), prefill "
-                        f"of {pre}+{frames}x{patches}+{post} = {L} synthetic tokens, cost={COST}, thr={THRESHOLD}",
+    del model
+    torch.cuda.empty_cache()
+    return {"workload": f"Qwen2 LLM of LLaVA-Video-{shape.upper()}'s shape (d={d}, {n_layers} layers, {n_heads}/{n_kv} heads, MLP {mlp}, random "
+                        f"weights), prefill of {pre}+{frames}x{patches}+{post} = {L} synthetic tokens, cost={COST}, thr={THRESHOLD}",
             "dense_prefill_ms": dense_ms, "regimes": results}
 
 
