@@ -24,6 +24,24 @@ def test_header_and_binding_agree():
     assert sorted(_lib.PROTOTYPES) == names
 
 
+def test_header_is_plain_c(tmp_path):
+    """include/framefusion_hip.h is the boundary a C host binds: it must compile as C99 (no C++ in the signatures), and its
+    structure sizes there are the ones the library and the ctypes mirrors agree on."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "t.c"
+    src.write_text('#include <stdio.h>\n#include "framefusion_hip.h"\nint main(void) { printf("%zu %zu %zu %zu %zu\\n", sizeof(ff_ctx_t), '
+                   'sizeof(ff_merge_call_t), sizeof(ff_merge_result_t), sizeof(ff_prune_call_t), sizeof(ff_aux_t)); return 0; }\n')
+    exe = tmp_path / "t"
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.dirname(HEADER), str(src), "-o", str(exe)],
+                   check=True, capture_output=True)
+    sizes = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert sizes == [C.sizeof(c) for c in (_lib.FFCtx, _lib.FFMergeCall, _lib.FFMergeResult, _lib.FFPruneCall, _lib.FFAux)]
+
+
 def test_library_exports_every_declared_symbol():
     assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
     lib = C.CDLL(_lib.LIB_PATH)
