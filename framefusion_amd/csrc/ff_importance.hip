@@ -213,6 +213,44 @@ __global__ __launch_bounds__(256) void k_lq_mean(const float* __restrict__ probs
 // k_lq_finish: one thread per key: p = T(exp(x - M) / Sum) with the row's global (M, Sum) folded from the
 // tile statistics, fp32 head/query mean -> importance, optional [H, num, S] weights, and the select
 // tables of the prune's plan kernel on the way.
+// (max, sum of exp) of one row from its tile statistics, folded by ONE wave (every lane gets the result): 8 tiles in
+// flight per lane, running max with the sum rescaled to it, then a butterfly over the 64 lanes.  The order of the
+// additions is fixed by (tiles) alone, so every workgroup that folds a row - its owner or, after a timeout, anybody -
+// gets the same bits.
+__device__ inline float2 fold_row_wave(const float2* __restrict__ ts, int tiles) {
+    const int lane = lane_id();
+    float M = -INFINITY, sum = 0.f;
+    for (int t0 = lane; t0 < tiles; t0 += 8 * kWave) {
+        float2 ms[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ms[u] = t0 + u * kWave < tiles ? ts[t0 + u * kWave] : make_float2(-INFINITY, 0.f);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (ms[u].y > 0.f) {
+                const float Mn = fmaxf(M, ms[u].x);
+                sum = sum * expf(M - Mn) + ms[u].y * expf(ms[u].x - Mn);      // (exp(-inf) = 0 on the first)
+                M = Mn;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float Mo = __shfl_xor(M, o, kWave), so = __shfl_xor(sum, o, kWave);
+        const float Mn = fmaxf(M, Mo);
+        sum = (M > -INFINITY ? sum * expf(M - Mn) : 0.f) + (Mo > -INFINITY ? so * expf(Mo - Mn) : 0.f);
+        M = Mn;
+    }
+    return make_float2(M, sum);
+}
+
+// Tag of a published granule.  The score kernel that precedes every finish launch on the stream clears the exchange
+// area (lq_clear_exchange), so a granule carrying kLqTag was written by THIS launch.
+constexpr uint32_t kLqTag = 0x5eed0001u;
+__device__ inline void lq_clear_exchange(unsigned long long* xch, int rows_total) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+        for (int x = threadIdx.x; x < 2 * rows_total; x += blockDim.x) xch[x] = 0ull;
+}
+
 constexpr int kLqKeys = 256;
 constexpr int kLqRows = 16;
 
@@ -259,9 +297,11 @@ __device__ inline float group_sum(float v) {
 template <int DT, int LPK>
 __global__ __launch_bounds__(256) void k_lq_tile(const void* __restrict__ q, const void* __restrict__ k, int64_t k_head_stride, uint32_t k_key_stride, int H, int H_kv,
                                                  int num, int S, float scale, int causal, const void* __restrict__ bias, int pitch,
-                                                 void* __restrict__ scores, float2* __restrict__ tstats, int tiles) {
+                                                 void* __restrict__ scores, float2* __restrict__ tstats, int tiles,
+                                                 unsigned long long* __restrict__ xch, int rows_total) {
     using A = Act<DT>;
-    constexpr int KPW = kWave / LPK;                 // keys per wave-load
+    constexpr int KPW = kWave / LPK;
+    lq_clear_exchange(xch, rows_total);                 // keys per wave-load
     __shared__ uint4 q_lds[kLqRows][LPK];
     __shared__ float sc[kLqKeys][kLqRows + 1];
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
@@ -337,11 +377,13 @@ typedef float mfma_cd_t __attribute__((ext_vector_type(16)));
 template <int DT, int NK, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k_lq_mfma(const void* __restrict__ q, const void* __restrict__ k, int64_t k_head_stride, uint32_t k_key_stride, int H, int H_kv,
                                                  int num, int S, float scale, int causal, const void* __restrict__ bias, int pitch,
-                                                 void* __restrict__ scores, float2* __restrict__ tstats, int tiles) {
+                                                 void* __restrict__ scores, float2* __restrict__ tstats, int tiles,
+                                                 unsigned long long* __restrict__ xch, int rows_total) {
     using A = Act<DT>;
     static_assert(A::kBytes == 2, "16-bit activations");
     constexpr int kRowsPad = 32;
     __shared__ float2 wstat[WAVES][kRowsPad];
+    lq_clear_exchange(xch, rows_total);
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     const int hk = blockIdx.y, group = H / H_kv, rows = group * num;
     const int r0 = blockIdx.z * kRowsPad, rows_here = min(kRowsPad, rows - r0);
@@ -426,45 +468,54 @@ __global__ __launch_bounds__(64 * WAVES) void k_lq_mfma(const void* __restrict__
     }
 }
 
+// k_lq_finish, two phases in one launch.  (1) The row statistics are folded ONCE: the first ceil(rows / 4) workgroups
+// own four rows each (a wave per row) and publish (max, sum) as two 8-byte {value, tag} granules (agent-scope store:
+// the data is the flag).  Until round 3 every workgroup folded every row (H * num * tiles pairs each: 560 KB per
+// workgroup at the 72B shape, 16.5 us for a kernel that moves 5 MB).  (2) Every workgroup polls the granules into
+// LDS, then normalises its keys.  Owners never wait before they publish, and workgroups are dispatched in index
+// order, so the wait ends; should it not (the contract does not promise dispatch order), a workgroup folds the rows
+// itself after ~1 ms - same bits, see fold_row_wave.
 template <int DT, int KG>
 __global__ __launch_bounds__(256) void k_lq_finish(const void* __restrict__ scores, const float2* __restrict__ tstats,
                                                    int rows_total, int pitch, int tiles, int S, void* __restrict__ weights,
                                                    void* __restrict__ imp, int lo, int hi, int* __restrict__ l0,
-                                                   int* t16_end) {
+                                                   int* t16_end, unsigned long long* __restrict__ xch) {
     using A = Act<DT>;
     constexpr int E = A::kPer16;
     extern __shared__ __attribute__((aligned(16))) float row_ms[];       // [rows_total][2]: the row's max and sum of exp
+    __shared__ int timed_out;
     const int tid = threadIdx.x;
-    {   // global (max, sum) of every row from the tile statistics: a group of G lanes per row
-        int G = 1;
-        while (G < 64 && G * 2 * rows_total <= 256) G *= 2;
-        const int per_pass = 256 / G, sub = tid & (G - 1);
-        for (int row0 = 0; row0 < rows_total; row0 += per_pass) {
-            const int row = row0 + tid / G;
-            const bool live = row < rows_total;
-            const float2* ts = tstats + (size_t)(live ? row : 0) * tiles;
-            // one pass, 8 tiles in flight per lane: running max with the sum rescaled to it
-            float M = -INFINITY, sum = 0.f;
-            for (int t0 = sub; t0 < tiles; t0 += 8 * G) {
-                float2 ms[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) ms[u] = t0 + u * G < tiles ? ts[t0 + u * G] : make_float2(-INFINITY, 0.f);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (ms[u].y > 0.f) {
-                        const float Mn = fmaxf(M, ms[u].x);
-                        sum = sum * expf(M - Mn) + ms[u].y * expf(ms[u].x - Mn);      // (exp(-inf) = 0 on the first)
-                        M = Mn;
-                    }
-                }
+    {
+        const int w = wave_id(), lane = lane_id();
+        const int owners = min((int)gridDim.x, (rows_total + 3) / 4);
+        if (tid == 0) timed_out = 0;
+        if ((int)blockIdx.x < owners) {
+            for (int row = blockIdx.x * 4 + w; row < rows_total; row += owners * 4) {
+                const float2 ms = fold_row_wave(tstats + (size_t)row * tiles, tiles);
+                if (lane < 2)
+                    __hip_atomic_store(&xch[2 * row + lane], ((unsigned long long)kLqTag << 32) | (unsigned long long)__float_as_uint(lane ? ms.y : ms.x),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            for (int o = G >> 1; o > 0; o >>= 1) {
-                const float Mo = __shfl_xor(M, o, kWave), so = __shfl_xor(sum, o, kWave);
-                const float Mn = fmaxf(M, Mo);
-                sum = (M > -INFINITY ? sum * expf(M - Mn) : 0.f) + (Mo > -INFINITY ? so * expf(Mo - Mn) : 0.f);
-                M = Mn;
+        }
+        __syncthreads();
+        for (int x0 = 0; x0 < 2 * rows_total; x0 += 256) {
+            const int x = x0 + tid;
+            const bool need_it = x < 2 * rows_total;
+            unsigned long long v = 0;
+            for (int spins = 0;; ++spins) {
+                if (need_it) v = __hip_atomic_load(&xch[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all(!need_it || (uint32_t)(v >> 32) == kLqTag)) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (spins > (1 << 14)) { if (lane == 0) timed_out = 1; break; }
             }
-            if (live && sub == 0) { row_ms[2 * row] = M; row_ms[2 * row + 1] = sum; }
+            if (need_it) row_ms[x] = __uint_as_float((uint32_t)v);
+        }
+        __syncthreads();
+        if (timed_out) {                                  // (uniform) an owner never arrived: fold here
+            for (int row = w; row < rows_total; row += 4) {
+                const float2 ms = fold_row_wave(tstats + (size_t)row * tiles, tiles);
+                if (lane == 0) { row_ms[2 * row] = ms.x; row_ms[2 * row + 1] = ms.y; }
+            }
         }
     }
     __syncthreads();
@@ -517,13 +568,13 @@ static int launch_lq_general(const void* q, const void* k, KStrides ks, int64_t 
 }
 
 template <int DT>
-static int launch_lq_finish(void* scores, float2* tstats, int rows_total, int pitch, int tiles, int64_t S, void* weights,
+static int launch_lq_finish(void* scores, float2* tstats, unsigned long long* xch, int rows_total, int pitch, int tiles, int64_t S, void* weights,
                             void* importance, int64_t lo, int64_t hi, int* l0, int* t16_end, hipStream_t st) {
     const int words = pitch * Act<DT>::kBytes / 16;              // 16-byte words of one key's scores
     const size_t lds = (size_t)rows_total * 2 * sizeof(float);
 #define FF_LQ_FIN(KG)                                                                                                      \
     hipLaunchKernelGGL((k_lq_finish<DT, KG>), dim3((unsigned)((S * KG + 255) / 256)), dim3(256), lds, st, (const void*)scores, \
-                       (const float2*)tstats, rows_total, pitch, tiles, (int)S, weights, importance, (int)lo, (int)hi, l0, t16_end)
+                       (const float2*)tstats, rows_total, pitch, tiles, (int)S, weights, importance, (int)lo, (int)hi, l0, t16_end, xch)
     if (words >= 8) FF_LQ_FIN(4);
     else if (words >= 4) FF_LQ_FIN(2);
     else FF_LQ_FIN(1);
@@ -538,7 +589,7 @@ size_t lq_ws_bytes(int dtype, int64_t H, int64_t num, int64_t S, int64_t dh) {
     if (!tiled) return (size_t)(2 * H * num * S) * sizeof(float);
     const int64_t tiles = (S + kLqKeys - 1) / kLqKeys;
     const int64_t pitch_bytes = (H * num * esz + 15) & ~(int64_t)15;           // one key's scores: whole 16-byte words
-    return (size_t)(S * pitch_bytes + H * num * tiles * 8 + 16);
+    return (size_t)(S * pitch_bytes + H * num * tiles * 8 + H * num * 16 + 16);     // scores | tile statistics | row granules
 }
 
 template <int DT>
@@ -555,11 +606,13 @@ static int launch_lq(const void* q, const void* k, KStrides ks, int64_t H, int64
     const int64_t pitch_bytes = ((int64_t)rows_total * kB + 15) & ~(int64_t)15;
     const int pitch = (int)(pitch_bytes / kB);
     float2* tstats = (float2*)((char*)scores + S * pitch_bytes);
+    unsigned long long* xch = (unsigned long long*)(tstats + (size_t)rows_total * tiles);
     if constexpr (kB == 2) {
         // matrix-core scores for the head sizes of real models.  4 waves (256 keys) per workgroup = per statistics tile:
         // wider workgroups would mean fewer tiles for the finish kernel to fold (72B shape: 16.5 us at 256 keys per tile,
-        // 12.3 at 512, 9.9 at 1024) but cost this kernel more than that (23.8 -> 38.5 -> 42.5 us); 2 waves: 23.7 + 24.5
-        // (profiles/r03_k5_experiments.txt)
+        // 12.3 at 512, 9.9 at 1024) but cost this kernel more than that (23.8 -> 38.5 -> 42.5 us); 2 waves: 23.7 + 24.5;
+        // a streaming form (workgroup = a run of 32-key blocks, next block in flight, one statistics entry per workgroup):
+        // 22.9-29.9 us at 256-1024 workgroups against 23.5 (profiles/r03_k5_experiments.txt)
         if (dh == 64 || dh == 128 || dh == 256) {
             const int64_t zg = (rows + 31) / 32;
             constexpr int waves = 4;
@@ -567,18 +620,18 @@ static int launch_lq(const void* q, const void* k, KStrides ks, int64_t H, int64
             const dim3 mgrid((unsigned)tiles_m, (unsigned)H_kv, (unsigned)zg);
 #define FF_LQ_MFMA(NK)                                                                                                         \
     hipLaunchKernelGGL((k_lq_mfma<DT, NK, waves>), mgrid, dim3(64 * waves), 0, st, q, k, ks.head, (uint32_t)ks.key, (int)H, (int)H_kv, (int)num, (int)S,   \
-                       (float)scale, causal, bias, pitch, scores, tstats, tiles_m)
+                       (float)scale, causal, bias, pitch, scores, tstats, tiles_m, xch, rows_total)
             if (dh == 64) FF_LQ_MFMA(4);
             else if (dh == 128) FF_LQ_MFMA(8);
             else FF_LQ_MFMA(16);
 #undef FF_LQ_MFMA
-            return launch_lq_finish<DT>(scores, tstats, rows_total, pitch, tiles_m, S, weights, importance, lo, hi, l0, t16_end, st);
+            return launch_lq_finish<DT>(scores, tstats, xch, rows_total, pitch, tiles_m, S, weights, importance, lo, hi, l0, t16_end, st);
         }
     }
     const dim3 grid((unsigned)tiles, (unsigned)H_kv, (unsigned)((rows + kLqRows - 1) / kLqRows));
 #define FF_LQ_TILE(LPK)                                                                                                   \
     hipLaunchKernelGGL((k_lq_tile<DT, LPK>), grid, dim3(256), 0, st, q, k, ks.head, (uint32_t)ks.key, (int)H, (int)H_kv, (int)num, (int)S, (float)scale, \
-                       causal, bias, pitch, scores, tstats, tiles)
+                       causal, bias, pitch, scores, tstats, tiles, xch, rows_total)
     switch ((int)lpk) {
         case 1: FF_LQ_TILE(1); break;
         case 2: FF_LQ_TILE(2); break;
@@ -589,7 +642,7 @@ static int launch_lq(const void* q, const void* k, KStrides ks, int64_t H, int64
         default: FF_LQ_TILE(64);
     }
 #undef FF_LQ_TILE
-    return launch_lq_finish<DT>(scores, tstats, rows_total, pitch, tiles, S, weights, importance, lo, hi, l0, t16_end, st);
+    return launch_lq_finish<DT>(scores, tstats, xch, rows_total, pitch, tiles, S, weights, importance, lo, hi, l0, t16_end, st);
 }
 
 }  // namespace ff
