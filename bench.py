@@ -496,10 +496,28 @@ class _EagerFrameFusion(torch.nn.Module):
         return out
 
 
-E2E_SHAPES = {   # name: (d, layers, heads, kv heads, MLP, patches per frame, reps)
-    "7b": (3584, 28, 28, 4, 18944, 210, 3),          # LLaVA-Video-7B-Qwen2 (BASELINE configs[1]); 14 x 15 tokens per frame
-    "72b": (8192, 80, 64, 8, 29568, 576, 1),         # LLaVA-Video-72B's LLM (configs[4]): 145 GB of bf16 weights on ONE MI355X
+E2E_SHAPES = {   # name: (d, layers, heads, kv heads, MLP, patches per frame, reps, family)
+    "7b": (3584, 28, 28, 4, 18944, 210, 3, "qwen2"),         # LLaVA-Video-7B-Qwen2 (BASELINE configs[1]); 14 x 15 tokens per frame
+    "72b": (8192, 80, 64, 8, 29568, 576, 1, "qwen2"),        # LLaVA-Video-72B's LLM (configs[4]): 145 GB of bf16 weights on ONE MI355X
+    # Qwen2-VL-7B (configs[2]): 128 frames = 64 temporal grids x 195 merged patches (13 x 15), M-RoPE [3, 1, L, 128] position
+    # embeddings, num = 4 importance queries; the regimes are a similarity_lower_bound sweep instead of two p_change values
+    "qwen2vl": (3584, 28, 28, 4, 18944, 195, 2, "qwen2_vl"),
 }
+QWEN2VL_SWEEP = (0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9)
+
+
+def mrope_position_ids(frames, grid_h, grid_w, pre, post, device):
+    """[3, 1, L] (temporal, height, width) position ids of a Qwen2-VL prompt with one video: text tokens advance all three
+    together, a video token takes (start + frame, start + row, start + column), the text behind continues from the largest id
+    (what transformers' Qwen2VLModel.get_rope_index computes for such a prompt)."""
+    t = torch.arange(frames).view(-1, 1, 1).expand(frames, grid_h, grid_w).reshape(-1)
+    h = torch.arange(grid_h).view(1, -1, 1).expand(frames, grid_h, grid_w).reshape(-1)
+    w = torch.arange(grid_w).view(1, 1, -1).expand(frames, grid_h, grid_w).reshape(-1)
+    vis = torch.stack([t, h, w]) + pre
+    head = torch.arange(pre).view(1, -1).expand(3, -1)
+    nxt = int(vis.max()) + 1
+    tail = (torch.arange(post) + nxt).view(1, -1).expand(3, -1)
+    return torch.cat([head, vis, tail], dim=1).view(3, 1, -1).to(device)
 
 
 def e2e_prefill(dev, shape="7b", frames=64, pre=14, post=20, regimes=((P_CHANGE, None), (0.5, 1.6))):
@@ -508,28 +526,45 @@ def e2e_prefill(dev, shape="7b", frames=64, pre=14, post=20, regimes=((P_CHANGE,
     MLP 18944; no checkpoint exists offline) prefills 14 + 64 x 210 + 20 synthetic tokens (a) dense, (b) patched with
     apply_framefusion of THIS build, (c) with the same adapter driving the torch port of the reference's FrameFusion on the
     GPU.  Wall time of the LLM prefill (synchronised), per-layer sequence lengths, and the time spent inside
-    FrameFusion.forward."""
-    from transformers import Qwen2Config, Qwen2ForCausalLM
+    FrameFusion.forward.  shape "72b": configs[4]; shape "qwen2vl": configs[2] - transformers' Qwen2VLTextModel (M-RoPE,
+    num = 4 importance queries) of Qwen2-VL-7B's shape over a similarity_lower_bound sweep."""
     from transformers.cache_utils import DynamicCache
     import framefusion_amd as ffa
-    from framefusion_amd.models.qwen2 import register_hf_qwen2
     from framefusion_amd.synth import video_tokens
     from oracle import ff_oracle as orc
-    d, n_layers, n_heads, n_kv, mlp, patches, reps = E2E_SHAPES[shape]
-    cfg = Qwen2Config(vocab_size=1024, hidden_size=d, intermediate_size=mlp, num_hidden_layers=n_layers, num_attention_heads=n_heads,
-                      num_key_value_heads=n_kv, max_position_embeddings=65536, rope_theta=1000000.0)
+    d, n_layers, n_heads, n_kv, mlp, patches, reps, family = E2E_SHAPES[shape]
+    vl = family == "qwen2_vl"
+    if vl:
+        from transformers.models.qwen2_vl.modeling_qwen2_vl import Qwen2VLTextConfig, Qwen2VLTextModel
+        from framefusion_amd.models.qwen2_vl import register_hf_qwen2_vl
+        pre, post = 15, 12
+        cfg = Qwen2VLTextConfig(vocab_size=1024, hidden_size=d, intermediate_size=mlp, num_hidden_layers=n_layers,
+                                num_attention_heads=n_heads, num_key_value_heads=n_kv, max_position_embeddings=65536,
+                                rope_parameters={"rope_type": "default", "rope_theta": 1e6, "mrope_section": [16, 24, 24]})
+    else:
+        from transformers import Qwen2Config, Qwen2ForCausalLM
+        from framefusion_amd.models.qwen2 import register_hf_qwen2
+        cfg = Qwen2Config(vocab_size=1024, hidden_size=d, intermediate_size=mlp, num_hidden_layers=n_layers, num_attention_heads=n_heads,
+                          num_key_value_heads=n_kv, max_position_embeddings=65536, rope_theta=1000000.0)
     cfg._attn_implementation = "sdpa"
     torch.manual_seed(0)
     prev = torch.get_default_dtype()
     torch.set_default_dtype(torch.bfloat16)          # (the 72B stack is 145 GB in bf16: it must never exist in fp32)
     try:
         with torch.device(dev):
-            model = Qwen2ForCausalLM(cfg).eval()
+            if vl:
+                class Holder(torch.nn.Module):       # the bare text-decoder wrapper of models/qwen2_vl.py ("hf_qwen2_vl_text")
+                    def __init__(self):
+                        super().__init__()
+                        self.model = Qwen2VLTextModel(cfg)
+                model = Holder().eval()
+            else:
+                model = Qwen2ForCausalLM(cfg).eval()
     finally:
         torch.set_default_dtype(prev)
     n_vis = frames * patches
     L = pre + n_vis + post
-    state = {}
+    state = {"pos": mrope_position_ids(frames, 13, 15, pre, post, dev) if vl else None}
 
     def prefill(prepare):
         times, lengths = [], None
@@ -537,10 +572,11 @@ def e2e_prefill(dev, shape="7b", frames=64, pre=14, post=20, regimes=((P_CHANGE,
             if prepare is not None:
                 prepare()
             cache = DynamicCache(config=cfg)
+            kw = {"position_ids": state["pos"]} if vl else {}
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             with torch.no_grad():
-                out = model.model(inputs_embeds=state["emb"], past_key_values=cache, use_cache=True)
+                out = model.model(inputs_embeds=state["emb"], past_key_values=cache, use_cache=True, **kw)
             torch.cuda.synchronize()
             times.append((time.perf_counter() - t0) * 1e3)
             lengths = getattr(model.model, "framefusion_lengths", None) or [out.last_hidden_state.shape[1]] * cfg.num_hidden_layers
@@ -557,13 +593,18 @@ def e2e_prefill(dev, shape="7b", frames=64, pre=14, post=20, regimes=((P_CHANGE,
             i = j
         return ", ".join(out)
 
-    state["emb"], _ = video_tokens(frames, patches, d, p_change=P_CHANGE, sigma=SIGMA, seed=1234, pre=pre, post=post,
-                                   dtype=torch.bfloat16, device=str(dev))
+    if vl:
+        regimes = tuple((0.5, 1.8, thr) for thr in QWEN2VL_SWEEP)        # the C3 sample of extra_configs, threshold swept
+        seed = 77
+    else:
+        regimes = tuple((pc, sh, THRESHOLD) for pc, sh in regimes)
+        seed = 1234
+    state["emb"], _ = video_tokens(frames, patches, d, p_change=regimes[0][0], sigma=SIGMA, sigma_hi=regimes[0][1], seed=seed,
+                                   pre=pre, post=post, dtype=torch.bfloat16, device=str(dev))
     dense_ms, _ = prefill(None)
-    register_hf_qwen2()
+    (register_hf_qwen2_vl if vl else register_hf_qwen2)()
     ffa.apply_framefusion(model, cost=COST, similarity_lower_bound=THRESHOLD, ratio_lower_bound=RATIO_LB)
     hip_ff = model.framefusion
-    eager = _EagerFrameFusion(orc.OracleFrameFusion(COST, THRESHOLD, RATIO_LB))
 
     def install(obj):
         model.framefusion = obj
@@ -572,10 +613,12 @@ def e2e_prefill(dev, shape="7b", frames=64, pre=14, post=20, regimes=((P_CHANGE,
             layer.framefusion = obj
             layer.self_attn.framefusion = obj
     results = []
-    for p_change, sigma_hi in regimes:
-        emb, pt = video_tokens(frames, patches, d, p_change=p_change, sigma=SIGMA, sigma_hi=sigma_hi, seed=1234, pre=pre, post=post,
+    for p_change, sigma_hi, thr in regimes:
+        emb, pt = video_tokens(frames, patches, d, p_change=p_change, sigma=SIGMA, sigma_hi=sigma_hi, seed=seed, pre=pre, post=post,
                                dtype=torch.bfloat16, device=str(dev))
         state["emb"] = emb
+        hip_ff.similarity_lower_bound = thr
+        eager = _EagerFrameFusion(orc.OracleFrameFusion(COST, thr, RATIO_LB))
         install(hip_ff)
         hip_ms, hip_lengths = prefill(lambda: hip_ff.prepare(pt, patches, pre, pre + n_vis - 1, n_vis, L))
         # wall time of the FrameFusion.forward calls of this build (each bracketed by synchronise: launch-from-idle and drain
@@ -603,7 +646,7 @@ def e2e_prefill(dev, shape="7b", frames=64, pre=14, post=20, regimes=((P_CHANGE,
             eager.time_s = 0.0
             eager.prepare(pt, patches, pre, pre + n_vis - 1, n_vis, L)
         eager_ms, eager_lengths = prefill(prep_eager)
-        results.append({"p_change": p_change, "hip_prefill_ms": hip_ms, "eager_reference_prefill_ms": eager_ms,
+        results.append({"p_change": p_change, "similarity_lower_bound": thr, "hip_prefill_ms": hip_ms, "eager_reference_prefill_ms": eager_ms,
                         "prefill_speedup_vs_dense": dense_ms / hip_ms, "prefill_speedup_vs_eager_reference": eager_ms / hip_ms,
                         "framefusion_calls": hip_ff_calls, "hip_ms_inside_framefusion": hip_ff_ms,
                         "eager_ms_inside_framefusion": eager.time_s * 1e3,
@@ -611,8 +654,10 @@ def e2e_prefill(dev, shape="7b", frames=64, pre=14, post=20, regimes=((P_CHANGE,
                         "lengths_hip": runs(hip_lengths), "lengths_eager": runs(eager_lengths)})
     del model
     torch.cuda.empty_cache()
-    return {"workload": f"Qwen2 LLM of LLaVA-Video-{shape.upper()}'s shape (d={d}, {n_layers} layers, {n_heads}/{n_kv} heads, MLP {mlp}, random "
-                        f"weights), prefill of {pre}+{frames}x{patches}+{post} = {L} synthetic tokens, cost={COST}, thr={THRESHOLD}",
+    name = "Qwen2-VL-7B's text decoder (Qwen2VLTextModel, M-RoPE, num=4 importance queries)" if vl else f"Qwen2 LLM of LLaVA-Video-{shape.upper()}'s shape"
+    return {"workload": f"{name} (d={d}, {n_layers} layers, {n_heads}/{n_kv} heads, MLP {mlp}, random "
+                        f"weights), prefill of {pre}+{frames}x{patches}+{post} = {L} synthetic tokens, cost={COST}"
+                        + (", similarity_lower_bound sweep" if vl else f", thr={THRESHOLD}"),
             "dense_prefill_ms": dense_ms, "regimes": results}
 
 

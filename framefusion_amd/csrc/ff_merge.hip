@@ -16,6 +16,7 @@
 // T(n+1) - the order CPU index_add_ applies; fp32-accumulate-then-round differs on ~23 % of
 // elements by more than 1e-3 relative.
 #include <atomic>
+#include <stdlib.h>
 
 #include "ff_common.h"
 
@@ -399,6 +400,8 @@ static int merge_places() {
     return places;
 }
 static int merge_slots(int dtype, bool add, int64_t L, int ny) {
+    static const int forced = getenv("FF_MERGE_SLOTS") ? atoi(getenv("FF_MERGE_SLOTS")) : 0;     // EXPERIMENT knob
+    if (forced >= 1 && forced <= 53) return forced;
     int places;
     switch (dtype) {
         case FF_F32: places = add ? merge_places<FF_F32, true>() : merge_places<FF_F32, false>(); break;

@@ -336,6 +336,44 @@ def test_importance_matrix_core_path(dtype, dh, H, Hk, num, S):
     assert torch.allclose(imp.reshape(-1).cpu().float(), torch.mean(want, dim=(1, 2))[0].float(), rtol=tol, atol=1e-30)
 
 
+def test_importance_owner_timeout_same_bits():
+    """The finish kernel's row statistics come from owner workgroups through tagged granules; a workgroup that gets no
+    answer folds the rows itself after a timeout.  FF_LQ_TEST_NO_PUBLISH silences the owners (a child process: the
+    switch is read once per process): weights and importance must be the same BITS as with the exchange, at shapes with
+    one owner workgroup, several, more rows than one polling pass (H * num = 448) and a one-workgroup grid."""
+    import os, subprocess, sys, tempfile
+    code = r'''
+import sys, torch
+import framefusion_amd as ffa
+out = {}
+for dh, H, Hk, num, S, dt in [(128, 28, 4, 4, 1111, torch.bfloat16), (64, 8, 2, 1, 700, torch.float16), (128, 64, 8, 1, 9000, torch.bfloat16),
+                              (128, 28, 4, 16, 40, torch.bfloat16), (32, 6, 3, 1, 333, torch.float32)]:
+    g = torch.Generator().manual_seed(dh + S)
+    q = torch.randn(1, H, num, dh, generator=g).to(dt).cuda()
+    k = torch.randn(1, Hk, S, dh, generator=g).to(dt).cuda()
+    w = ffa.scaled_dot_product_attention(q, k, None, num=num, is_causal=True, enable_gqa=True)
+    imp = ffa.last_query_importance(q, k, num=num, is_causal=True)
+    out[f"w{S}"] = w.float().cpu()
+    out[f"i{S}"] = imp.float().cpu()
+torch.save(out, sys.argv[1])
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for i, extra in enumerate(({}, {"FF_LQ_TEST_NO_PUBLISH": "1"})):
+            env = {k: v for k, v in os.environ.items() if k != "FF_LQ_TEST_NO_PUBLISH"}
+            env.update(extra)
+            env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+            path = os.path.join(tmp, f"o{i}.pt")
+            subprocess.run([sys.executable, "-c", code, path], check=True, env=env, cwd=root, timeout=600)
+            res.append(torch.load(path))
+    assert res[0].keys() == res[1].keys() and len(res[0]) == 10
+    for key in res[0]:
+        a, b = res[0][key], res[1][key]
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), key
+        assert torch.isfinite(a).all() and float(a.abs().sum()) > 0, key
+
+
 @pytest.mark.parametrize("name", MASK_CASES)
 def test_importance_attn_mask_golden(golden, name):
     """scaled_dot_product_attention(attn_mask=...) (utils.py:40-44) against the real reference's outputs."""
