@@ -12,6 +12,8 @@
 //   s = T(sum_fp32 q_i*k_i);  s = T(fp32(s) * fp32(scale));  s = T(s + bias);  p = T(exp(s - max) / sum)
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "ff_common.h"
 
 namespace ff {
@@ -470,6 +472,137 @@ __global__ __launch_bounds__(64 * WAVES) void k_lq_mfma(const void* __restrict__
     }
 }
 
+// ---- k_lq_dot: scores of at most 8 query rows per kv head (num = 1 with a GQA group of up to 8: LLaVA-Video 7B / 72B) ----
+// The matrix-core kernel above wants one key per lane: a wave-load touches 32 rows x 32 bytes, and with 8 real rows out of
+// the 32 padded ones 3/4 of its epilogue lanes idle - 23 us for the 72 MB of K of the 72B shape, which a bare read delivers
+// in 11 us (profiles/r03_membench_small.txt).  Here 8 consecutive lanes own a key and read its row as whole 128-byte
+// lines (16 bytes per lane and line, NL = dh / 64 lines): every wave-load is 8 full cache lines.  The 8 rows' partial dots
+// (v_dot2c on the packed words, exact products, fp32 sums) meet in a TRANSPOSED reduction over the 8 lanes - 21 DPP /
+// select operations instead of 8 butterflies - after which lane q holds the score of row q: no padded lanes in the
+// epilogue.  A workgroup owns a contiguous run of keys of one kv head; a wave walks 16 keys per step with the next 16
+// (4 KiB) in flight, keeps the running (max, sum of exp) of its row in registers and leaves ONE statistics entry per
+// workgroup and row.
+template <int DT>
+__device__ inline float dot16_packed(const uint4& a, const uint4& b, float acc) {
+    using A = Act<DT>;
+    acc = A::dot2(a.x, b.x, acc); acc = A::dot2(a.y, b.y, acc); acc = A::dot2(a.z, b.z, acc);
+    return A::dot2(a.w, b.w, acc);
+}
+
+// a[r] = lane's partial of row r; returns the sum over the 8 lanes of the key for row q = lane & 7
+__device__ inline float reduce8_transposed(const float (&a)[8], int q) {
+    auto hm = [](float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xf, 0xf, false)); };   // row_half_mirror: q <- 7 - q
+    auto x2 = [](float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, false)); };    // quad_perm [2,3,0,1]
+    auto x1 = [](float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, false)); };    // quad_perm [1,0,3,2]
+    const bool lo4 = q < 4, lo2 = (q & 2) == 0, lo1 = (q & 1) == 0;
+    float b[4], c[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[i] = (lo4 ? a[i] : a[i + 4]) + hm(lo4 ? a[i + 4] : a[i]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) c[i] = (lo2 ? b[i] : b[i + 2]) + x2(lo2 ? b[i + 2] : b[i]);
+    return (lo1 ? c[0] : c[1]) + x1(lo1 ? c[1] : c[0]);
+}
+
+template <int DT, int NL>
+__global__ __launch_bounds__(256) void k_lq_dot(const void* __restrict__ q, const void* __restrict__ k, int64_t k_head_stride, uint32_t k_key_stride, int H, int H_kv,
+                                                int num, int S, float scale, int causal, const void* __restrict__ bias, int pitch,
+                                                void* __restrict__ scores, float2* __restrict__ tstats, int keys_per_wg,
+                                                unsigned long long* __restrict__ xch, int rows_total) {
+    using A = Act<DT>;
+    static_assert(A::kBytes == 2, "16-bit activations");
+    constexpr int U = 2, WAVES = 4, kStep = 8 * U, kStride = WAVES * kStep;  // key groups per wave and step; keys per wave / per workgroup and step
+    __shared__ float2 wstat[WAVES][8];
+    lq_clear_exchange(xch, rows_total);
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const int hk = blockIdx.y, rows = (H / H_kv) * num;               // <= 8 (the launcher's condition)
+    const int sub = lane & 7, kslot = lane >> 3;
+    constexpr uint32_t row_bytes = NL * 128u;                          // dh * 2
+    const uint32_t lane_off = (uint32_t)sub * 16u;
+    uint4 qf[8][NL];                                                   // my 16-byte piece of every line of every query row
+    {
+        const __amdgpu_buffer_rsrc_t qrs = make_rsrc((const char*)q + (size_t)(hk * rows) * row_bytes, (uint32_t)rows * row_bytes);
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int j = 0; j < NL; ++j) qf[r][j] = buf_load16(qrs, (uint32_t)r * row_bytes + (uint32_t)j * 128u + lane_off);   // rows past the group: zeros
+    }
+    const __amdgpu_buffer_rsrc_t krs = make_rsrc((const char*)k + (int64_t)hk * k_head_stride, (uint32_t)(S - 1) * k_key_stride + row_bytes);
+    const int key_end = min(S, ((int)blockIdx.x + 1) * keys_per_wg);
+    int base = blockIdx.x * keys_per_wg + w * kStep;
+    struct Stage { uint4 v[U][NL]; };
+    auto load = [&](Stage& st, int b0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int key = b0 + u * 8 + kslot;
+#pragma unroll
+            for (int j = 0; j < NL; ++j)
+                st.v[u][j] = key < key_end ? buf_load16(krs, (uint32_t)key * k_key_stride + (uint32_t)j * 128u + lane_off) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    const int n = sub % num;
+    const bool my_row = sub < rows;
+    float m_run = -INFINITY, e_run = 0.f;
+    auto compute = [&](const Stage& st, int b0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float a[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < NL; ++j) acc = dot16_packed<DT>(st.v[u][j], qf[r][j], acc);
+                a[r] = acc;
+            }
+            float x = reduce8_transposed(a, sub);
+            // staged rounding + the causal bias; scores out as T, key-major
+            x = A::rnd(x);
+            const int s_key = b0 + u * 8 + kslot;
+            x = A::rnd(x * scale);
+            if (causal && s_key > S - num + n) x = A::rnd(x + (-INFINITY));
+            const bool live = my_row && s_key < key_end;
+            if (bias && live) x = A::rnd(x + A::load1(bias, (int64_t)n * S + s_key));
+            if (live) {
+                A::store1(scores, (int64_t)s_key * pitch + hk * rows + sub, x);
+                if (x > -INFINITY) {                   // running statistics of my row over my keys: one exp
+                    const float dlt = x - m_run;                       // (+inf on the first)
+                    const float t = expf(-fabsf(dlt));                 // exp(-inf) = 0
+                    e_run = dlt > 0.f ? e_run * t + 1.f : e_run + t;
+                    m_run = fmaxf(m_run, x);
+                }
+            }
+        }
+    };
+    // the next step's 4 KiB are in flight while this one is multiplied; the two stages swap by name (no register copies).
+    // (two steps in flight, 8 keys per step, more or fewer workgroups: all slower, profiles/r03_k5_experiments.txt)
+    Stage s0, s1;
+    load(s0, base);
+    while (true) {
+        load(s1, base + kStride); compute(s0, base); base += kStride; if (base >= key_end) break;
+        load(s0, base + kStride); compute(s1, base); base += kStride; if (base >= key_end) break;
+    }
+    // the 8 key slots of the wave hold different keys of the same row
+#pragma unroll
+    for (int o = 8; o < kWave; o <<= 1) {
+        const float mo = __shfl_xor(m_run, o, kWave), eo = __shfl_xor(e_run, o, kWave);
+        const float mn = fmaxf(m_run, mo);
+        e_run = (m_run > -INFINITY ? e_run * expf(m_run - mn) : 0.f) + (mo > -INFINITY ? eo * expf(mo - mn) : 0.f);
+        m_run = mn;
+    }
+    if (lane < 8) wstat[w][lane] = make_float2(m_run, e_run);
+    __syncthreads();
+    if (tid < rows) {
+        float M = -INFINITY, sum = 0.f;
+#pragma unroll
+        for (int x = 0; x < WAVES; ++x) M = fmaxf(M, wstat[x][tid].x);
+#pragma unroll
+        for (int x = 0; x < WAVES; ++x) {
+            const float2 ms = wstat[x][tid];
+            sum += ms.y > 0.f ? ms.y * expf(ms.x - M) : 0.f;
+        }
+        tstats[(size_t)(hk * rows + tid) * gridDim.x + blockIdx.x] = make_float2(M, sum);
+    }
+}
+
 // k_lq_finish, two phases in one launch.  (1) The row statistics are folded ONCE: the first ceil(rows / 4) workgroups
 // own four rows each (a wave per row) and publish (max, sum) as two 8-byte {value, tag} granules (agent-scope store:
 // the data is the flag).  Until round 3 every workgroup folded every row (H * num * tiles pairs each: 560 KB per
@@ -592,11 +725,40 @@ size_t lq_ws_bytes(int dtype, int64_t H, int64_t num, int64_t S, int64_t dh) {
     const int64_t lpk = dh * esz / 16;
     const bool tiled = (dh * esz) % 16 == 0 && lpk >= 1 && lpk <= 64 && (lpk & (lpk - 1)) == 0;
     if (!tiled) return (size_t)(2 * H * num * S) * sizeof(float);
-    const int64_t tiles = (S + kLqKeys - 1) / kLqKeys;
+    const int64_t cap = (S + 63) / 64;                                         // statistics entries per row (k_lq_dot: one per 64-key step at most)
     const int64_t pitch_bytes = (H * num * esz + 15) & ~(int64_t)15;           // one key's scores: whole 16-byte words
-    return (size_t)(S * pitch_bytes + H * num * tiles * 8 + H * num * 16 + 16);     // scores | tile statistics | row granules
+    return (size_t)(S * pitch_bytes + H * num * cap * 8 + H * num * 16 + 16);       // scores | tile statistics | row granules
 }
 
+// One launch of k_lq_dot<DT, NL>: one round of workgroups (what the current device holds of this instantiation at once,
+// cached per device like merge_places in ff_merge.hip), whole steps per workgroup, at least 64 keys per workgroup (the
+// workspace has room for S / 64 statistics entries per row).  Returns the number of statistics entries per row.
+template <int DT, int NL>
+static int launch_lq_dot(const void* q, const void* k, KStrides ks, int64_t H, int64_t H_kv, int64_t num, int64_t S, float scale, int causal,
+                         const void* bias, int pitch, void* scores, float2* tstats, unsigned long long* xch, int rows_total, hipStream_t st) {
+    static std::atomic<int> cache[kMaxDevices];
+    int dev = 0, places = 768;
+    const bool cached = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDevices;
+    if (cached) places = cache[dev].load(std::memory_order_relaxed);
+    if (!cached || places <= 0) {
+        int per_cu = 0;
+        hipDeviceProp_t prop;
+        places = 768;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lq_dot<DT, NL>, 256, 0) == hipSuccess && per_cu >= 1 &&
+            hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            places = per_cu * prop.multiProcessorCount;
+        if (cached) cache[dev].store(places, std::memory_order_relaxed);
+    }
+    constexpr int step = 64;                                           // keys per workgroup and step
+    int G = (int)(places / H_kv);
+    G = G < 1 ? 1 : G;
+    int kpw = (int)((S + G - 1) / G);
+    kpw = (kpw + step - 1) / step * step;
+    G = (int)((S + kpw - 1) / kpw);
+    hipLaunchKernelGGL((k_lq_dot<DT, NL>), dim3((unsigned)G, (unsigned)H_kv), dim3(256), 0, st, q, k, ks.head, (uint32_t)ks.key, (int)H,
+                       (int)H_kv, (int)num, (int)S, scale, causal, bias, pitch, scores, tstats, kpw, xch, rows_total);
+    return G;
+}
 template <int DT>
 static int launch_lq(const void* q, const void* k, KStrides ks, int64_t H, int64_t H_kv, int64_t num, int64_t S, int64_t dh,
                      double scale, int causal, const void* bias, void* weights, void* importance, void* ws, int64_t lo, int64_t hi,
@@ -611,13 +773,19 @@ static int launch_lq(const void* q, const void* k, KStrides ks, int64_t H, int64
     const int64_t pitch_bytes = ((int64_t)rows_total * kB + 15) & ~(int64_t)15;
     const int pitch = (int)(pitch_bytes / kB);
     float2* tstats = (float2*)((char*)scores + S * pitch_bytes);
-    unsigned long long* xch = (unsigned long long*)(tstats + (size_t)rows_total * tiles);
+    const int cap = (int)((S + 63) / 64);
+    unsigned long long* xch = (unsigned long long*)(tstats + (size_t)rows_total * cap);
     if constexpr (kB == 2) {
         // matrix-core scores for the head sizes of real models.  4 waves (256 keys) per workgroup = per statistics tile:
         // wider workgroups would mean fewer tiles for the finish kernel to fold (72B shape: 16.5 us at 256 keys per tile,
         // 12.3 at 512, 9.9 at 1024) but cost this kernel more than that (23.8 -> 38.5 -> 42.5 us); 2 waves: 23.7 + 24.5;
         // a streaming form (workgroup = a run of 32-key blocks, next block in flight, one statistics entry per workgroup):
         // 22.9-29.9 us at 256-1024 workgroups against 23.5 (profiles/r03_k5_experiments.txt)
+        if ((dh == 64 || dh == 128) && rows <= 8) {
+            const int G = dh == 64 ? launch_lq_dot<DT, 1>(q, k, ks, H, H_kv, num, S, (float)scale, causal, bias, pitch, scores, tstats, xch, rows_total, st)
+                                   : launch_lq_dot<DT, 2>(q, k, ks, H, H_kv, num, S, (float)scale, causal, bias, pitch, scores, tstats, xch, rows_total, st);
+            return launch_lq_finish<DT>(scores, tstats, xch, rows_total, pitch, G, S, weights, importance, lo, hi, l0, t16_end, st);
+        }
         if (dh == 64 || dh == 128 || dh == 256) {
             const int64_t zg = (rows + 31) / 32;
             constexpr int waves = 4;

@@ -16,7 +16,6 @@
 // T(n+1) - the order CPU index_add_ applies; fp32-accumulate-then-round differs on ~23 % of
 // elements by more than 1e-3 relative.
 #include <atomic>
-#include <stdlib.h>
 
 #include "ff_common.h"
 
@@ -373,8 +372,8 @@ __global__ __launch_bounds__(256) void k_gather_mask8(const char* __restrict__ m
 // Slots per workgroup, chosen per launch (measured at 64 x 576 x 4096, K4 in the step; 32 was the fixed value):
 //  * the waves are long streams, so a launch whose workgroups do not all fit on the chip at once ends with a
 //    nearly empty extra round: 32 slots = 2 304 workgroups on 2 048 places 79 us, 36 slots (2 048) 73.6 us,
-//    40 slots (1 844) 75.8 us, 48 slots (1 536) 80.5 us.  The main workgroups are sized to ~97 % of r rounds'
-//    places (the rest is for the short aux / order / table blocks passing through), smallest r that fits;
+//    40 slots (1 844) 75.8 us, 48 slots (1 536) 80.5 us.  The main workgroups are sized to ~97 % of ONE round's
+//    places (the rest is for the short aux / order / table blocks passing through) whenever that fits;
 //  * all workgroups start together and advance at the same pace: when the slot count shares a factor with the
 //    frames per patch they all sit on the same few frames - the same few MB - at any time (64 frames: 16 / 24 /
 //    32 slots 34.5 us, 19 / 21 slots 31 us at 64 x 210 x 3584; 36 / 38 slots 73.6 us, 37 slots 71 us above).
@@ -400,8 +399,6 @@ static int merge_places() {
     return places;
 }
 static int merge_slots(int dtype, bool add, int64_t L, int ny) {
-    static const int forced = getenv("FF_MERGE_SLOTS") ? atoi(getenv("FF_MERGE_SLOTS")) : 0;     // EXPERIMENT knob
-    if (forced >= 1 && forced <= 53) return forced;
     int places;
     switch (dtype) {
         case FF_F32: places = add ? merge_places<FF_F32, true>() : merge_places<FF_F32, false>(); break;
@@ -409,12 +406,21 @@ static int merge_slots(int dtype, bool add, int64_t L, int ny) {
         default: places = add ? merge_places<FF_F16, true>() : merge_places<FF_F16, false>();
     }
     static const int primes[] = {17, 19, 23, 29, 31, 37, 41, 43, 47, 53};
-    const double fill = 0.975 * (double)places;
-    for (int r = 1;; ++r) {
-        const double want = (double)L * ny / (fill * r);
-        for (int p : primes)
-            if ((double)p >= want) return p;
-    }
+    const double want = (double)L * ny / (0.975 * (double)places);
+    for (int p : primes)
+        if ((double)p >= want) return p;
+    // One round does not hold the call.  Whole rounds of long workgroups only pay when they are WHOLE (128 x 576 x 4096:
+    // 37 slots = 1.996 rounds 155 us, 11 slots 163, 7 slots 164, 5 slots 158; 96 x 576 x 4096: 29 slots = 1.91 rounds 127 us,
+    // 7 slots 121.5) and the rows are at most two column groups wide (64 x 576 x 8192, four groups: 37 slots = 2.0 rounds
+    // 166 us, 29 162, 11 159, 7 158): otherwise many short workgroups (profiles/r03_k5_experiments.txt)
+    if (ny <= 2)
+        for (int r = 2; r <= 3; ++r)
+            for (int p : primes)
+                if ((double)p >= want / r) {
+                    if (want / r >= 0.985 * p) return p;
+                    break;
+                }
+    return 7;
 }
 
 int launch_merge_compact(const void* hidden, const void* addend, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,

@@ -336,6 +336,40 @@ def test_importance_matrix_core_path(dtype, dh, H, Hk, num, S):
     assert torch.allclose(imp.reshape(-1).cpu().float(), torch.mean(want, dim=(1, 2))[0].float(), rtol=tol, atol=1e-30)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("dh,H,Hk,num,S", [(128, 64, 8, 1, 4099), (128, 28, 4, 1, 3001), (64, 16, 2, 1, 1000), (128, 8, 4, 2, 777), (64, 4, 2, 4, 130),
+                                           (128, 8, 1, 1, 9), (128, 5, 5, 1, 1), (64, 24, 3, 1, 65), (128, 16, 2, 1, 20000)])
+def test_importance_dot_path(dtype, dh, H, Hk, num, S):
+    """At most 8 query rows per kv head and dh in {64, 128} (num = 1 of LLaVA-Video 7B / 72B): the v_dot2c kernel - 8 lanes
+    per key, whole cache lines, transposed 8-lane reduction, one statistics entry per workgroup.  Grid inputs make every
+    product sum exact (any summation order gives the oracle's scores); what is left is the softmax's ulp noise.  Lengths
+    around the 8-key group, the 64-key step and the workgroup's run; 1 to 8 rows."""
+    g = torch.Generator().manual_seed(dh + S + H)
+    q = harness.snap(0.5 * torch.randn(1, H, num, dh, generator=g), dtype)
+    k = harness.snap(0.5 * torch.randn(1, Hk, S, dh, generator=g), dtype)
+    want = orc.last_query_attention(q, k, num=num, is_causal=True, enable_gqa=True)
+    got = ffa.scaled_dot_product_attention(dev(q), dev(k), None, num=num, is_causal=True, enable_gqa=True)
+    tol = 2 ** -7 if dtype == torch.bfloat16 else 2 ** -10
+
+    def ulps(a, b):       # non-negative 16-bit values: neighbouring bit patterns are neighbouring values (fp16 subnormals included)
+        return int((a.cpu().view(torch.int16).int() - b.cpu().view(torch.int16).int()).abs().max())
+    assert got.shape == want.shape
+    assert ulps(got, want) <= 1
+    # (fp16's 11-bit mantissa sees the fp32 order of the row's exponentials more often: the soak's bound, tests/soak_gpu.py)
+    assert float((got.cpu().float() != want.float()).float().mean()) <= (2e-3 if dtype == torch.bfloat16 else 1.6e-2)
+    imp = ffa.last_query_importance(dev(q), dev(k), num=num, is_causal=True).reshape(-1)
+    assert ulps(imp, torch.mean(got, dim=(1, 2))[0]) <= 1 and ulps(imp, torch.mean(want, dim=(1, 2))[0]) <= 2
+    # gaussian (off-grid) inputs: the fp32 order of a score's 128 products differs from the oracle's, so a score now and
+    # then rounds to the neighbouring T value (and its weight moves by more than an ulp): rare, and bounded
+    q2 = torch.randn(1, H, num, dh, generator=g).to(dtype)
+    k2 = torch.randn(1, Hk, S, dh, generator=g).to(dtype)
+    want2 = orc.last_query_attention(q2, k2, num=num, is_causal=True, enable_gqa=True).float()
+    got2 = ffa.scaled_dot_product_attention(dev(q2), dev(k2), None, num=num, is_causal=True, enable_gqa=True).cpu().float()
+    off = ((got2 - want2).abs() > 2 * tol * want2.abs()).float().mean()
+    assert float(off) <= 5e-3, float(off)
+    assert torch.allclose(got2, want2, rtol=0.1, atol=1e-30)
+
+
 def test_importance_owner_timeout_same_bits():
     """The finish kernel's row statistics come from owner workgroups through tagged granules; a workgroup that gets no
     answer folds the rows itself after a timeout.  FF_LQ_TEST_NO_PUBLISH silences the owners (a child process: the
