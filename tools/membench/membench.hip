@@ -195,14 +195,15 @@ __global__ void k_read_seq(const char* __restrict__ base, int n_rows, int row_by
 
 // pattern 3: copy - every word is read, a fraction `keep_256`/256 of the rows is written (row = 8 KiB),
 // stores optionally non-temporal: the traffic mix of the merge+compaction pass
-template <int NT>
+template <int NT, int REV = 0>
 __global__ void k_copy_rows(const uint4* __restrict__ src, uint4* __restrict__ dst, int n_rows, int keep_256) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int waves = (gridDim.x * blockDim.x) >> 6;
     typedef unsigned int v4u __attribute__((ext_vector_type(4)));
     int out_row = 0;
-    for (int r = wave; r < n_rows; r += waves) {
+    for (int r0 = wave; r0 < n_rows; r0 += waves) {
+        const int r = REV ? n_rows - 1 - r0 : r0;          // REV: from the end of the buffer (what a previous read pass fetched last)
         const bool keep = ((r * 37) & 255) < keep_256;
         const uint4* p = src + (size_t)r * 512 + lane;
         uint4 v[8];
@@ -277,6 +278,26 @@ static float time_us(F f, int reps) {
     return ms * 1e3f / reps;
 }
 
+// `pre` (untimed) then `f` (timed), per repetition: the state a consumer finds right after a producer pass over its input
+template <class G, class F>
+static float time_after_us(G pre, F f, int reps) {
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    pre(); f(); pre(); f();
+    CK(hipDeviceSynchronize());
+    float total = 0;
+    for (int i = 0; i < reps; ++i) {
+        pre();
+        CK(hipEventRecord(a));
+        f();
+        CK(hipEventRecord(b));
+        CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b));
+        total += ms;
+    }
+    return total * 1e3f / reps;
+}
+
 int main(int argc, char** argv) {
     const size_t bytes = (argc > 1 ? atol(argv[1]) : 302) * 1000000ull / 16 * 16;
     // two buffers, alternated, so that a buffer larger than the Infinity Cache is really cold
@@ -348,6 +369,31 @@ int main(int argc, char** argv) {
         float us = time_us([&] { flip ^= 1; hipLaunchKernelGGL((k_copy_coltile<SLOTS, DEPTH, NT>), grid, dim3(256), 0, 0, (const char*)(flip ? a : b), c, n_rows, F, KEEP); }, 10); \
         const double moved = (double)n_rows * row_bytes * (1.0 + KEEP / 256.0); \
         printf("colt  slots=%2d depth=%d nt=%d keep=%3d/256 : %7.1f us  %7.1f GB/s (read + written bytes)\n", SLOTS, DEPTH, NT, KEEP, us, moved / us / 1e3); }
+    // the merge pass's real situation: the similarity pass has just read the whole source (ascending), the Infinity Cache holds
+    // its last 256 MiB.  An event pair around one launch adds ~7 us of command-processor round trips to every line here
+    // (the "pre only" line shows it): compare lines with each other, not with the back-to-back loops above.
+#define WARM(NT, REV, KEEP, BLOCKS) { \
+        auto pre = [&] { flip ^= 1; hipLaunchKernelGGL((k_read_flat<1, 0>), dim3(2048), dim3(256), 0, 0, (const uint4*)(flip ? a : b), n16, sink); }; \
+        float us = time_after_us(pre, [&] { hipLaunchKernelGGL((k_copy_rows<NT, REV>), dim3(BLOCKS), dim3(256), 0, 0, (const uint4*)(flip ? a : b), (uint4*)c, n_rows, KEEP); }, 10); \
+        float cold = time_after_us(pre, [&] { hipLaunchKernelGGL((k_copy_rows<NT, REV>), dim3(BLOCKS), dim3(256), 0, 0, (const uint4*)(flip ? b : a), (uint4*)c, n_rows, KEEP); }, 10); \
+        const double moved = (double)n_rows * row_bytes * (1.0 + KEEP / 256.0); \
+        printf("copy after a read pass of the SAME buffer: nt=%d rev=%d keep=%3d/256 blocks=%5d : %7.1f us  %7.1f GB/s | of the OTHER buffer: %7.1f us\n", NT, REV, KEEP, BLOCKS, us, moved / us / 1e3, cold); }
+#define WARMCOLT(SLOTS, DEPTH, NT, KEEP) { \
+        dim3 grid((n_rows + SLOTS - 1) / SLOTS, 2); \
+        auto pre = [&] { flip ^= 1; hipLaunchKernelGGL((k_read_flat<1, 0>), dim3(2048), dim3(256), 0, 0, (const uint4*)(flip ? a : b), n16, sink); }; \
+        float us = time_after_us(pre, [&] { hipLaunchKernelGGL((k_copy_coltile<SLOTS, DEPTH, NT>), grid, dim3(256), 0, 0, (const char*)(flip ? a : b), c, n_rows, F, KEEP); }, 10); \
+        float cold = time_after_us(pre, [&] { hipLaunchKernelGGL((k_copy_coltile<SLOTS, DEPTH, NT>), grid, dim3(256), 0, 0, (const char*)(flip ? b : a), c, n_rows, F, KEEP); }, 10); \
+        const double moved = (double)n_rows * row_bytes * (1.0 + KEEP / 256.0); \
+        printf("colt after a read pass of the SAME buffer: slots=%2d depth=%d nt=%d keep=%3d/256 : %7.1f us  %7.1f GB/s | of the OTHER buffer: %7.1f us\n", SLOTS, DEPTH, NT, KEEP, us, moved / us / 1e3, cold); }
+    { auto pre = [&] { flip ^= 1; hipLaunchKernelGGL((k_read_flat<1, 0>), dim3(2048), dim3(256), 0, 0, (const uint4*)(flip ? a : b), n16, sink); };
+      float us = time_after_us(pre, [&] { hipLaunchKernelGGL((k_read_flat<1, 0>), dim3(1), dim3(64), 0, 0, (const uint4*)a, (size_t)64, sink); }, 10);
+      printf("event pair around an (almost) empty launch after the read pass: %7.1f us\n", us);
+      us = time_after_us(pre, [&] { hipLaunchKernelGGL((k_read_flat<1, 0>), dim3(2048), dim3(256), 0, 0, (const uint4*)(flip ? a : b), n16, sink); }, 10);
+      float cold = time_after_us(pre, [&] { hipLaunchKernelGGL((k_read_flat<1, 0>), dim3(2048), dim3(256), 0, 0, (const uint4*)(flip ? b : a), n16, sink); }, 10);
+      printf("flat read after a read pass of the SAME buffer: %7.1f us | of the OTHER buffer: %7.1f us\n", us, cold); }
+    WARM(1, 0, 77, 2048) WARM(1, 1, 77, 2048) WARM(1, 1, 77, 4096) WARM(0, 1, 77, 2048) WARM(1, 1, 0, 2048) WARM(1, 0, 0, 2048)
+    WARMCOLT(37, 4, 1, 77) WARMCOLT(37, 4, 0, 77)
+    if (argc > 3) return 0;
     COLT(37, 4, 1, 77) COLT(36, 4, 1, 77) COLT(19, 4, 1, 77) COLT(32, 4, 1, 77) COLT(32, 4, 0, 77) COLT(32, 8, 1, 77) COLT(16, 4, 1, 77) COLT(64, 4, 1, 77) COLT(32, 2, 1, 77)
     COPY(0, 256, 2048) COPY(1, 256, 2048) COPY(0, 77, 2048) COPY(1, 77, 2048) COPY(1, 77, 4096) COPY(1, 77, 1024) COPY(1, 128, 2048)
     return 0;
