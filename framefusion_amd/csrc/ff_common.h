@@ -73,6 +73,18 @@ template <> struct Act<FF_BF16> {
                           (__float_as_uint(f[4]) >> 16) | (__float_as_uint(f[5]) & 0xffff0000u),
                           (__float_as_uint(f[6]) >> 16) | (__float_as_uint(f[7]) & 0xffff0000u));
     }
+    // any floats: rounded to bf16 (RNE) on the way, two per v_cvt_pk_bf16_f32
+    __device__ static inline uint4 pack_rne(const float* f) {
+        uint32_t w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            bf16x2_t pr;
+            pr.x = (__bf16)f[2 * e];
+            pr.y = (__bf16)f[2 * e + 1];
+            w[e] = __builtin_bit_cast(uint32_t, pr);
+        }
+        return make_uint4(w[0], w[1], w[2], w[3]);
+    }
     __device__ static inline float load1(const void* p, int64_t idx) {
         return __uint_as_float((uint32_t)((const uint16_t*)p)[idx] << 16);
     }

@@ -162,6 +162,41 @@ def test_merge_golden(golden, name):
         assert same_bits(merged[0].cpu(), from_bits(g[f"{name}/merge_{sname}/hidden"], dtype)), sname
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_merge_arbitrary_bit_patterns(dtype, seed):
+    """The fold on values the grid fixtures never contain: every exponent (subnormal quotients, overflowing sums), -0,
+    infinities, runs of 1..20+ members (divisors that are not powers of two).  The bf16 flush multiplies by one IEEE
+    reciprocal instead of dividing (csrc/ff_merge.hip, proven exhaustively on the CPU in tests/test_host_logic.py): the
+    result must still be the oracle's `rows / (n + 1)` bit for bit."""
+    g = torch.Generator().manual_seed(seed)
+    F, P, d = 48, 8, 64
+    bits = torch.randint(0, 65536, (F * P, d), generator=g, dtype=torch.int32)
+    expo_mask, expo_max = (0x7f80, 0x7f00) if dtype == torch.bfloat16 else (0x7c00, 0x7800)
+    is_special = (bits & expo_mask) == expo_mask                      # no NaN / inf from the generator (payloads differ by device)
+    bits = torch.where(is_special, (bits & ~expo_mask) | expo_max, bits)
+    if seed == 1:                                                       # small magnitudes: quotients in the subnormal range
+        bits = bits & (0x80ff if dtype == torch.bfloat16 else 0x83ff) | (torch.randint(0, 3, bits.shape, generator=g, dtype=torch.int32) << (7 if dtype == torch.bfloat16 else 10))
+    h = bits.to(torch.int16).view(dtype)[None].clone()
+    h[0, 5] = 0.0
+    h[0, 6] = -0.0
+    h[0, 7, :8] = float("inf")
+    order, _ = orc.by_patch_order(torch.arange(P).repeat(F)[None], P)
+    nv = F * P
+    flags = torch.rand(nv, generator=g) < 0.75
+    flags[torch.arange(P) * F] = False                                  # a chain's first slot has no predecessor
+    midx = torch.nonzero(flags).reshape(-1)
+    want, keep_want = orc.merge_rows(h.clone(), order, midx)
+    sim = torch.zeros(1, nv, dtype=dtype)
+    got, keep = ffa.FrameFusion.merge_tokens_and_get_mask(dev(h.clone()), dev(sim), dev(order.reshape(1, -1)), dev(midx))
+    assert torch.equal(keep.cpu(), keep_want)
+    a, b = got[0].cpu()[keep_want[0]], want[0][keep_want[0]]
+    same = (a.view(torch.int16) == b.view(torch.int16)) | (torch.isnan(a.float()) & torch.isnan(b.float()))
+    assert bool(same.all()), f"{int((~same).sum())} elements differ"
+    lens = orc.run_lengths(flags[None].to(torch.long))[0]
+    assert int(lens.max()) >= 9                                         # long runs are really in there
+
+
 # ---------------------------------------------------------------------------------------------
 # FrameFusion.forward
 # ---------------------------------------------------------------------------------------------

@@ -211,3 +211,27 @@ def test_forward_residual_signature_and_errors():
     assert torch.equal(out, a + b) and pe == "pos" and m is None
     with pytest.raises(ffa.FrameFusionHipError):
         ff.forward(b, "pos", None, residual=torch.ones(1, 3, 8))
+
+
+def test_bf16_divide_equals_multiply_by_reciprocal_exhaustively():
+    """What the merge kernel's bf16 flush relies on (csrc/ff_merge.hip): for EVERY bf16 value a and every run-length
+    divisor T(k), k = 2..70 000, T(a / d) == T(a * RN(1 / d)) with fp32 arithmetic in between - the quotient of two 8-bit
+    significands is never within 2^-17 of a bf16 rounding boundary.  fp16 (11-bit significands) fails the same check,
+    which is why only the bf16 instantiation uses the reciprocal."""
+    torch.set_flush_denormal(False)
+    one = torch.tensor(1.0, dtype=torch.float32)
+
+    def mismatches(dtype, int_view):
+        a = torch.arange(65536, dtype=torch.int32).to(torch.int16).view(dtype).to(torch.float32)
+        ds = torch.unique(torch.arange(2, 70001, dtype=torch.float32).to(dtype).to(torch.float32))
+        bad = 0
+        for d in ds:
+            ref = (a / d).to(dtype)
+            got = (a * (one / d)).to(dtype)
+            same = (ref.view(int_view) == got.view(int_view)) | (torch.isnan(ref.float()) & torch.isnan(got.float()))
+            bad += int((~same).sum())
+        return bad, len(ds)
+    bad, n = mismatches(torch.bfloat16, torch.int16)
+    assert n == 1288 and bad == 0
+    bad16, _ = mismatches(torch.float16, torch.int16)
+    assert bad16 > 0                                   # the reason fp16 keeps the IEEE division
