@@ -1,5 +1,5 @@
 #!/bin/bash
-# K4 timing probes (development): rebuild ff_merge.o with -DFF_K4_VAR=<mask> on the GPU box, in-step timeline each.
+# K4 timing probes (development): rebuild ff_merge.o with -DFF_K4_PROBE=<mask> on the GPU box, in-step timeline each.
 #   tools/_k4probe.sh <out_dir> <mask> [<mask> ...]
 out=$1; shift
 mkdir -p "$out"
