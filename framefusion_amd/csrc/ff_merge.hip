@@ -21,9 +21,6 @@
 
 namespace ff {
 
-#ifndef FF_K4_PROBE
-#define FF_K4_PROBE 0     // 1: uniform streams (exactly the own slots), 2: output row = input row (no dst gather)
-#endif
 constexpr int kMergeThreads = 256;
 constexpr int kMergeWaves = kMergeThreads / kWave;
 
@@ -196,12 +193,12 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
     unsigned long long memw = __ballot((t0 + lane < L) ? (member[t0 + lane] != 0) : false);
     // output rows of my anchors (only slots [t0, t_end) can open a row here)
     const bool anchor_lane = t0 + lane < t_end && !((memw >> lane) & 1ull);
-    const int dv = (FF_K4_PROBE & 2) ? ordw : (anchor_lane ? dst[ordw] : 0);
+    const int dv = anchor_lane ? dst[ordw] : 0;
 
     // first slot of the stream
     const unsigned long long own = (1ull << (t_end - t0)) - 1ull;         // slots <= 53 (merge_slots)
     const unsigned long long starts = ~memw & own;
-    if (!(FF_K4_PROBE & 1) && starts == 0ull) return;                             // every slot here belongs to an earlier anchor
+    if (starts == 0ull) return;                             // every slot here belongs to an earlier anchor
 
     auto piece = [&](int i) { return make_rsrc(hidden + (int64_t)i * row_bytes + col, blk_bytes); };
     auto piece2 = [&](int i) { return make_rsrc((kAdd ? addend : hidden) + (int64_t)i * row_bytes + col, blk_bytes); };
@@ -220,7 +217,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
         for (int u = 0; u < kDepth; ++u) {
             const int s = pos + u;
             const bool is_mem = (memw >> (rel + u)) & 1ull;
-            const bool in = (FF_K4_PROBE & 1) ? (take == u && s < t_end) : (take == u && s < L && (is_mem || s < t_end));
+            const bool in = take == u && s < L && (is_mem || s < t_end);
             if (in) { ++take; mem_bits |= is_mem ? (1u << u) : 0u; }
             b.idx[u] = __builtin_amdgcn_readlane(ordw, rel + u);
         }
@@ -284,7 +281,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
         for (int u = 0; u < kDepth; ++u) {
             if (u < b.take) {
                 const bool is_mem = (b.mem_bits >> u) & 1u;
-                if (!is_mem || ((FF_K4_PROBE & 1) && open_r < 0)) {
+                if (!is_mem) {
                     if (open_r >= 0) flush();
                     open_r = __builtin_amdgcn_readlane(dv, b.pos + u - t0);
                     open_n = 0;
@@ -307,7 +304,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
     };
 
     Batch<kDepth, kAdd> b0, b1;
-    int pos = (FF_K4_PROBE & 1) ? t0 : t0 + __ffsll((long long)starts) - 1;
+    int pos = t0 + __ffsll((long long)starts) - 1;
     issue(b0, pos);
     pos += b0.take;
     while (true) {
