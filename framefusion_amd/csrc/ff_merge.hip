@@ -4,10 +4,11 @@
 // reference runs as 6+ kernels with host syncs, by one launch that reads every surviving or
 // folded row exactly once and writes every output row exactly once.
 //
-// Work decomposition: by INPUT rows, not output rows - a wave owns `slots` consecutive slots t of
+// Work decomposition: by INPUT rows, not output rows - a wave owns about `slots` consecutive slots t of
 // the by-patch order (then the non-visual tail) for one 1 KiB column block.  Member slots are
-// read by the wave that owns their anchor.  Because every input row
-// is read by exactly one wave per column block and slots are spread evenly, the HBM read load is
+// read by the wave that owns their anchor: the boundary between two waves' ranges sits on the non-member
+// slot nearest to a multiple of `slots`.  Because every input row is read by exactly one wave per column
+// block and the ranges are even (headline call: 37 +- 3.9 slots, longest 53), the HBM read load is
 // balanced no matter how long individual runs are (an output-row decomposition would leave the
 // longest run as the tail).
 //
@@ -53,8 +54,8 @@ __device__ inline void copy_row(const char* __restrict__ src, char* __restrict__
 // Waves are independent (no LDS, no barrier): the 4 waves of a workgroup own the same `slots`
 // consecutive by-patch slots and one 1 KiB column tile each (16 bytes per lane), so a workgroup
 // reads 4 KiB of a row at a time.  A wave treats its job as a STREAM of rows in by-patch order:
-// it starts at its first non-member slot and runs until the first non-member slot at or beyond
-// t0 + slots; a non-member row opens a new output row, a member row is folded into the open one.
+// it runs from boundary(t0) to boundary(t0 + slots) (see `boundary` in the kernel: the nearest non-member
+// slot); a non-member row opens a new output row, a member row is folded into the open one.
 // One coalesced load of order[] / member[] for 64 slots tells the wave the whole stream, so the
 // row pieces are requested kDepth at a time, the next batch being issued BEFORE the current one
 // is folded (two register batches), with no dependent index fetch in between (dst[] is only
@@ -187,18 +188,48 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
     const uint32_t voff = (uint32_t)lane * 16;
     const int t_end = min(t0 + slots, L);
 
-    // window of 64 slots: row indices and member flags
-    int win = t0;
-    int ordw = (t0 + lane < L) ? (order ? order[t0 + lane] : t0 + lane) : 0;
-    unsigned long long memw = __ballot((t0 + lane < L) ? (member[t0 + lane] != 0) : false);
-    // output rows of my anchors (only slots [t0, t_end) can open a row here)
-    const bool anchor_lane = t0 + lane < t_end && !((memw >> lane) & 1ull);
-    const int dv = anchor_lane ? dst[ordw] : 0;
+    // window of 64 slots: row indices and member flags, starting `look` slots BEFORE the nominal range
+    const int look = min(10, (kWave - slots) / 2);          // slots <= 53 (merge_slots): look >= 5
+    const int win0 = t0 - look;
+    int win = win0;
+    const int sl = win0 + lane;
+    const bool sl_ok = sl >= 0 && sl < L;
+    int ordw = sl_ok ? (order ? order[sl] : sl) : 0;
+    const bool sl_mem = sl_ok ? (member[sl] != 0) : false;
+    unsigned long long memw = __ballot(sl_mem);
+    const unsigned long long nonmem = __ballot(sl_ok && !sl_mem);
 
-    // first slot of the stream
-    const unsigned long long own = (1ull << (t_end - t0)) - 1ull;         // slots <= 53 (merge_slots)
-    const unsigned long long starts = ~memw & own;
-    if (starts == 0ull) return;                             // every slot here belongs to an earlier anchor
+    // The stream of this wave is [bs, be): a run cannot be split between waves (the rounding after every add makes the fold
+    // sequential), so the boundary between two slot groups moves to a non-member slot - the NEAREST one within `look` slots
+    // before the nominal boundary x, else the first one at or after x (the rule until round 3, which made the longest
+    // stream of the headline call 68 slots for a mean of 37; nearest: 53, profiles/r03_k4_probes.txt).  boundary(x) only
+    // reads the flags of [x - look, ...): both neighbours of a boundary compute the same slot.
+    auto first_nonmember_from = [&](int s0) {               // rare: no non-member left in the window
+        for (int s = s0; s < L; s += kWave) {
+            const unsigned long long b = __ballot(s + lane < L && member[s + lane] == 0);
+            if (b) return s + (int)__ffsll((long long)b) - 1;
+        }
+        return L;
+    };
+    auto boundary = [&](int x) {                            // x in [t0, t_end]: inside the window
+        if (x >= L) return L;
+        const int xr = x - win0;
+        const unsigned long long above = nonmem >> xr;
+        const int fwd = above ? x + (int)__ffsll((long long)above) - 1 : first_nonmember_from(win0 + kWave);
+        unsigned long long below = nonmem & ((1ull << xr) - 1ull);
+        if (xr > look) below &= ~((1ull << (xr - look)) - 1ull);
+        if (below) {
+            const int bwd = win0 + 63 - (int)__builtin_clzll(below);
+            if (x - bwd < fwd - x) return bwd;
+        }
+        return fwd;
+    };
+    const int bs = boundary(t0), be = boundary(t_end);
+    if (bs >= be) return;                                   // the whole nominal range belongs to a neighbour's stream
+    // output rows of my anchors: non-members of [bs, be), all inside the first window (bs < t_end <= win0 + 64 - look, and
+    // everything from t_end to be is a member)
+    const bool anchor_lane = sl_ok && !sl_mem && sl >= bs && sl < be;
+    const int dv = anchor_lane ? dst[ordw] : 0;
 
     auto piece = [&](int i) { return make_rsrc(hidden + (int64_t)i * row_bytes + col, blk_bytes); };
     auto piece2 = [&](int i) { return make_rsrc((kAdd ? addend : hidden) + (int64_t)i * row_bytes + col, blk_bytes); };
@@ -217,7 +248,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
         for (int u = 0; u < kDepth; ++u) {
             const int s = pos + u;
             const bool is_mem = (memw >> (rel + u)) & 1ull;
-            const bool in = take == u && s < L && (is_mem || s < t_end);
+            const bool in = take == u && s < be;
             if (in) { ++take; mem_bits |= is_mem ? (1u << u) : 0u; }
             b.idx[u] = __builtin_amdgcn_readlane(ordw, rel + u);
         }
@@ -283,7 +314,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
                 const bool is_mem = (b.mem_bits >> u) & 1u;
                 if (!is_mem) {
                     if (open_r >= 0) flush();
-                    open_r = __builtin_amdgcn_readlane(dv, b.pos + u - t0);
+                    open_r = __builtin_amdgcn_readlane(dv, b.pos + u - win0);
                     open_n = 0;
                     row_of(b, u, acc);
                 } else if (fold == FF_FOLD_MEAN) {
@@ -304,7 +335,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
     };
 
     Batch<kDepth, kAdd> b0, b1;
-    int pos = t0 + __ffsll((long long)starts) - 1;
+    int pos = bs;
     issue(b0, pos);
     pos += b0.take;
     while (true) {
