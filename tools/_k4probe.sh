@@ -1,6 +1,7 @@
 #!/bin/bash
 # Kernel timing probes (development): rebuild ff_merge.o / ff_similarity.o with extra -D switches on the GPU box, in-step
-# timeline of bench.py each.
+# timeline of bench.py each.  The switches themselves (FF_K4_PROBE, FF_K1_PROBE, FF_K4_SLOTS, FF_K4_LOOK ...) are added to the
+# sources for one run and removed again: profiles/r03_k4_probes.txt and r03_k1_probes.txt say which ones were used.
 #   tools/_k4probe.sh <out_dir> "<EXTRA flags>" ["<EXTRA flags>" ...]
 out=$1; shift
 mkdir -p "$out"
