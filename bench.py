@@ -268,7 +268,7 @@ def stage_times(ff, _lib, hidden, hidden_alt, ptype, cos, sin, P, L, d, info, de
                                                       order_buf.data_ptr(), sc.member.data_ptr(), 1, sc.dst.data_ptr(),
                                                       sc.keep.data_ptr(), aux, 3, stream),
     }
-    reps = max(30, min(steps, 60))
+    reps = 60            # (~22 ms of the step's own kernels: the GPU has left its post-idle transient when the loop starts)
     names = list(stages)
     for name in names:
         _lib.check(stages[name](), name)
