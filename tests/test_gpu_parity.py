@@ -197,6 +197,49 @@ def test_merge_arbitrary_bit_patterns(dtype, seed):
     assert int(lens.max()) >= 9                                         # long runs are really in there
 
 
+@pytest.mark.parametrize("pattern", ["all_but_first", "alternating", "period_9_10_11", "period_20_21", "dense_0.95", "none",
+                                     "one_giant_run"])
+@pytest.mark.parametrize("F,P", [(200, 24), (64, 576)])
+def test_merge_run_patterns_across_stream_boundaries(pattern, F, P):
+    """The merge kernel cuts the by-patch order into streams at the non-member slot nearest to a multiple of its slot count
+    (csrc/ff_merge.hip `boundary`: look-back of up to 10 slots, else the first non-member at or after the nominal boundary,
+    a forward scan when the window holds none).  Member patterns that put runs of every length across those boundaries -
+    runs longer than a window, runs of about the look-back length, no members at all - must fold exactly like the oracle."""
+    d = 64
+    g = torch.Generator().manual_seed(F * 1000 + P)
+    h = (torch.randint(-8, 9, (1, F * P, d), generator=g).to(torch.float32) * 0.125).to(torch.bfloat16)     # dyadic grid: exact sums
+    order, _ = orc.by_patch_order(torch.arange(P).repeat(F)[None], P)
+    nv = F * P
+    f = torch.arange(nv) % F                                    # frame of a by-patch slot (slot = patch * F + frame)
+    if pattern == "all_but_first":
+        flags = f != 0
+    elif pattern == "alternating":
+        flags = (f % 2) == 1
+    elif pattern == "period_9_10_11":
+        flags = ((torch.arange(nv) % 31) != 0) & ((torch.arange(nv) % 31) != 10) & ((torch.arange(nv) % 31) != 21) & (f != 0)
+    elif pattern == "period_20_21":
+        flags = ((torch.arange(nv) % 43) != 0) & ((torch.arange(nv) % 43) != 21) & (f != 0)
+    elif pattern == "dense_0.95":
+        flags = (torch.rand(nv, generator=g) < 0.95) & (f != 0)
+    elif pattern == "none":
+        flags = torch.zeros(nv, dtype=torch.bool)
+    else:                                                       # every slot but the very first: one run over all patches
+        flags = torch.ones(nv, dtype=torch.bool)
+        flags[0] = False
+    midx = torch.nonzero(flags).reshape(-1)
+    stock = orc.run_lengths
+    orc.run_lengths = lambda fl: stock(fl.to(torch.long))       # exact integer run lengths (DESIGN.md section 6, deviation 2)
+    try:
+        want, keep_want = orc.merge_rows(h.clone(), order, midx)
+    finally:
+        orc.run_lengths = stock
+    sim = torch.zeros(1, nv, dtype=h.dtype)
+    got, keep = ffa.FrameFusion.merge_tokens_and_get_mask(dev(h.clone()), dev(sim), dev(order.reshape(1, -1)), dev(midx))
+    assert torch.equal(keep.cpu(), keep_want)
+    kept = keep_want[0]
+    assert same_bits(got[0].cpu()[kept], want[0][kept])
+
+
 # ---------------------------------------------------------------------------------------------
 # FrameFusion.forward
 # ---------------------------------------------------------------------------------------------
