@@ -29,7 +29,7 @@ STAT_ERROR = 11
 ERR_BIT_BARRIER, ERR_BIT_LAYOUT = 1, 2
 STAT_WORDS = 32
 MAX_AUX = 4
-ABI_VERSION = 7
+ABI_VERSION = 8
 ERR_DEVICE, ERR_STATE = -5, -6
 
 
@@ -139,6 +139,7 @@ PROTOTYPES = {
     "ff_ctx_reset": (_i32, [_vp, _vp]),
     "ff_ctx_expect_tables": (None, [_vp]),
     "ff_abi_sizeof": (_sz, [_i32]),
+    "ff_set_fused_launch": (_i32, [_i32]),
     "ff_merge_step": (_i32, [_vp, _vp, _vp, _i32, _i64, _i64, _i64, _vp, _i64, _i32, _f64, _f64, _f64, _vp, _vp, _vp, _vp,
                              _vp, _vp, _vp, _vp, _i64, C.POINTER(FFAux), _i32, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
 }
@@ -146,8 +147,18 @@ PROTOTYPES = {
 _lib = None
 
 
-HASHED_SOURCES = ("ff_abi.hip", "ff_order.hip", "ff_similarity.hip", "ff_plan.hip", "ff_merge.hip", "ff_importance.hip",
-                  "ff_layout.hip", "ff_common.h", "../../include/framefusion_hip.h", "Makefile")
+def hashed_sources():
+    """The files csrc/Makefile hashes into the library (its HASHED list: SRCS + HDRS + the public header + itself), read
+    from the Makefile so that the two lists cannot drift apart."""
+    import re
+    text = open(os.path.join(CSRC, "Makefile")).read().replace("\\\n", " ")
+    names = []
+    for var in ("SRCS", "HDRS"):
+        m = re.search(rf"^{var}\s*=\s*(.*)$", text, re.M)
+        if m is None:
+            raise FrameFusionHipError(f"csrc/Makefile has no {var} line")
+        names += m.group(1).split()
+    return tuple(names) + ("../../include/framefusion_hip.h", "Makefile")
 
 
 def source_hash() -> str:
@@ -156,10 +167,10 @@ def source_hash() -> str:
     import hashlib
     h = hashlib.sha256()
     try:
-        for name in sorted(HASHED_SOURCES):
+        for name in sorted(hashed_sources()):
             with open(os.path.join(CSRC, name), "rb") as f:
                 h.update(f.read())
-    except OSError:
+    except (OSError, FrameFusionHipError):
         return None
     return h.hexdigest()[:16]
 

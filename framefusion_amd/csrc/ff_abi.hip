@@ -27,6 +27,13 @@ int launch_merge_compact(const void* hidden, const void* addend, void* hidden_ou
 int launch_similarity_any(const void* hidden, const void* addend, int dtype, int64_t L, int64_t d, const int64_t* ptype,
                           int32_t* order, int32_t* inv, int64_t* stats, void* sim, int* l0, int* t16_end, double thr,
                           int64_t hint_pre, int64_t hint_patches, int64_t hint_frames, hipStream_t st);
+bool fused_applies(int dtype, int64_t L, const int32_t* inv, const int32_t* order, const int64_t* stats);
+void fused_disable();
+int launch_plan_merge_fused(const void* sim, int dtype, const int32_t* order, const int32_t* inv, int64_t L, double thr, double sub,
+                            double ratio_lb, long long force_k, uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
+                            void* ws, size_t ws_bytes, int64_t* host_mapped, int64_t seq, const void* hidden, const void* addend,
+                            void* hidden_out, int64_t d, int64_t L_cap, int fold, const ff_aux_t* aux_host, int n_aux,
+                            int32_t* order_next, int32_t* inv_next, void* zero_a, size_t zero_a_bytes, hipStream_t st);
 int launch_head_mean(const void* attn_w, int dtype, int64_t H, int64_t num, int64_t S, void* importance,
                      int64_t lo, int64_t hi, int* l0, int* t16_end, hipStream_t st);
 }  // namespace ff
@@ -91,7 +98,7 @@ static int merge_finish(const void* hidden, const void* addend, void* hidden_out
                         const int32_t* order, const int32_t* inv, const void* sim, uint8_t* member, int32_t* dst,
                         uint8_t* keep, int64_t* stats, int64_t* stats_host_mapped, int64_t seq, const ff_aux_t* aux_host,
                         int n_aux, int32_t* order_next, int32_t* inv_next, void* ws, size_t ws_bytes,
-                        ff_stream_t stream) {
+                        ff_stream_t stream, bool allow_fused = false) {
     if (!hidden || !hidden_out || !order || !inv || !sim || !member || !dst || !keep || !stats || !ws) return FF_ERR_ARG;
     if ((order_next == nullptr) != (inv_next == nullptr)) return FF_ERR_ARG;
     if (ws_bytes < ff_workspace_bytes(L, 1)) return FF_ERR_WORKSPACE;
@@ -105,14 +112,20 @@ static int merge_finish(const void* hidden, const void* addend, void* hidden_out
     if (((uintptr_t)member & 7) || ((uintptr_t)dst & 15) || ((uintptr_t)keep & 15) || ((uintptr_t)order & 15) ||
         ((uintptr_t)sim & 15) || ((uintptr_t)ws & 15) || ((uintptr_t)inv & 15))
         return FF_ERR_ALIGN;
-    int rc = ff::launch_plan_merge(sim, dtype, order, inv, L, threshold, sub, ratio_lb, member, dst, keep, stats, ws, ws_bytes,
-                                   true, stats_host_mapped, seq, (hipStream_t)stream, force_k);
-    if (rc) return rc;
     // when the select folds nothing the merge kernel exits at once: see ff_merge_finish in the header;
     // its extra workgroups clear the select tables for the next call either way
     void *za, *zb;
     size_t zab, zbb;
     ff::table_regions(ws, ws_bytes, L, &za, &zab, &zb, &zbb);
+    // one launch for plan + merge (ff_fused.hip) where it applies: 16-bit activations, <= 65 536 tokens, a call context
+    // (its sequence numbers strictly increase, which the hand-over flag relies on)
+    if (allow_fused && order_next && ff::fused_applies(dtype, L, inv, order, stats))
+        return ff::launch_plan_merge_fused(sim, dtype, order, inv, L, threshold, sub, ratio_lb, force_k, member, dst, keep, stats, ws,
+                                           ws_bytes, stats_host_mapped, seq, hidden, addend, hidden_out, d, L_cap, fold, aux_host,
+                                           n_aux, order_next, inv_next, za, zab, (hipStream_t)stream);
+    int rc = ff::launch_plan_merge(sim, dtype, order, inv, L, threshold, sub, ratio_lb, member, dst, keep, stats, ws, ws_bytes,
+                                   true, stats_host_mapped, seq, (hipStream_t)stream, force_k);
+    if (rc) return rc;
     return ff::launch_merge_compact(hidden, addend, hidden_out, dtype, L, d, L_cap, order, member, fold, dst, keep, aux_host,
                                     n_aux, order_next, inv_next, stats, (hipStream_t)stream, true, za, zab, sim, L, dtype,
                                     ff::ws_t16_end(ws, ws_bytes));
@@ -303,7 +316,7 @@ static int ctx_finish_enqueue(ff_ctx_t* c, const ff_merge_call_t* a) {
     int rc = merge_finish(a->hidden, a->addend, a->hidden_out, (int)a->dtype, a->L, a->d, a->L_cap, a->threshold, a->sub,
                           a->ratio_lb, a->force_k < 0 ? -1 : (long long)a->force_k, (int)a->fold, c->order, c->inv, c->sim,
                           c->member, c->dst, c->keep, c->stats, c->stats_host, c->seq, a->aux, (int)a->n_aux, c->order_next,
-                          c->inv_next, c->ws, c->ws_bytes, a->stream);
+                          c->inv_next, c->ws, c->ws_bytes, a->stream, true);
     if (rc) return rc;
     c->dirty = 0;
     if (a->mask)
@@ -342,7 +355,12 @@ extern "C" int ff_ctx_merge_finish(ff_ctx_t* c, const ff_merge_call_t* a, ff_mer
             r->unhinted = 1;
             continue;
         }
-        if (err) { c->dirty = 1; c->order_len = 0; return FF_ERR_DEVICE; }
+        if (err) {
+            // a workgroup of the fused plan + merge launch waited in vain (this call's or the previous one's): three launches from now on
+            if (err & FF_ERR_BIT_BARRIER) ff::fused_disable();
+            c->dirty = 1; c->order_len = 0;
+            return FF_ERR_DEVICE;
+        }
         r->nv = h[FF_STAT_NV];
         r->ftn = h[FF_STAT_FTN];
         r->count = h[FF_STAT_COUNT];

@@ -19,80 +19,9 @@
 #include <atomic>
 
 #include "ff_common.h"
+#include "ff_merge_body.h"
 
 namespace ff {
-
-constexpr int kMergeThreads = 256;
-constexpr int kMergeWaves = kMergeThreads / kWave;
-
-
-struct AuxPack {
-    ff_aux_t a[FF_MAX_AUX];
-    int n;
-};
-
-// Copy `bytes` (multiple of 2) from src to dst with the widest unit the alignment allows,
-// spread over the threads [tid, nthreads).
-__device__ inline void copy_row(const char* __restrict__ src, char* __restrict__ dst, int64_t bytes,
-                                int tid, int nthreads) {
-    const uintptr_t al = (uintptr_t)src | (uintptr_t)dst | (uintptr_t)bytes;
-    if ((al & 15) == 0) {
-        for (int64_t o = (int64_t)tid * 16; o < bytes; o += (int64_t)nthreads * 16)
-            *(uint4*)(dst + o) = *(const uint4*)(src + o);
-    } else if ((al & 7) == 0) {
-        for (int64_t o = (int64_t)tid * 8; o < bytes; o += (int64_t)nthreads * 8)
-            *(uint2*)(dst + o) = *(const uint2*)(src + o);
-    } else if ((al & 3) == 0) {
-        for (int64_t o = (int64_t)tid * 4; o < bytes; o += (int64_t)nthreads * 4)
-            *(uint32_t*)(dst + o) = *(const uint32_t*)(src + o);
-    } else {
-        for (int64_t o = (int64_t)tid * 2; o < bytes; o += (int64_t)nthreads * 2)
-            *(uint16_t*)(dst + o) = *(const uint16_t*)(src + o);
-    }
-}
-
-// Waves are independent (no LDS, no barrier): the 4 waves of a workgroup own the same `slots`
-// consecutive by-patch slots and one 1 KiB column tile each (16 bytes per lane), so a workgroup
-// reads 4 KiB of a row at a time.  A wave treats its job as a STREAM of rows in by-patch order:
-// it runs from boundary(t0) to boundary(t0 + slots) (see `boundary` in the kernel: the nearest non-member
-// slot); a non-member row opens a new output row, a member row is folded into the open one.
-// One coalesced load of order[] / member[] for 64 slots tells the wave the whole stream, so the
-// row pieces are requested kDepth at a time, the next batch being issued BEFORE the current one
-// is folded (two register batches), with no dependent index fetch in between (dst[] is only
-// needed by the stores).  The additions stay sequential - a rounding after each - but the loads
-// do not wait for them.  Row pieces move as raw buffer loads/stores (lanes past the row end read
-// 0 / are dropped).
-template <int kDepth, bool kAdd>
-struct Batch {
-    uint4 buf[kDepth];
-    uint4 buf2[kAdd ? kDepth : 1];   // the addend's pieces (kAdd: rows are T(hidden + addend))
-    int idx[kDepth];       // sequence index of each row (wave-uniform)
-    int pos, take;
-    unsigned mem_bits;
-    bool last;
-};
-
-// Select tables to clear for the next call (ff_plan.hip).  The level-0 table (a few KB) is cleared as a
-// byte range; the per-slice level-1 tables are megabytes of which a few hundred bins are non-zero, so
-// they are cleared BY KEY: every value that was counted names its bin (streaming zeros over the whole
-// table inside this kernel cost 8 us at 64 x 576 - measured).
-struct ZeroJob {
-    uint4* a;                 // level-0 table
-    int a_n16;
-    const void* keys;         // the values the producer counted (n of them, dtype key_dt), or NULL
-    int n, key_dt;
-    int* t16_end;
-    int n_blocks;
-};
-
-template <int KDT>
-__device__ inline void zero_by_key(const ZeroJob& z, int t) {
-    using K = Act<KDT>;
-    const uint32_t bin = t16_bin(order_key<KDT>(K::bits1(z.keys, t)) >> (K::kKeyBits - 16));
-    int* tab = t16_slice(z.t16_end, t / kSelSlice) + bin;
-#pragma unroll
-    for (int x = 0; x < kT16Copies; ++x) tab[x * 65536] = 0;
-}
 
 template <int DT, bool kAdd>
 __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
@@ -101,252 +30,9 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
     const int32_t* __restrict__ dst, const uint8_t* __restrict__ keep, AuxPack aux, int n_main,
     int n_aux_blocks, int n_next_blocks, int32_t* __restrict__ order_next, int32_t* __restrict__ inv_next,
     int64_t* __restrict__ stats, const int64_t* __restrict__ identity_stats, ZeroJob zero, int slots) {
-    using A = Act<DT>;
-    constexpr int E = A::kPer16;
-    constexpr int kDepth = 4;                     // row pieces requested per batch (two batches in flight)
-    const int lane = lane_id();
-    if ((int)blockIdx.x >= n_main + n_aux_blocks + n_next_blocks) {
-        // ---- the select tables of this call have been consumed by the plan kernel: clear them for the
-        // next call's producer (runs even when nothing is folded)
-        if (blockIdx.y != 0) return;
-        const int zb = (int)blockIdx.x - n_main - n_aux_blocks - n_next_blocks;
-        if (zb == 0)
-            for (int z = threadIdx.x; z < zero.a_n16; z += kMergeThreads) zero.a[z] = make_uint4(0, 0, 0, 0);
-        if (zero.keys) {
-            const int t0 = (zb * kMergeThreads + threadIdx.x) * 16;
-            for (int t = t0; t < min(t0 + 16, zero.n); ++t) {
-                if (zero.key_dt == FF_BF16) zero_by_key<FF_BF16>(zero, t);
-                else if (zero.key_dt == FF_F16) zero_by_key<FF_F16>(zero, t);
-                else zero_by_key<FF_F32>(zero, t);
-            }
-        }
-        return;
-    }
-    // nothing folded (a merge call whose threshold set is empty, main.py:264-266): the reduced
-    // sequence IS the input, the caller keeps using its own tensors and this launch writes nothing
-    if (identity_stats && identity_stats[FF_STAT_MERGED] == 0) return;
-    if ((int)blockIdx.x >= n_main + n_aux_blocks) {
-        // ---- by-patch order of the COMPACTED sequence, for the next merge call (order maintenance):
-        // the surviving slots keep their relative by-patch order and dst[] is monotonic in the
-        // sequence position, so new_order = dst[order[t]] compacted over the non-member slots.
-        // Same communication-free scan as k_scan: this workgroup recounts the slots before its own.
-        if (blockIdx.y != 0) return;
-        __shared__ int scratch[kMergeWaves + 1];
-        const int tid = threadIdx.x;
-        const int base = ((int)blockIdx.x - n_main - n_aux_blocks) * (kMergeThreads * 16);
-        int before = 0;
-        for (int off = tid * 16; off < base; off += kMergeThreads * 16) {
-            const uint4 m4 = *(const uint4*)(member + off);
-            before += 16 - (__popc(m4.x) + __popc(m4.y) + __popc(m4.z) + __popc(m4.w));
-        }
-        before = block_sum_i<kMergeWaves>(before, scratch);
-        const int s0 = base + tid * 16;
-        const int n_here = min(max(L - s0, 0), 16);
-        unsigned nonmem = 0;
-        for (int e = 0; e < n_here; ++e) nonmem |= (member[s0 + e] ? 0u : 1u) << e;
-        int total;
-        int pos = before + block_excl_scan<kMergeWaves>(__popc(nonmem), scratch, total);
-        for (int e = 0; e < n_here; ++e) {
-            if ((nonmem >> e) & 1u) {
-                const int np = dst[order[s0 + e]];      // the slot's position in the compacted sequence
-                order_next[pos] = np;
-                if (inv_next) inv_next[np] = pos;
-                ++pos;
-            }
-        }
-        if (base + kMergeThreads * 16 >= L && tid == 0) {
-            const int64_t merged = stats[FF_STAT_MERGED];
-            stats[FF_STAT_NV] -= merged;        // the next call (order_valid) skips K0, which would set these
-            stats[FF_STAT_FTN] -= merged;
-        }
-        return;
-    }
-    if ((int)blockIdx.x >= n_main) {
-        // ---- auxiliary rows (position embeddings, patch types, position ids): plain compaction by
-        // SEQUENCE position - reads coalesced, writes in increasing order.  Only blockIdx.y == 0.
-        if (blockIdx.y != 0) return;
-        const int i = ((int)blockIdx.x - n_main) * kMergeWaves * 4 + wave_id() * 4 + (lane >> 4);
-        const int sub = lane & 15;                       // 16 lanes per row
-        if (i >= L || !keep[i]) return;
-        const int r = dst[i];
-        for (int x = 0; x < aux.n; ++x) {
-            const ff_aux_t& ax = aux.a[x];
-            for (int64_t ou = 0; ou < ax.outer; ++ou)
-                copy_row((const char*)ax.src + (ou * L + i) * ax.row_bytes,
-                         (char*)ax.dst + (ou * L_cap + r) * ax.row_bytes, ax.row_bytes, sub, 16);
-        }
-        return;
-    }
-    // slot groups are walked from the END of the by-patch order: the similarity pass read the rows
-    // in ascending order, so its most recently fetched rows - the ones the 256 MiB Infinity Cache
-    // still holds - are the first ones this pass asks for
-    const int t0 = (n_main - 1 - (int)blockIdx.x) * slots;
-    const int cb = uniform(blockIdx.y * kMergeWaves + wave_id());     // 1 KiB column tile
-    const uint32_t col = (uint32_t)cb * 1024u;
-    if (col >= row_bytes) return;
-    const uint32_t blk_bytes = min(1024u, row_bytes - col);
-    const uint32_t voff = (uint32_t)lane * 16;
-    const int t_end = min(t0 + slots, L);
-
-    // window of 64 slots: row indices and member flags, starting `look` slots BEFORE the nominal range
-    const int look = min(10, (kWave - slots) / 2);          // slots <= 53 (merge_slots): look >= 5
-    const int win0 = t0 - look;
-    int win = win0;
-    const int sl = win0 + lane;
-    const bool sl_ok = sl >= 0 && sl < L;
-    int ordw = sl_ok ? (order ? order[sl] : sl) : 0;
-    const bool sl_mem = sl_ok ? (member[sl] != 0) : false;
-    unsigned long long memw = __ballot(sl_mem);
-    const unsigned long long nonmem = __ballot(sl_ok && !sl_mem);
-
-    // The stream of this wave is [bs, be): a run cannot be split between waves (the rounding after every add makes the fold
-    // sequential), so the boundary between two slot groups moves to a non-member slot - the NEAREST one within `look` slots
-    // before the nominal boundary x, else the first one at or after x (the rule until round 3, which made the longest
-    // stream of the headline call 68 slots for a mean of 37; nearest: 53, profiles/r03_k4_probes.txt).  boundary(x) only
-    // reads the flags of [x - look, ...): both neighbours of a boundary compute the same slot.
-    auto first_nonmember_from = [&](int s0) {               // rare: no non-member left in the window
-        for (int s = s0; s < L; s += kWave) {
-            const unsigned long long b = __ballot(s + lane < L && member[s + lane] == 0);
-            if (b) return s + (int)__ffsll((long long)b) - 1;
-        }
-        return L;
-    };
-    auto boundary = [&](int x) {                            // x in [t0, t_end]: inside the window
-        if (x >= L) return L;
-        const int xr = x - win0;
-        const unsigned long long above = nonmem >> xr;
-        const int fwd = above ? x + (int)__ffsll((long long)above) - 1 : first_nonmember_from(win0 + kWave);
-        unsigned long long below = nonmem & ((1ull << xr) - 1ull);
-        if (xr > look) below &= ~((1ull << (xr - look)) - 1ull);
-        if (below) {
-            const int bwd = win0 + 63 - (int)__builtin_clzll(below);
-            if (x - bwd < fwd - x) return bwd;
-        }
-        return fwd;
-    };
-    const int bs = boundary(t0), be = boundary(t_end);
-    if (bs >= be) return;                                   // the whole nominal range belongs to a neighbour's stream
-    // output rows of my anchors: non-members of [bs, be), all inside the first window (bs < t_end <= win0 + 64 - look, and
-    // everything from t_end to be is a member)
-    const bool anchor_lane = sl_ok && !sl_mem && sl >= bs && sl < be;
-    const int dv = anchor_lane ? dst[ordw] : 0;
-
-    auto piece = [&](int i) { return make_rsrc(hidden + (int64_t)i * row_bytes + col, blk_bytes); };
-    auto piece2 = [&](int i) { return make_rsrc((kAdd ? addend : hidden) + (int64_t)i * row_bytes + col, blk_bytes); };
-
-    // request the next (up to) kDepth rows of the stream
-    auto issue = [&](Batch<kDepth, kAdd>& b, int pos) {
-        if (pos - win > kWave - kDepth) {                   // keep kDepth slots of lookahead in the window
-            win = pos;
-            ordw = (pos + lane < L) ? (order ? order[pos + lane] : pos + lane) : 0;
-            memw = __ballot((pos + lane < L) ? (member[pos + lane] != 0) : false);
-        }
-        const int rel = pos - win;
-        int take = 0;
-        unsigned mem_bits = 0;
-#pragma unroll
-        for (int u = 0; u < kDepth; ++u) {
-            const int s = pos + u;
-            const bool is_mem = (memw >> (rel + u)) & 1ull;
-            const bool in = take == u && s < be;
-            if (in) { ++take; mem_bits |= is_mem ? (1u << u) : 0u; }
-            b.idx[u] = __builtin_amdgcn_readlane(ordw, rel + u);
-        }
-        b.pos = pos; b.take = take; b.mem_bits = mem_bits; b.last = take < kDepth;
-#pragma unroll
-        for (int u = 0; u < kDepth; ++u) {
-            const bool is_mem = (mem_bits >> u) & 1u;
-            if (u < take && (fold || !is_mem)) {
-                b.buf[u] = buf_load16<2>(piece(b.idx[u]), voff);
-                if constexpr (kAdd) b.buf2[u] = buf_load16<2>(piece2(b.idx[u]), voff);
-            }
-        }
-    };
-
-    float acc[E];
-    int open_r = -1, open_n = 0;                            // the output row being accumulated
-    auto flush = [&]() {
-        float o[E];
-        if (open_n > 0 && fold == FF_FOLD_MEAN) {
-            // torch .mean(dim=1): fp32 sum (which starts from +0, so an all -0 column gives +0) / N, one rounding
-            const float div = (float)(open_n + 1);
-#pragma unroll
-            for (int e = 0; e < E; ++e) o[e] = A::rnd((acc[e] + 0.0f) / div);
-        } else if (open_n > 0) {
-            const float div = A::rnd((float)(open_n + 1));
-            if constexpr (DT == FF_BF16) {
-                // bf16 only: T(a / div) == T(a * RN(1 / div)) for EVERY bf16-valued a (acc is one: it is rounded after each
-                // add) and every divisor T(k) - a quotient of two 8-bit significands is never closer than 2^-17 (relative)
-                // to a bf16 rounding boundary and never on one, the product is within 2^-23 of it; checked exhaustively
-                // (65 536 values x the 1 288 divisors up to T(70 000)) by tests/test_host_logic.py.  One IEEE reciprocal
-                // per flush instead of eight IEEE divisions; fp16 fails the same check (11-bit significands) and keeps
-                // the division, like fp32.
-                const float r = 1.0f / div;
-#pragma unroll
-                for (int e = 0; e < E; ++e) o[e] = acc[e] * r;
-                buf_store16<2>(make_rsrc(out + (int64_t)open_r * row_bytes + col, blk_bytes), voff, A::pack_rne(o));
-                return;
-            } else {
-#pragma unroll
-                for (int e = 0; e < E; ++e) o[e] = A::rnd(acc[e] / div);
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < E; ++e) o[e] = acc[e];
-        }
-        buf_store16<2>(make_rsrc(out + (int64_t)open_r * row_bytes + col, blk_bytes), voff, A::pack(o));
-    };
-    auto row_of = [&](const Batch<kDepth, kAdd>& b, int u, float* f) {          // the (summed) row piece as T-valued floats
-        if constexpr (kAdd) {
-            float y[E];
-            A::unpack(b.buf[u], f);
-            A::unpack(b.buf2[u], y);
-#pragma unroll
-            for (int e = 0; e < E; ++e) f[e] = A::rnd(f[e] + y[e]);
-        } else {
-            A::unpack(b.buf[u], f);
-        }
-    };
-    auto fold_batch = [&](Batch<kDepth, kAdd>& b) {
-#pragma unroll
-        for (int u = 0; u < kDepth; ++u) {
-            if (u < b.take) {
-                const bool is_mem = (b.mem_bits >> u) & 1u;
-                if (!is_mem) {
-                    if (open_r >= 0) flush();
-                    open_r = __builtin_amdgcn_readlane(dv, b.pos + u - win0);
-                    open_n = 0;
-                    row_of(b, u, acc);
-                } else if (fold == FF_FOLD_MEAN) {
-                    float x[E];
-                    row_of(b, u, x);
-#pragma unroll
-                    for (int e = 0; e < E; ++e) acc[e] = acc[e] + x[e];
-                    ++open_n;
-                } else if (fold) {
-                    float x[E];
-                    row_of(b, u, x);
-#pragma unroll
-                    for (int e = 0; e < E; ++e) acc[e] = A::rnd(acc[e] + x[e]);
-                    ++open_n;
-                }
-            }
-        }
-    };
-
-    Batch<kDepth, kAdd> b0, b1;
-    int pos = bs;
-    issue(b0, pos);
-    pos += b0.take;
-    while (true) {
-        if (!b0.last) { issue(b1, pos); pos += b1.take; }
-        fold_batch(b0);
-        if (b0.last) break;
-        if (!b1.last) { issue(b0, pos); pos += b0.take; }
-        fold_batch(b1);
-        if (b1.last) break;
-    }
-    if (open_r >= 0) flush();
+    merge_compact_body<DT, kAdd, false>(hidden, addend, out, row_bytes, L, L_cap, order, member, fold, dst, keep, aux, n_main,
+                                        n_aux_blocks, n_next_blocks, order_next, inv_next, stats, identity_stats, zero, slots,
+                                        (int)blockIdx.x, (int)blockIdx.y, FusedWait{nullptr, 0ull, nullptr, 0, nullptr});
 }
 
 // ---- square attention-mask gather (main.py:137-138, 99-100): out[r, c] = mask[src[r], src[c]] ----------------
@@ -443,13 +129,8 @@ static int merge_places() {
     if (dev >= 0 && dev < kMaxDevices) cache[dev].store(places, std::memory_order_relaxed);
     return places;
 }
-static int merge_slots(int dtype, bool add, int64_t L, int ny) {
-    int places;
-    switch (dtype) {
-        case FF_F32: places = add ? merge_places<FF_F32, true>() : merge_places<FF_F32, false>(); break;
-        case FF_BF16: places = add ? merge_places<FF_BF16, true>() : merge_places<FF_BF16, false>(); break;
-        default: places = add ? merge_places<FF_F16, true>() : merge_places<FF_F16, false>();
-    }
+// (`places`: workgroups of the launching kernel the device holds at once, less whatever else must fit next to them)
+int merge_slots_for(int places, int64_t L, int ny) {
     static const int primes[] = {17, 19, 23, 29, 31, 37, 41, 43, 47, 53};
     const double want = (double)L * ny / (0.975 * (double)places);
     for (int p : primes)
@@ -466,6 +147,15 @@ static int merge_slots(int dtype, bool add, int64_t L, int ny) {
                     break;
                 }
     return 7;
+}
+static int merge_slots(int dtype, bool add, int64_t L, int ny) {
+    int places;
+    switch (dtype) {
+        case FF_F32: places = add ? merge_places<FF_F32, true>() : merge_places<FF_F32, false>(); break;
+        case FF_BF16: places = add ? merge_places<FF_BF16, true>() : merge_places<FF_BF16, false>(); break;
+        default: places = add ? merge_places<FF_F16, true>() : merge_places<FF_F16, false>();
+    }
+    return merge_slots_for(places, L, ny);
 }
 
 int launch_merge_compact(const void* hidden, const void* addend, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,

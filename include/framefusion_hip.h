@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FF_ABI_VERSION 7
+#define FF_ABI_VERSION 8
 
 enum { FF_F32 = 0, FF_BF16 = 1, FF_F16 = 2 };
 
@@ -464,6 +464,13 @@ int ff_ctx_reset(ff_ctx_t* ctx, ff_stream_t stream);
  * filled) - ff_last_query_attention with sel_ws = ctx->ws: if the matching ff_ctx_prune never comes,
  * the next call resets the workspace. */
 void ff_ctx_expect_tables(ff_ctx_t* ctx);
+
+/* How ff_ctx_merge_finish enqueues plan + K4: 1 (default; FF_FUSED=0 in the environment makes it 0) = ONE launch
+ * whose merge workgroups are dispatched while the plan runs and wait for its flag (16-bit activations, <= 65 536
+ * tokens; csrc/ff_fused.hip), 0 = two launches.  Same results either way.  Process-wide; returns the previous
+ * value (on < 0: only reports).  The library switches to 0 by itself if a waiting workgroup ever times out
+ * (FF_ERR_BIT_BARRIER). */
+int ff_set_fused_launch(int on);
 
 /* sizeof() of the structures above as THIS library was compiled (0: ff_ctx_t, 1: ff_merge_call_t,
  * 2: ff_merge_result_t, 3: ff_prune_call_t, 4: ff_aux_t), so a binding can verify its own layout. */

@@ -45,9 +45,10 @@ def main():
     t_max, mine, out = dp.timed_steps(dist, step, cfg["steps"], cfg["warmup"], dev)
     recs = dp.gather_records(dist, (L, out.shape[1], mine * 1e3 / cfg["steps"], cfg["seed"]), dev)
     t_all, units = dp.aggregate(dist, mine, float((L - out.shape[1]) * cfg["steps"]), dev)
+    ids = dp.gather_identities(dist, dev)
     if rank == 0:
         print(json.dumps(dict(n_gpus=world, ranks=dist.get_world_size() if dist else 1, records=recs, t_max=t_max,
-                              t_all=t_all, units=units, seed=cfg["seed"], steps=cfg["steps"])))
+                              t_all=t_all, units=units, seed=cfg["seed"], steps=cfg["steps"], identities=ids)))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -14,11 +14,19 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_worker(*argv, env_extra=None):
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+def run_worker(*argv, env_extra=None, env_drop=(), direct=False):
+    """`direct`: start the two ranks with an external torch.distributed.run (what the driver does), so that dp.launch_ranks -
+    which would fill HSA_ENABLE_IPC_MODE_LEGACY in - is not involved."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT") + tuple(env_drop)}
     env.update(env_extra or {})
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), *argv], capture_output=True,
-                         text=True, timeout=240, env=env, cwd=ROOT)
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), *argv]
+    if direct:
+        from framefusion_amd import dp
+        n = argv[argv.index("--gpus") + 1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+               "--master-port", str(dp.free_port())] + cmd[1:]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout           # rank 0 prints ONE JSON line
@@ -40,6 +48,27 @@ def test_self_launched_two_ranks_over_gloo():
 
 
 @pytest.mark.timeout(300)
+@pytest.mark.timeout(300)
+def test_ranks_fall_back_to_the_other_ipc_mode_when_the_first_collective_fails():
+    """dp.init: a failure of the join / first collective on the first attempt makes every rank re-execute itself with
+    HSA_ENABLE_IPC_MODE_LEGACY flipped and join again under a fresh store prefix - here over gloo, under the same
+    torch.distributed.run the product starts, with the failure injected."""
+    out = run_worker("--gpus", "2", "--steps", "2", "--warmup", "1", "--seed", "100",
+                     env_extra={"FF_DP_FAIL_FIRST_ATTEMPT": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert out["n_gpus"] == 2 and out["ranks"] == 2 and len(out["records"]) == 2
+    ids = out["identities"]
+    assert [i["attempt"] for i in ids] == [1, 1] and all(i["ipc_mode"].endswith("unset") for i in ids)
+    assert len({i["pid"] for i in ids}) == 2
+    # ... and vice versa: a job that starts without the variable retries with it
+    out = run_worker("--gpus", "2", "--steps", "2", "--warmup", "1", env_extra={"FF_DP_FAIL_FIRST_ATTEMPT": "1"},
+                     env_drop=("HSA_ENABLE_IPC_MODE_LEGACY",), direct=True)
+    assert [i["attempt"] for i in out["identities"]] == [1, 1]
+    assert all(i["ipc_mode"] == "HSA_ENABLE_IPC_MODE_LEGACY=0" for i in out["identities"])
+    # no failure: first attempt, the environment's mode untouched
+    out = run_worker("--gpus", "2", "--steps", "2", "--warmup", "1", env_extra={"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert [i["attempt"] for i in out["identities"]] == [0, 0]
+
+
 def test_single_rank_does_not_launch():
     out = run_worker("--gpus", "1", "--steps", "2", "--warmup", "0")
     assert out["n_gpus"] == 1 and out["ranks"] == 1 and len(out["records"]) == 1
@@ -77,6 +106,8 @@ def test_nccl_init_plumbing_without_a_gpu(monkeypatch):
     calls = []
     monkeypatch.setattr(dist, "is_initialized", lambda: False)
     monkeypatch.setattr(dist, "init_process_group", lambda backend, **kw: calls.append((backend, kw)))
+    monkeypatch.setattr(dp, "_probe", lambda *a: None)           # (the first collective: nothing to run it on here)
+    monkeypatch.setenv("FF_DP_NO_RETRY", "1")
     for k in ("MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY"):
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setenv("WORLD_SIZE", "2")
@@ -85,7 +116,8 @@ def test_nccl_init_plumbing_without_a_gpu(monkeypatch):
     dev = torch.device("cuda", 1)
     assert dp.init("nccl", dev) is dist
     assert calls == [("nccl", {"device_id": dev})]                           # world / rank come from the launcher's env
-    assert os.environ["MASTER_ADDR"] == "127.0.0.1" and os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert os.environ["MASTER_ADDR"] == "127.0.0.1"
+    assert "HSA_ENABLE_IPC_MODE_LEGACY" not in os.environ       # init() reports the IPC mode, it does not set it
     calls.clear()
     assert dp.init("gloo", dev) is dist and calls == [("gloo", {})]          # gloo: no device binding
     calls.clear()
