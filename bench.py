@@ -65,7 +65,8 @@ def parse():
                          "LLaVA-Video model's shape, 64 frames prefilled dense / with this build / with the torch port of the reference "
                          "(7b adds ~1 min, 72b ~3 min and 150 GB of HBM)")
     ap.add_argument("--cpu-calls", type=int, default=12,
-                    help="merge calls of the CPU oracle timed for cpu_baseline (~0.9 s each on the GPU box's host: ~11 s)")
+                    help="at most this many merge calls of the CPU oracle are timed for cpu_baseline, at the fastest thread count of "
+                         "a short sweep (capped to ~6 s of CPU work)")
     return ap.parse_args()
 
 
@@ -144,7 +145,8 @@ def main():
     info = ff.last_call
     # whole-job numbers: tokens summed over ranks; one record per rank all_gathered for the report
     _, tok_all = dp.aggregate(dist, elapsed, float(reduced * args.steps), dev)
-    per_rank = dp.gather_records(dist, (rank, dev.index, L, L_out, elapsed / args.steps * 1e3), dev)
+    per_rank = dp.gather_records(dist, (rank, dev.index, L, L_out, elapsed / args.steps * 1e3, dp.sample_seed(args.seed, rank)), dev)
+    who = dp.gather_identities(dist, dev)          # hostname / pid / PCI address of every rank's GPU: N ranks = N distinct devices?
 
     result = None
     if rank == 0:
@@ -161,8 +163,11 @@ def main():
             "n_gpus": world,
             "rccl_ranks": dist.get_world_size() if dist is not None else 1,
             "collective_backend": (dist.get_backend() if dist is not None else None),
+            "ipc_mode": dp.ipc_mode(), "dp_attempt": dp.attempt(),
+            "distinct_devices": len({(w.get("hostname"), w.get("pci_bus_id")) for w in who}),
             "per_rank": [{"rank": int(r[0]), "gpu": int(r[1]), "tokens_in": int(r[2]), "tokens_out": int(r[3]),
-                          "ms_per_step": r[4]} for r in per_rank],
+                          "ms_per_step": r[4], "seed": int(r[5]), "hostname": w.get("hostname"), "pid": w.get("pid"),
+                          "pci_bus_id": w.get("pci_bus_id")} for r, w in zip(per_rank, who)],
             "steps": args.steps,
             "warmup": args.warmup,
             "before_the_loop": "1 priming step + per-kernel stage timing (the roofline figure), no idle gap before the warm-up steps",
@@ -676,7 +681,6 @@ def baselines(hidden, ptype, cos, sin, P, L, L_out, calls, hip_ms):
     reference costs through PyTorch-ROCm eager (~450 aten dispatches, 17 host syncs per call)."""
     from oracle import ff_oracle as orc
     h, pt, c, s = hidden.cpu(), ptype.cpu(), cos.cpu(), sin.cpu()
-    threads = torch.get_num_threads()
 
     def one(hh, pp, cc, ss):
         f = orc.OracleFrameFusion(COST, THRESHOLD, RATIO_LB)
@@ -684,14 +688,30 @@ def baselines(hidden, ptype, cos, sin, P, L, L_out, calls, hip_ms):
         o, _, _ = f.forward(hh, [cc, ss], None)
         return o.shape[1]
 
-    one(h, pt, c, s)
+    # The index-heavy torch-CPU path does not scale with threads (SURVEY.md §6 measured 0.42-0.50 s per call on 8 threads;
+    # 128 threads took 0.8-1.4 s on the GPU boxes): the baseline is the CPU's BEST, so sweep the thread count - one warm-up
+    # call and one timed call each - and time `calls` calls at the fastest setting.
+    all_threads = torch.get_num_threads()
+    sweep = {}
+    for n_thr in sorted({t for t in (8, 16, 32, all_threads) if 1 <= t <= max(all_threads, 8)}):
+        torch.set_num_threads(n_thr)
+        one(h, pt, c, s)
+        t0 = time.perf_counter()
+        one(h, pt, c, s)
+        sweep[n_thr] = time.perf_counter() - t0
+    threads = min(sweep, key=sweep.get)
+    torch.set_num_threads(threads)
+    calls = max(1, min(calls, int(6.0 / sweep[threads]) or 1))          # ~6 s at the best setting
     t0 = time.perf_counter()
     for _ in range(calls):
         lo = one(h, pt, c, s)
     dt = time.perf_counter() - t0
+    torch.set_num_threads(all_threads)
     cpu = {"value": (L - lo) * calls / dt, "unit": "tokens/s", "cores": threads, "kind": "port",
-           "sample": f"{calls} merge calls of the CPU oracle on the same [1, {L}, {hidden.shape[2]}] bf16 sample "
-                     f"({dt / calls * 1e3:.0f} ms per call, torch {torch.__version__} CPU, {os.cpu_count()} logical cores)"}
+           "thread_sweep_ms_per_call": {str(k): round(v * 1e3, 1) for k, v in sweep.items()},
+           "sample": f"{calls} merge calls of the CPU oracle on the same [1, {L}, {hidden.shape[2]}] bf16 sample at the fastest "
+                     f"of {sorted(sweep)} torch threads = {threads} ({dt / calls * 1e3:.0f} ms per call, torch {torch.__version__} "
+                     f"CPU, {os.cpu_count()} logical cores)"}
     n = 5
     for _ in range(2):
         one(hidden, ptype, cos, sin)

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_num_sgpr(80)))
         }
         plan_fast_body<DT, kRowSlicesLds, kFusedThreads>(pa.values, pa.cap, pa.pp, pa.l0, pa.t16_end, pa.stats, pa.inv, pa.L,
                                                          pa.member, pa.keep, pa.dst, pa.agg, pa.tagword, pa.host_mapped, pa.seq,
-                                                         lds_raw, b, pa.n_plan);
+                                                         lds_raw, b, pa.n_plan, pa.flags);
         __syncthreads();                           // every store of this workgroup has been issued and acknowledged
         if ((pa.dbg & 4) && threadIdx.x == 0 && b == pa.n_plan - 1) pa.stats[FF_STAT_T_ORDER + 1] = wall_clock64();
         if (threadIdx.x < kWave) {
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_num_sgpr(80)))
     merge_compact_body<DT, kAdd, true>(ma.hidden, ma.addend, ma.out, ma.row_bytes, ma.L, ma.L_cap, ma.order, pa.member, ma.fold,
                                        pa.dst, pa.keep, ma.aux, ma.n_main, ma.n_aux_blocks, ma.n_next_blocks, ma.order_next,
                                        ma.inv_next, pa.stats, pa.stats, ma.zero, ma.slots, bx, by,
-                                       FusedWait{pa.flags, (unsigned long long)pa.seq, pa.stats, pa.dbg, pa.dbg_buf});
+                                       FusedWait{pa.flags, (unsigned long long)pa.seq, pa.stats, pa.values, pa.pp.thr_key, pa.dbg, pa.dbg_buf});
 }
 
 template <int DT, bool kAdd>
@@ -158,7 +158,7 @@ static int fused_enabled() {
     int enabled = g_fused.load(std::memory_order_relaxed);
     if (enabled < 0) {
         const char* e = getenv("FF_FUSED");
-        enabled = (e && e[0] == '0') ? 0 : 1;
+        enabled = (e && e[0] == '1') ? 1 : 0;          // off unless asked for: measured slower than two launches (header comment)
         g_fused.store(enabled, std::memory_order_relaxed);
     }
     return enabled;

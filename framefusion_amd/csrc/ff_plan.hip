@@ -624,7 +624,7 @@ __global__ __launch_bounds__(kFastThreads) void k_plan_fast(
     unsigned long long* agg, uint32_t* tagword, int64_t* host_mapped, int64_t seq) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     plan_fast_body<DT, RS, kFastThreads>(values, cap, pp, l0, t16_end, stats, inv, L, member, keep, dst, agg, tagword,
-                                         host_mapped, seq, lds_raw, (int)blockIdx.x, (int)gridDim.x);
+                                         host_mapped, seq, lds_raw, (int)blockIdx.x, (int)gridDim.x, nullptr);
 }
 
 // ---- explicit merge set (merge_tokens_and_get_mask, main.py:243-319) --------------------------------

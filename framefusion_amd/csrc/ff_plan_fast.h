@@ -3,6 +3,7 @@
 #pragma once
 
 #include "ff_common.h"
+#include "ff_merge_body.h"      // publish_decision
 
 namespace ff {
 
@@ -53,7 +54,7 @@ __device__ inline void plan_fast_body(
     int64_t* __restrict__ stats, const int32_t* __restrict__ inv, int L,
     uint8_t* __restrict__ member, uint8_t* __restrict__ keep, int32_t* __restrict__ dst,
     unsigned long long* agg, uint32_t* tagword, int64_t* host_mapped, int64_t seq,
-    unsigned char* lds_raw, const int bid, const int nblk) {
+    unsigned char* lds_raw, const int bid, const int nblk, unsigned long long* decision_out = nullptr) {
     using A = Act<DT>;
     static_assert(A::kBytes == 2, "16-bit values only");
     constexpr int NW = NT / kWave, NQ = NT / 256, kSpec = RS / NQ;
@@ -275,6 +276,8 @@ __device__ inline void plan_fast_body(
 #ifdef FF_PLAN_PROBE
     stamp[4] = wall_clock64();
 #endif
+    // fused launch: the merge workgroups only need THIS to start (ff_merge_body.h, "decision")
+    if (decision_out && bid == 0 && wv == 0) publish_decision(decision_out, (unsigned long long)seq, is_topk, topk, kth, tstar, nv);
     // is slot t (raw value bits) folded (mode 0) / dropped (mode 1)?  branch-free
     auto folded = [&](uint32_t bits, int t) -> uint32_t {
         const uint32_t key = order_key<DT>(bits);

@@ -31,7 +31,19 @@ from oracle import ff_oracle as orc                # noqa: E402
 from framefusion_amd.synth import video_tokens, rotary_tables  # noqa: E402
 from tests import harness                           # noqa: E402
 
-OUT = os.path.join(ROOT, "tests", "golden")
+OUT = os.environ.get("FF_GOLDEN_DIR") or os.path.join(ROOT, "tests", "golden")     # (tools/check_golden.sh regenerates into a temp dir)
+
+
+class one_thread:
+    """torch-CPU's bf16 `q @ K^T` is not bit-stable from run to run when several threads split it (one weight in 70 106
+    moved by 1 ulp between two generations of full.npz): the reference's sdpa - the only matmul of the path - runs on ONE
+    thread while a fixture is generated, so that every array regenerates bit-identically."""
+    def __enter__(self):
+        self.n = torch.get_num_threads()
+        torch.set_num_threads(1)
+
+    def __exit__(self, *exc):
+        torch.set_num_threads(self.n)
 DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
 
 
@@ -357,8 +369,9 @@ def gen_importance():
         k = harness.snap(torch.randn(1, Hk, S, dh, generator=g), dtype)
         v = torch.zeros_like(k)
         gqa = H != Hk
-        w_r = sdpa(q, k, v, num=num, is_causal=causal, enable_gqa=gqa)
-        w_o = orc.last_query_attention(q, k, num=num, is_causal=causal, enable_gqa=gqa)
+        with one_thread():
+            w_r = sdpa(q, k, v, num=num, is_causal=causal, enable_gqa=gqa)
+            w_o = orc.last_query_attention(q, k, num=num, is_causal=causal, enable_gqa=gqa)
         assert same(w_r, w_o), name
         imp = torch.mean(w_r, dim=(1, 2))[0]
         out[f"{name}/q"], out[f"{name}/k"] = bits(q[0]), bits(k[0])

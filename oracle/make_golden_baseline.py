@@ -33,7 +33,7 @@ from oracle import ff_oracle as orc                  # noqa: E402
 from framefusion_amd.synth import video_tokens       # noqa: E402
 
 SRC = os.path.join(REF, "framefusion", "models", "qwen2", "modeling_qwen2_baseline.py")
-OUT = os.path.join(ROOT, "tests", "golden", "baseline.npz")
+OUT = os.path.join(os.environ.get("FF_GOLDEN_DIR") or os.path.join(ROOT, "tests", "golden"), "baseline.npz")
 DT = {"bf16": torch.bfloat16, "fp32": torch.float32, "fp16": torch.float16}
 
 

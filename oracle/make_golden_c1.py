@@ -26,7 +26,7 @@ import framefusion.main as ref                       # noqa: E402
 from oracle import ff_oracle as orc                  # noqa: E402
 from framefusion_amd.synth import video_tokens       # noqa: E402
 
-OUT = os.path.join(ROOT, "tests", "golden", "c1.npz")
+OUT = os.path.join(os.environ.get("FF_GOLDEN_DIR") or os.path.join(ROOT, "tests", "golden"), "c1.npz")
 F, P, D, PRE, POST, SEED = 8, 576, 1024, 14, 20, 1234
 
 

@@ -44,7 +44,7 @@ import framefusion.main as ref                       # noqa: E402  (the referenc
 from oracle import ff_oracle as orc                  # noqa: E402
 from framefusion_amd.synth import video_tokens       # noqa: E402
 
-OUT = os.path.join(ROOT, "tests", "golden", "full.npz")
+OUT = os.path.join(os.environ.get("FF_GOLDEN_DIR") or os.path.join(ROOT, "tests", "golden"), "full.npz")
 N_ROWS = 8
 
 # name: (F, P, D, pre, post, seed, p_change, sigma_hi, (cost, thr, lb))
@@ -174,8 +174,11 @@ def gen_prune(name, spec, store, sdpa):
     q = torch.randn(1, H, num, dh, generator=g).to(torch.bfloat16)
     kk = torch.randn(1, Hk, S, dh, generator=g).to(torch.bfloat16)
     hid = torch.randn(1, S, d, generator=g).to(torch.bfloat16)
+    n_thr = torch.get_num_threads()
+    torch.set_num_threads(1)     # (several threads splitting the bf16 q @ K^T are not bit-stable run to run: make_golden.one_thread)
     w = sdpa(q, kk, torch.zeros_like(kk), num=num, is_causal=True, enable_gqa=True)          # [1, H, num, S]
     w_o = orc.last_query_attention(q, kk, num=num, is_causal=True, enable_gqa=True)
+    torch.set_num_threads(n_thr)
     assert torch.equal(w.view(torch.int16), w_o.view(torch.int16)), name
     imp = torch.mean(w, dim=(1, 2))[0]
     original_length = S + 1000          # tokens already folded by the merge calls (main.py:66)

@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 
 from oracle import layout_oracle as lay                # noqa: E402
 
-OUT = os.path.join(ROOT, "tests", "golden", "layout.npz")
+OUT = os.path.join(os.environ.get("FF_GOLDEN_DIR") or os.path.join(ROOT, "tests", "golden"), "layout.npz")
 TEXT_TOKEN, IMAGE_TOKEN_INDEX = -1, -200
 
 

@@ -17,7 +17,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
-from make_golden import DT, OUT, bits, load_reference_sdpa, same     # noqa: E402
+from make_golden import DT, OUT, bits, load_reference_sdpa, one_thread, same     # noqa: E402
 from oracle import ff_oracle as orc                                   # noqa: E402
 from tests import harness                                             # noqa: E402
 
@@ -42,8 +42,9 @@ def main():
             mask = harness.snap(torch.randn(rows, S, generator=g), torch.float32 if kind.endswith("f32") else dtype)
             mask[:, 3] = float("-inf")
         gqa = H != Hk
-        w_r = sdpa(q, k, torch.zeros_like(k), num=num, attn_mask=mask, enable_gqa=gqa)
-        w_o = orc.last_query_attention(q, k, num=num, enable_gqa=gqa, attn_mask=mask)
+        with one_thread():
+            w_r = sdpa(q, k, torch.zeros_like(k), num=num, attn_mask=mask, enable_gqa=gqa)
+            w_o = orc.last_query_attention(q, k, num=num, enable_gqa=gqa, attn_mask=mask)
         assert same(w_r, w_o), name
         out[f"{name}/q"], out[f"{name}/k"] = bits(q[0]), bits(k[0])
         out[f"{name}/mask"] = mask.numpy().copy() if mask.dtype in (torch.bool, torch.float32) else bits(mask)

@@ -44,7 +44,7 @@ def test_two_ranks_over_rccl():
     out = run_bench("--gpus", "2", "--steps", "10", "--warmup", "3")
     check_multi(out, 2)
     assert out["collective_backend"] == "nccl"
-    assert sorted(r["gpu"] for r in out["per_rank"]) == [0, 1]
+    assert sorted(r["gpu"] for r in out["per_rank"]) == [0, 1] and out["distinct_devices"] == 2
 
 
 @pytest.mark.timeout(900)
@@ -64,6 +64,24 @@ def test_two_ranks_sharing_one_gpu_over_gloo():
     out = run_bench("--gpus", "2", "--steps", "10", "--warmup", "3", "--backend", "gloo", "--oversubscribe")
     check_multi(out, 2)
     assert out["collective_backend"] == "gloo"
+
+
+@pytest.mark.timeout(1200)
+def test_eight_ranks_sharing_one_gpu_over_gloo():
+    """The N = 8 control flow of the driver's scaling run, executed once on whatever the box has: 8 processes (rank r -> GPU
+    r % device_count) drive the kernels concurrently, rank 0's config is broadcast, 8 records + 8 identities are
+    all_gathered, one JSON line comes out.  (RCCL itself needs 8 devices; gloo carries the scalars here.)"""
+    out = run_bench("--gpus", "8", "--steps", "5", "--warmup", "2", "--backend", "gloo", "--oversubscribe")
+    check_multi(out, 8)
+    assert out["collective_backend"] == "gloo"
+    assert [r["seed"] for r in out["per_rank"]] == list(range(1234, 1242))            # seed + rank: 8 distinct samples
+    assert len({r["tokens_out"] for r in out["per_rank"]}) > 1                         # ... which reduce differently
+    assert len({r["pid"] for r in out["per_rank"]}) == 8
+    n_dev = torch.cuda.device_count()
+    assert [r["gpu"] for r in out["per_rank"]] == [r % n_dev for r in range(8)]
+    assert all(r["hostname"] and r["pci_bus_id"] for r in out["per_rank"])
+    assert out["distinct_devices"] == min(8, n_dev)
+    assert out["dp_attempt"] == 0 and "HSA_ENABLE_IPC_MODE_LEGACY" in out["ipc_mode"]
 
 
 @pytest.mark.timeout(900)
