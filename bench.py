@@ -390,7 +390,8 @@ def two_samples_per_gpu(ffa, dev, F, P, d, p_change, seed, steps, warmup):
             "tokens_reduced_per_s": reduced * steps / dt}
 
 
-def cascade(ffa, dev, F, P, d, p_change, thr, pre, post, heads, kv_heads, num, mrope, sigma_hi=1.6, reps=6, seed=1234):
+def cascade(ffa, dev, F, P, d, p_change, thr, pre, post, heads, kv_heads, num, mrope, sigma_hi=1.6, reps=6, seed=1234,
+            idle_before_b2b_s=0.0):
     """Every FrameFusion.forward call of ONE prefill (call A, then call B per layer until merging and pruning are
     finished), the importance of the prune call computed by the HIP attention-hook kernel from synthetic q / K
     (un-repeated GQA heads).  GPU time of the whole cascade (one synchronise at the end), mean over `reps`."""
@@ -434,6 +435,8 @@ def cascade(ffa, dev, F, P, d, p_change, thr, pre, post, heads, kv_heads, num, m
     # when the calls sit between other kernels of the model
     n_b2b = 4 * reps
     torch.cuda.synchronize()
+    if idle_before_b2b_s:                # (tools/trace_config.py: an idle gap that marks the block in a kernel trace)
+        time.sleep(idle_before_b2b_s)
     t0 = time.perf_counter()
     for _ in range(n_b2b):
         one_prefill()

@@ -136,6 +136,7 @@ PROTOTYPES = {
     "ff_ctx_merge_finish": (_i32, [_vp, _vp, _vp]),
     "ff_ctx_merge": (_i32, [_vp, _vp, _vp]),
     "ff_ctx_prune": (_i32, [_vp, _vp]),
+    "ff_ctx_gather_mask": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "ff_ctx_reset": (_i32, [_vp, _vp]),
     "ff_ctx_expect_tables": (None, [_vp]),
     "ff_abi_sizeof": (_sz, [_i32]),
@@ -218,9 +219,17 @@ def load():
                 f"{LIB_PATH} is missing and could not be built ({e}): run `python -c 'import __graft_entry__ as g; "
                 f"g.build()'` (or `make -C {CSRC}`). framefusion_amd has no CPU/eager fallback.") from e
     # a stale binary (sources edited since it was built, or a copy whose timestamps hide that from make) is rebuilt,
-    # never run: the stamp is read from the file BEFORE anything is loaded
+    # never run: the stamp is read from the file BEFORE anything is loaded.  Rebuilding needs make + hipcc: a deployment
+    # that ships sources next to a binary built from OTHER sources, without a compiler, gets an error that says so
+    # (FF_AUTO_BUILD=0 turns the implicit build off altogether).
     want = source_hash()
     if want is not None and file_stamp() != want:
+        import shutil
+        if os.environ.get("FF_AUTO_BUILD", "1") == "0" or not (shutil.which("make") and shutil.which(os.environ.get("HIPCC", "hipcc"))):
+            raise FrameFusionHipError(
+                f"{LIB_PATH} was built from other sources (its stamp {file_stamp()}, the sources' {want}) and this process may "
+                f"not or cannot rebuild it (FF_AUTO_BUILD=0, or make / hipcc not on PATH): run `make -C {CSRC}` where a ROCm "
+                f"toolchain is installed, or ship the library without the csrc/ directory")
         build()
         if file_stamp() != want:
             build(force=True)

@@ -29,15 +29,18 @@ from .main import FrameFusion, TEXT_TOKEN, _PACK_I64, _PACK_PTR, _Scratch, _dtyp
 
 
 def compute_density_overhead(sparsity_list) -> tuple:
-    """(mean cumulative density, final density) of a per-layer sparsity schedule (:26-43)."""
-    density_list = [1 - s for s in sparsity_list]
-    cost = 0.0
-    remaining_density = 1.0
-    for density in density_list:
-        remaining_density *= density
-        cost += remaining_density
-    norm_cost = cost / len(density_list)
-    return norm_cost, remaining_density
+    """What a per-layer sparsity schedule costs (modeling_qwen2_baseline.py:26-43): the fraction of tokens alive after
+    layer i is the running product of (1 - sparsity) - returns (its mean over the layers, its last value).  Python floats,
+    folded left to right, so the pair is bit-identical to the reference's."""
+    alive = 1.0
+    alive_per_layer = []
+    for sparsity in sparsity_list:
+        alive *= 1 - sparsity
+        alive_per_layer.append(alive)
+    total = 0.0
+    for a in alive_per_layer:
+        total += a
+    return total / len(alive_per_layer), alive
 
 
 class FixedSparsityMerging:

@@ -286,18 +286,32 @@ extern "C" int ff_ctx_merge_begin(ff_ctx_t* c, const ff_merge_call_t* a) {
     return ctx_begin(c, a, true);
 }
 
-// spin on the pinned result block; no HIP call on the fast path
+// Wait for the pinned result block; no HIP call on the fast path.  A call whose stream is empty is answered in ~70 us:
+// pure spin (pause).  Inside a real prefill the host runs far ahead of the device and the answer is tens of milliseconds
+// away: after 200 us the loop yields its time slice on every turn, after 2 ms it sleeps 50 us per turn - other ranks and
+// threads of an oversubscribed host keep their cores.  The stream is looked at after 1 ms and then every ~50 us of
+// waiting: a drained or failed stream ends the wait.
+#include <sched.h>
 static int ctx_wait(ff_ctx_t* c, hipStream_t st, int64_t* waited_ns) {
     volatile int64_t* host = c->stats_host;
     const int64_t seq = c->seq;
     const int64_t t0 = now_ns();
     int64_t next_query = t0 + 1000000;               // first look at the stream after 1 ms
     int rc = FF_OK;
+    int phase = 0;                                   // 0 spin, 1 yield, 2 sleep
     for (uint32_t spins = 0;; ++spins) {
         if (__atomic_load_n(&host[FF_STAT_SEQ], __ATOMIC_ACQUIRE) == seq) break;
-        cpu_relax();
-        if ((spins & 255u) != 255u) continue;
+        if (phase == 0) {
+            cpu_relax();
+            if ((spins & 255u) != 255u) continue;
+        } else if (phase == 1) {
+            sched_yield();
+        } else {
+            timespec ts{0, 50000};
+            nanosleep(&ts, nullptr);
+        }
         const int64_t t = now_ns();
+        phase = t - t0 < 200000 ? 0 : (t - t0 < 2000000 ? 1 : 2);
         if (t < next_query) continue;
         next_query = t + 50000;
         hipError_t e = hipStreamQuery(st);
@@ -319,9 +333,6 @@ static int ctx_finish_enqueue(ff_ctx_t* c, const ff_merge_call_t* a) {
                           c->inv_next, c->ws, c->ws_bytes, a->stream, true);
     if (rc) return rc;
     c->dirty = 0;
-    if (a->mask)
-        rc = ff_gather_mask(a->mask, a->mask_out, a->mask_elem_bytes, a->L, a->L_cap, c->dst, c->stats,
-                            ff::ws_scratch_ints(c->ws, c->cap), a->stream);
     return rc;
 }
 
@@ -369,6 +380,13 @@ extern "C" int ff_ctx_merge_finish(ff_ctx_t* c, const ff_merge_call_t* a, ff_mer
         r->l_out = h[FF_STAT_LOUT];
         break;
     }
+    // the attention mask follows once the call is known to be valid and to fold something: nothing for an attempt whose layout
+    // hint was wrong, nothing when the sequence stays as it is (the caller keeps its own mask)
+    if (a->mask && r->l_out != a->L) {
+        rc = ff_gather_mask(a->mask, a->mask_out, a->mask_elem_bytes, a->L, a->L_cap, c->dst, c->stats,
+                            ff::ws_scratch_ints(c->ws, c->cap), a->stream);
+        if (rc) { c->dirty = 1; c->order_len = 0; return rc; }
+    }
     if (r->l_out != a->L) {
         // the merge kernel wrote the by-patch order of the compacted sequence: it is the current one now
         int32_t* t = c->order; c->order = c->order_next; c->order_next = t;
@@ -385,6 +403,13 @@ extern "C" int ff_ctx_merge(ff_ctx_t* c, const ff_merge_call_t* a, ff_merge_resu
     int rc = ff_ctx_merge_begin(c, a);
     if (rc) return rc;
     return ff_ctx_merge_finish(c, a, r);
+}
+
+extern "C" int ff_ctx_gather_mask(ff_ctx_t* c, const void* mask, void* mask_out, int64_t elem_bytes, int64_t L, int64_t L_cap,
+                                  ff_stream_t stream) {
+    int rc = ctx_check(c, L);
+    if (rc) return rc;
+    return ff_gather_mask(mask, mask_out, elem_bytes, L, L_cap, c->dst, c->stats, ff::ws_scratch_ints(c->ws, c->cap), stream);
 }
 
 extern "C" int ff_ctx_prune(ff_ctx_t* c, const ff_prune_call_t* a) {

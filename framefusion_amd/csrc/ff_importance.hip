@@ -720,11 +720,18 @@ static int launch_lq_finish(void* scores, float2* tstats, unsigned long long* xc
     return (int)hipGetLastError();
 }
 
+// Which path launch_lq takes - ONE predicate for the launcher and for the workspace size (they used to be two copies, and
+// the size's copy lacked the H * num clause: 256 queries x 28 heads took the general path into a tiled-size workspace).
+// Tiled: a key row is read by a power-of-two number of lanes, 16 bytes each, and one key's scores fit the finish
+// kernel's row loop.
+static bool lq_tiled(int64_t esz, int64_t H, int64_t num, int64_t dh) {
+    const int64_t lpk = dh * esz / 16;
+    return (dh * esz) % 16 == 0 && lpk >= 1 && lpk <= 64 && (lpk & (lpk - 1)) == 0 && H * num <= 4096;
+}
+
 size_t lq_ws_bytes(int dtype, int64_t H, int64_t num, int64_t S, int64_t dh) {
     const int64_t esz = dtype == FF_F32 ? 4 : 2;
-    const int64_t lpk = dh * esz / 16;
-    const bool tiled = (dh * esz) % 16 == 0 && lpk >= 1 && lpk <= 64 && (lpk & (lpk - 1)) == 0;
-    if (!tiled) return (size_t)(2 * H * num * S) * sizeof(float);
+    if (!lq_tiled(esz, H, num, dh)) return (size_t)(2 * H * num * S) * sizeof(float);
     const int64_t cap = (S + 63) / 64;                                         // statistics entries per row (k_lq_dot: one per 64-key step at most)
     const int64_t pitch_bytes = (H * num * esz + 15) & ~(int64_t)15;           // one key's scores: whole 16-byte words
     return (size_t)(S * pitch_bytes + H * num * cap * 8 + H * num * 16 + 16);       // scores | tile statistics | row granules
@@ -765,8 +772,7 @@ static int launch_lq(const void* q, const void* k, KStrides ks, int64_t H, int64
                      int* l0, int* t16_end, hipStream_t st) {
     constexpr int kB = Act<DT>::kBytes;
     const int64_t lpk = dh * kB / 16;
-    const bool tiled = (dh * kB) % 16 == 0 && lpk >= 1 && lpk <= 64 && (lpk & (lpk - 1)) == 0 && H * num <= 4096;
-    if (!tiled) return launch_lq_general<DT>(q, k, ks, H, H_kv, num, S, dh, scale, causal, bias, weights, importance, ws, lo, hi, l0, t16_end, st);
+    if (!lq_tiled(kB, H, num, dh)) return launch_lq_general<DT>(q, k, ks, H, H_kv, num, S, dh, scale, causal, bias, weights, importance, ws, lo, hi, l0, t16_end, st);
     const int rows = (int)((H / H_kv) * num), rows_total = (int)(H * num);
     const int tiles = (int)((S + kLqKeys - 1) / kLqKeys);
     void* scores = ws;

@@ -205,8 +205,7 @@ extern "C" int ff_merge_compact(const void* hidden, void* hidden_out, int dtype,
     if (dtype != FF_F32 && dtype != FF_BF16 && dtype != FF_F16) return FF_ERR_ARG;
     if (n_aux < 0 || n_aux > FF_MAX_AUX || (n_aux > 0 && !aux_host)) return FF_ERR_ARG;
     for (int x = 0; x < n_aux; ++x)
-        if (!aux_host[x].src || !aux_host[x].dst || aux_host[x].row_bytes < 2 || (aux_host[x].row_bytes & 1) ||
-            aux_host[x].outer < 1)
+        if (!aux_host[x].src || !aux_host[x].dst || aux_host[x].row_bytes < 1 || aux_host[x].outer < 1)
             return FF_ERR_ARG;
     const int64_t esz = dtype == FF_F32 ? 4 : 2;
     if (((uintptr_t)hidden & 15) || ((uintptr_t)hidden_out & 15) || ((d * esz) & 15)) return FF_ERR_ALIGN;
@@ -278,7 +277,7 @@ static int pack_aux(const ff_aux_t* aux_host, int n_aux, ff::AuxPack& pack) {
     pack.n = n_aux;
     for (int x = 0; x < FF_MAX_AUX; ++x) pack.a[x] = x < n_aux ? aux_host[x] : ff_aux_t{nullptr, nullptr, 0, 0};
     for (int x = 0; x < n_aux; ++x)
-        if (!pack.a[x].src || !pack.a[x].dst || pack.a[x].row_bytes < 2 || (pack.a[x].row_bytes & 1) || pack.a[x].outer < 1)
+        if (!pack.a[x].src || !pack.a[x].dst || pack.a[x].row_bytes < 1 || pack.a[x].outer < 1)     // (any row size: copy_row)
             return FF_ERR_ARG;
     return FF_OK;
 }

@@ -15,8 +15,8 @@ struct AuxPack {
     int n;
 };
 
-// Copy `bytes` (multiple of 2) from src to dst with the widest unit the alignment allows,
-// spread over the threads [tid, nthreads).
+// Copy `bytes` from src to dst with the widest unit the alignment allows (single bytes for odd sizes: 1-byte
+// position ids / boolean rows of the stand-alone gathers), spread over the threads [tid, nthreads).
 __device__ inline void copy_row(const char* __restrict__ src, char* __restrict__ dst, int64_t bytes,
                                 int tid, int nthreads) {
     const uintptr_t al = (uintptr_t)src | (uintptr_t)dst | (uintptr_t)bytes;
@@ -29,9 +29,11 @@ __device__ inline void copy_row(const char* __restrict__ src, char* __restrict__
     } else if ((al & 3) == 0) {
         for (int64_t o = (int64_t)tid * 4; o < bytes; o += (int64_t)nthreads * 4)
             *(uint32_t*)(dst + o) = *(const uint32_t*)(src + o);
-    } else {
+    } else if ((al & 1) == 0) {
         for (int64_t o = (int64_t)tid * 2; o < bytes; o += (int64_t)nthreads * 2)
             *(uint16_t*)(dst + o) = *(const uint16_t*)(src + o);
+    } else {
+        for (int64_t o = tid; o < bytes; o += nthreads) dst[o] = src[o];
     }
 }
 

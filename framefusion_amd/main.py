@@ -161,11 +161,17 @@ def _fail(rc: int, what: str, err_bits: int = 0):
 
 
 class FrameFusion(nn.Module):
-    def __init__(self, cost=0.3, similarity_lower_bound=0.6, ratio_lower_bound=0.1):
+    def __init__(self, cost=0.3, similarity_lower_bound=0.6, ratio_lower_bound=0.1, compact_outputs=False):
         super().__init__()
         self.cost = cost
         self.similarity_lower_bound = similarity_lower_bound
         self.ratio_lower_bound = ratio_lower_bound
+        # A merge call writes into buffers of the INPUT length (the output length is only known once the plan kernel
+        # has run, and the merge kernel is already enqueued behind it) and returns views of their first L_out rows: the
+        # caller's view keeps the whole buffer alive (302 MB for a 91 MB result at 64 x 576 x 4096).  compact_outputs
+        # = True copies the views into exactly sized tensors when less than half of the buffer is used - what the
+        # reference returns (main.py:132-138) - for ~30 us per call at that shape.  INTEGRATION.md, "Output buffers".
+        self.compact_outputs = compact_outputs
         self._scratch = {}
         self._ptype_gen = 0       # bumped whenever patch_type is (re)assigned: keys the cached by-patch order
         self._host_ints = {}      # id(0-d device tensor) -> (tensor, int): the prepare() scalars, read back once
@@ -356,14 +362,14 @@ class FrameFusion(nn.Module):
         raise NotImplementedError("Only support list or tensor for position embeddings")
 
     @staticmethod
-    def _mask_for(attention_mask, L, L_cap):
+    def _mask_for(attention_mask, L):
         m = attention_mask
         if m.ndim != 4 or m.shape[0] != 1 or m.shape[1] != 1 or m.shape[2] != L or m.shape[3] != L:
             raise FrameFusionHipError(f"attention mask of shape {tuple(m.shape)} is not [1, 1, {L}, {L}]")
         m = m.contiguous()
         if m.data_ptr() & 15:
             m = m.clone()
-        return m, torch.empty(1, 1, L_cap, L_cap, dtype=m.dtype, device=m.device)
+        return m
 
     # ---- merge call: main.py:104-138 -------------------------------------------------------------
     def _merge(self, hidden_states, position_embeddings, attention_mask, residual=None):
@@ -394,6 +400,7 @@ class FrameFusion(nn.Module):
             self._ptype_checked = (self._ptype_gen, L, device)
 
         sub = self._compute_pruning_ratio(self.sparsity_list, self.cost)           # main.py:109
+        mask_in = self._mask_for(attention_mask, L) if attention_mask is not None else None     # (shape errors before anything runs)
         sc, stream = self._scratch_for(device, L)
         order_valid = 1 if sc.order_gen == self._ptype_gen else 0
         # first call of a prefill: hand the frame-major layout the prepare() scalars describe to the
@@ -421,12 +428,8 @@ class FrameFusion(nn.Module):
         n_aux = 1 + sc.put_aux(call, _lib.MERGE_CALL_AUX_OFFSET + 32, zip(srcs, outs), L, room=_lib.MAX_AUX - 1)
         _PACK_PTR.pack_into(call, 16, out.data_ptr())
         _PACK_I64.pack_into(call, _lib.MERGE_CALL_AUX_OFFSET - 8, n_aux)
-        mask_out = None
-        if attention_mask is not None:
-            m, mask_out = self._mask_for(attention_mask, L, L_cap)
-            _lib.MASK_TRIPLE.pack_into(call, _lib.MERGE_CALL_MASK_OFFSET, m.data_ptr(), mask_out.data_ptr(), m.element_size())
-        else:
-            _lib.MASK_TRIPLE.pack_into(call, _lib.MERGE_CALL_MASK_OFFSET, 0, 0, 0)
+        # (the attention mask is gathered behind the call, into a buffer of the OUTPUT length: see below)
+        _lib.MASK_TRIPLE.pack_into(call, _lib.MERGE_CALL_MASK_OFFSET, 0, 0, 0)
         # The one device->host hand-off of the call: the plan kernel stores the result block into pinned
         # host memory (sequence word last) BEFORE the merge kernel runs, so the host learns L_out while the
         # second streaming pass is still in flight and returns without waiting for it.
@@ -465,11 +468,25 @@ class FrameFusion(nn.Module):
         # (now the context's current one), so the next merge call of this prefill skips K0
         self.last_call = dict(kind="merge", L_in=L, L_out=L_out, nv=nv, ftn=ftn, count=count, branch=branch,
                               k=k, scratch=sc, dtype=dtype, order=sc.order_next, wait_ns=wait_ns)
-        self.patch_type = ptype_out.narrow(1, 0, L_out)                             # main.py:132
+        if attention_mask is not None:                                              # main.py:137-138
+            # gathered now that L_out is known: [1, 1, L_out, L_out] exactly (an input-sized capacity buffer would be
+            # 2.7 GB for a bf16 mask at 37 k tokens), on the keep set still sitting in the context
+            m = mask_in
+            mask_out = torch.empty(1, 1, L_out, L_out, dtype=m.dtype, device=m.device)
+            rc = lib.ff_ctx_gather_mask(sc.ctx_ptr, m.data_ptr(), mask_out.data_ptr(), m.element_size(), L, L_out, stream or 0)
+            if rc:
+                _fail(rc, "merge (attention mask)")
+            attention_mask = mask_out
+        hidden_out, ptype_new, pos_new = out.narrow(1, 0, L_out), ptype_out.narrow(1, 0, L_out), rebuild(L_out)
+        if self.compact_outputs and 2 * L_out < L_cap:
+            hidden_out, ptype_new = hidden_out.clone(), ptype_new.clone()
+            if type(pos_new) == list:
+                pos_new[0], pos_new[1] = pos_new[0].clone(), pos_new[1].clone()
+            else:
+                pos_new = pos_new.clone()
+        self.patch_type = ptype_new                                                 # main.py:132
         sc.order_gen = self._ptype_gen
-        if mask_out is not None:
-            attention_mask = mask_out[:, :, :L_out, :L_out]
-        return out.narrow(1, 0, L_out), rebuild(L_out), attention_mask
+        return hidden_out, pos_new, attention_mask
 
     def last_plan(self):
         """Diagnostics of the most recent merge / prune call (views into the reusable scratch: valid
@@ -554,7 +571,8 @@ class FrameFusion(nn.Module):
                                        L_out, w_code, H, num, tables_ready, start, n_img, k, stream or 0, n_aux)
         mask_out = None
         if attention_mask is not None:
-            m, mask_out = self._mask_for(attention_mask, q_len, L_out)
+            m = self._mask_for(attention_mask, q_len)
+            mask_out = torch.empty(1, 1, L_out, L_out, dtype=m.dtype, device=m.device)
             _lib.MASK_TRIPLE.pack_into(call, _lib.PRUNE_CALL_MASK_OFFSET, m.data_ptr(), mask_out.data_ptr(), m.element_size())
         else:
             _lib.MASK_TRIPLE.pack_into(call, _lib.PRUNE_CALL_MASK_OFFSET, 0, 0, 0)
@@ -599,6 +617,13 @@ class FrameFusion(nn.Module):
             n = idx.numel()
             axis = -1 if srcs[0].ndim == 2 else -2
             L = srcs[0].shape[axis]
+            if n:
+                # torch's advanced indexing raises on an index outside [-L, L): so does this (one read-back; the handler is
+                # a compatibility entry point, the hot path gathers its position tensors inside the merge kernel)
+                lo, hi = int(idx.min()), int(idx.max())
+                if lo < -L or hi >= L:
+                    bad = lo if lo < -L else hi
+                    raise IndexError(f"index {bad} is out of bounds for dimension {srcs[0].ndim + axis} with size {L}")
             outs = []
             for t in srcs:
                 shape = list(t.shape)

@@ -437,6 +437,15 @@ int ff_ctx_merge_begin(ff_ctx_t* ctx, const ff_merge_call_t* call);
 int ff_ctx_merge_finish(ff_ctx_t* ctx, const ff_merge_call_t* call, ff_merge_result_t* result);
 int ff_ctx_merge(ff_ctx_t* ctx, const ff_merge_call_t* call, ff_merge_result_t* result);
 
+/* The attention mask of the merge call that just finished on this context, gathered with its keep set (main.py:137-138):
+ * out[r, c] = mask[src[r], src[c]] for the l_out kept positions, row stride L_cap (>= l_out) elements.  For a host that
+ * sizes mask_out AFTER it knows l_out - pass call->mask = NULL to ff_ctx_merge_finish and call this behind it (what
+ * FrameFusion.forward does: an [L, L] capacity buffer for a 37 k-token call would be 2.7 GB).  ff_ctx_merge_finish with
+ * call->mask set gathers into the caller's [L_cap, L_cap] buffer itself - after the result is known, and only when the
+ * call folded something. */
+int ff_ctx_gather_mask(ff_ctx_t* ctx, const void* mask, void* mask_out, int64_t elem_bytes, int64_t L, int64_t L_cap,
+                       ff_stream_t stream);
+
 /* One prune call (main.py:61-101) on the context's scratch: arguments as ff_prune_step.  Nothing is
  * waited for (the output length S - n_img + k is the caller's arithmetic). */
 typedef struct ff_prune_call {

@@ -67,6 +67,13 @@ def test_error_strings_and_workspace():
         assert len(lib.ff_error_string(code)) > 4
     assert lib.ff_workspace_bytes(36864, 576) >= 48
     assert lib.ff_workspace_bytes(-1, 1) == 0
+    # the importance workspace is sized for the path the launcher takes: 2-byte scores + statistics on the tiled path, two
+    # fp32 [H * num, S] arrays on the general one - which is also where more than 4096 query rows go, whatever the head size
+    bf16 = _lib.FF_BF16
+    assert lib.ff_last_query_workspace_bytes(bf16, 28, 4, 1000, 128) < 2 * 28 * 4 * 1000 * 4
+    assert lib.ff_last_query_workspace_bytes(bf16, 6, 4, 1000, 24) == 2 * 6 * 4 * 1000 * 4           # odd head size
+    assert lib.ff_last_query_workspace_bytes(bf16, 28, 256, 1000, 128) == 2 * 28 * 256 * 1000 * 4    # 7168 rows
+    assert lib.ff_set_fused_launch(-1) in (0, 1)                                                      # (reports only)
 
 
 def test_argument_validation_without_gpu():

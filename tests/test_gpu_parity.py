@@ -565,6 +565,29 @@ def test_importance_odd_head_size_general_path():
         assert torch.allclose(imp.reshape(-1).cpu().float(), torch.mean(want, dim=(1, 2))[0].float(), rtol=2 ** -7, atol=1e-30)
 
 
+def test_importance_more_than_4096_query_rows_takes_the_general_path_with_its_own_workspace():
+    """H * num > 4096 with a power-of-two head size (28 heads x 256 queries): launch_lq takes the general kernels, whose
+    workspace is 2 * H * num * S floats - ff_last_query_workspace_bytes must size for THAT path (it used to answer with the
+    tiled path's size: an out-of-bounds device write).  The bytes are checked through the C ABI, the values against the
+    oracle."""
+    H, Hk, num, S, dh = 28, 4, 256, 300, 128
+    lib = _lib.load()
+    assert lib.ff_last_query_workspace_bytes(_lib.FF_BF16, H, num, S, dh) == 2 * H * num * S * 4
+    assert lib.ff_last_query_workspace_bytes(_lib.FF_BF16, H, 4, S, dh) < 2 * H * 4 * S * 4          # (tiled: 2-byte scores)
+    g = torch.Generator().manual_seed(11)
+    q = harness.snap(torch.randn(1, H, num, dh, generator=g), torch.bfloat16)
+    k = harness.snap(torch.randn(1, Hk, S, dh, generator=g), torch.bfloat16)
+    want = orc.last_query_attention(q, k, num=num, is_causal=True, enable_gqa=True)
+    guard = torch.full((1 << 22,), 7, dtype=torch.uint8, device=DEV)        # (whatever the allocator puts behind the workspace)
+    got = ffa.scaled_dot_product_attention(dev(q), dev(k), None, num=num, is_causal=True, enable_gqa=True)
+    imp = ffa.last_query_importance(dev(q), dev(k), num=num, is_causal=True)
+    torch.cuda.synchronize()
+    assert bool((guard == 7).all())
+    assert torch.allclose(got.cpu().float(), want.float(), rtol=2 ** -7, atol=1e-30)
+    assert float((got.cpu().float() != want.float()).float().mean()) <= 5e-3
+    assert torch.allclose(imp.reshape(-1).cpu().float(), torch.mean(want, dim=(1, 2))[0].float(), rtol=2 ** -7, atol=1e-30)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
 @pytest.mark.parametrize("H,num,S", [(28, 4, 5000), (1, 1, 64), (3, 11, 4097), (8, 16, 1003), (65, 8, 777), (4, 1, 36898)])
 def test_head_mean_exact(dtype, H, num, S):
@@ -810,6 +833,25 @@ def test_position_handlers_match_torch_indexing(kind, dtype):
     want = orc.gather_position_embeddings([t.clone() for t in pe] if isinstance(pe, list) else pe.clone(), odd)
     for a, b in zip(got if isinstance(got, list) else [got], want if isinstance(want, list) else [want]):
         assert torch.equal(a.cpu().float(), b.float())
+    # ... and an index outside [-L, L) raises, as torch's indexing does (the kernel used to skip the row: uninitialised output)
+    for bad in (torch.tensor([3, L]), torch.tensor([-L - 1, 0])):
+        arg = [t.to(DEV) for t in pe] if isinstance(pe, list) else pe.to(DEV)
+        with pytest.raises(IndexError):
+            f.position_embedding_handler_at_pruning(arg, bad.to(DEV))
+
+
+@pytest.mark.parametrize("pdtype", [torch.uint8, torch.bool, torch.int16, torch.int32])
+def test_position_handlers_take_one_byte_position_tensors(pdtype):
+    """a 2-D position tensor of 1-byte elements (odd row size): the reference's `pe[:, keep]` accepts any dtype"""
+    L = 515
+    g = torch.Generator().manual_seed(3)
+    pe = torch.randint(0, 2 if pdtype == torch.bool else 120, (2, L), generator=g).to(pdtype)
+    keep = torch.sort(torch.randperm(L, generator=g)[:77]).values
+    mask = torch.zeros(1, L, dtype=torch.bool)
+    mask[0, keep] = True
+    f = ffa.FrameFusion()
+    assert torch.equal(f.position_embedding_handler_at_pruning(pe.to(DEV), keep.to(DEV)).cpu(), pe[:, keep])
+    assert torch.equal(f.position_embedding_handler_at_merging(pe.to(DEV), mask.to(DEV)).cpu(), pe[:, mask[0]])
 
 
 @pytest.mark.parametrize("mdtype", [torch.bfloat16, torch.float32, torch.bool, torch.float64])
