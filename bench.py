@@ -145,7 +145,8 @@ def main():
     info = ff.last_call
     # whole-job numbers: tokens summed over ranks; one record per rank all_gathered for the report
     _, tok_all = dp.aggregate(dist, elapsed, float(reduced * args.steps), dev)
-    per_rank = dp.gather_records(dist, (rank, dev.index, L, L_out, elapsed / args.steps * 1e3, dp.sample_seed(args.seed, rank)), dev)
+    per_rank = dp.gather_records(dist, (rank, dev.index, L, L_out, elapsed / args.steps * 1e3, dp.sample_seed(args.seed, rank),
+                                        info["count"]), dev)
     who = dp.gather_identities(dist, dev)          # hostname / pid / PCI address of every rank's GPU: N ranks = N distinct devices?
 
     result = None
@@ -166,7 +167,7 @@ def main():
             "ipc_mode": dp.ipc_mode(), "dp_attempt": dp.attempt(),
             "distinct_devices": len({(w.get("hostname"), w.get("pci_bus_id")) for w in who}),
             "per_rank": [{"rank": int(r[0]), "gpu": int(r[1]), "tokens_in": int(r[2]), "tokens_out": int(r[3]),
-                          "ms_per_step": r[4], "seed": int(r[5]), "hostname": w.get("hostname"), "pid": w.get("pid"),
+                          "ms_per_step": r[4], "seed": int(r[5]), "similarities_above_threshold": int(r[6]), "hostname": w.get("hostname"), "pid": w.get("pid"),
                           "pci_bus_id": w.get("pci_bus_id")} for r, w in zip(per_rank, who)],
             "steps": args.steps,
             "warmup": args.warmup,

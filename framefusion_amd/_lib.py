@@ -34,7 +34,8 @@ ERR_DEVICE, ERR_STATE = -5, -6
 
 
 class FFAux(C.Structure):
-    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("row_bytes", C.c_int64), ("outer", C.c_int64)]
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("row_bytes", C.c_int64), ("outer", C.c_int64),
+                ("src_outer_bytes", C.c_int64)]
 
 
 class FFCtx(C.Structure):
@@ -62,7 +63,7 @@ class FFMergeCall(C.Structure):
 # head of ff_merge_call_t up to and including n_aux; aux entries (4 x 8 bytes each) and the mask triple follow
 MERGE_CALL_HEAD = struct.Struct("=4Q6q3d4qQq")
 MERGE_CALL_AUX_OFFSET = MERGE_CALL_HEAD.size
-AUX_ENTRY = struct.Struct("=2Q2q")
+AUX_ENTRY = struct.Struct("=2Q3q")
 MERGE_CALL_MASK_OFFSET = MERGE_CALL_AUX_OFFSET + MAX_AUX * AUX_ENTRY.size
 MASK_TRIPLE = struct.Struct("=2Qq")
 

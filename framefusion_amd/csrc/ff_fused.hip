@@ -193,7 +193,7 @@ int launch_plan_merge_fused(const void* sim, int dtype, const int32_t* order, co
     FusedMergeArgs ma;
     ma.aux.n = n_aux;
     for (int x = 0; x < n_aux; ++x) ma.aux.a[x] = aux_host[x];
-    for (int x = n_aux; x < FF_MAX_AUX; ++x) ma.aux.a[x] = ff_aux_t{nullptr, nullptr, 0, 0};
+    for (int x = n_aux; x < FF_MAX_AUX; ++x) ma.aux.a[x] = ff_aux_t{nullptr, nullptr, 0, 0, 0};
     const int64_t row_bytes = d * 2;
     const int nblk = (int)((row_bytes + 1023) / 1024);
     ma.hidden = (const char*)hidden; ma.addend = (const char*)addend; ma.out = (char*)hidden_out;

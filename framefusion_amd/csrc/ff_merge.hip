@@ -166,7 +166,7 @@ int launch_merge_compact(const void* hidden, const void* addend, void* hidden_ou
     AuxPack pack;
     pack.n = keep ? n_aux : 0;
     for (int x = 0; x < pack.n; ++x) pack.a[x] = aux_host[x];
-    for (int x = pack.n; x < FF_MAX_AUX; ++x) pack.a[x] = ff_aux_t{nullptr, nullptr, 0, 0};
+    for (int x = pack.n; x < FF_MAX_AUX; ++x) pack.a[x] = ff_aux_t{nullptr, nullptr, 0, 0, 0};
     const int64_t row_bytes = d * (dtype == FF_F32 ? 4 : 2);
     const int nblk = (int)((row_bytes + 1023) / 1024);
     const int ny = (nblk + kMergeWaves - 1) / kMergeWaves;
@@ -205,7 +205,7 @@ extern "C" int ff_merge_compact(const void* hidden, void* hidden_out, int dtype,
     if (dtype != FF_F32 && dtype != FF_BF16 && dtype != FF_F16) return FF_ERR_ARG;
     if (n_aux < 0 || n_aux > FF_MAX_AUX || (n_aux > 0 && !aux_host)) return FF_ERR_ARG;
     for (int x = 0; x < n_aux; ++x)
-        if (!aux_host[x].src || !aux_host[x].dst || aux_host[x].row_bytes < 1 || aux_host[x].outer < 1)
+        if (!aux_host[x].src || !aux_host[x].dst || aux_host[x].row_bytes < 1 || aux_host[x].outer < 1 || aux_host[x].src_outer_bytes < 0)
             return FF_ERR_ARG;
     const int64_t esz = dtype == FF_F32 ? 4 : 2;
     if (((uintptr_t)hidden & 15) || ((uintptr_t)hidden_out & 15) || ((d * esz) & 15)) return FF_ERR_ALIGN;
@@ -252,8 +252,7 @@ __global__ __launch_bounds__(256) void k_rows_by_index(AuxPack aux, const int64_
     for (int x = 0; x < aux.n; ++x) {
         const ff_aux_t& ax = aux.a[x];
         for (int64_t ou = 0; ou < ax.outer; ++ou)
-            copy_row((const char*)ax.src + (ou * L + i) * ax.row_bytes, (char*)ax.dst + (ou * n + r) * ax.row_bytes,
-                     ax.row_bytes, sub, 16);
+            copy_row(aux_src_row(ax, ou, i, L), (char*)ax.dst + (ou * n + r) * ax.row_bytes, ax.row_bytes, sub, 16);
     }
 }
 __global__ __launch_bounds__(256) void k_rows_by_dst(AuxPack aux, const int32_t* __restrict__ dst, int L, int64_t L_cap) {
@@ -265,8 +264,7 @@ __global__ __launch_bounds__(256) void k_rows_by_dst(AuxPack aux, const int32_t*
     for (int x = 0; x < aux.n; ++x) {
         const ff_aux_t& ax = aux.a[x];
         for (int64_t ou = 0; ou < ax.outer; ++ou)
-            copy_row((const char*)ax.src + (ou * L + i) * ax.row_bytes, (char*)ax.dst + (ou * L_cap + r) * ax.row_bytes,
-                     ax.row_bytes, sub, 16);
+            copy_row(aux_src_row(ax, ou, i, L), (char*)ax.dst + (ou * L_cap + r) * ax.row_bytes, ax.row_bytes, sub, 16);
     }
 }
 int launch_scan_keep(const uint8_t* keep, int64_t L, int32_t* dst, int64_t* stats, hipStream_t st);
@@ -275,9 +273,9 @@ int launch_scan_keep(const uint8_t* keep, int64_t L, int32_t* dst, int64_t* stat
 static int pack_aux(const ff_aux_t* aux_host, int n_aux, ff::AuxPack& pack) {
     if (n_aux < 1 || n_aux > FF_MAX_AUX || !aux_host) return FF_ERR_ARG;
     pack.n = n_aux;
-    for (int x = 0; x < FF_MAX_AUX; ++x) pack.a[x] = x < n_aux ? aux_host[x] : ff_aux_t{nullptr, nullptr, 0, 0};
+    for (int x = 0; x < FF_MAX_AUX; ++x) pack.a[x] = x < n_aux ? aux_host[x] : ff_aux_t{nullptr, nullptr, 0, 0, 0};
     for (int x = 0; x < n_aux; ++x)
-        if (!pack.a[x].src || !pack.a[x].dst || pack.a[x].row_bytes < 1 || pack.a[x].outer < 1)     // (any row size: copy_row)
+        if (!pack.a[x].src || !pack.a[x].dst || pack.a[x].row_bytes < 1 || pack.a[x].outer < 1 || pack.a[x].src_outer_bytes < 0)     // (any row size: copy_row)
             return FF_ERR_ARG;
     return FF_OK;
 }

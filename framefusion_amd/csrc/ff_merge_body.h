@@ -14,6 +14,10 @@ struct AuxPack {
     ff_aux_t a[FF_MAX_AUX];
     int n;
 };
+// row i of outer slice ou of an auxiliary source holding L tokens
+__device__ inline const char* aux_src_row(const ff_aux_t& ax, int64_t ou, int64_t i, int64_t L) {
+    return (const char*)ax.src + ou * (ax.src_outer_bytes ? ax.src_outer_bytes : L * ax.row_bytes) + i * ax.row_bytes;
+}
 
 // Copy `bytes` from src to dst with the widest unit the alignment allows (single bytes for odd sizes: 1-byte
 // position ids / boolean rows of the stand-alone gathers), spread over the threads [tid, nthreads).
@@ -278,8 +282,7 @@ __device__ inline void merge_compact_body(
         for (int x = 0; x < aux.n; ++x) {
             const ff_aux_t& ax = aux.a[x];
             for (int64_t ou = 0; ou < ax.outer; ++ou)
-                copy_row((const char*)ax.src + (ou * L + i) * ax.row_bytes,
-                         (char*)ax.dst + (ou * L_cap + r) * ax.row_bytes, ax.row_bytes, sub, 16);
+                copy_row(aux_src_row(ax, ou, i, L), (char*)ax.dst + (ou * L_cap + r) * ax.row_bytes, ax.row_bytes, sub, 16);
         }
         return;
     }

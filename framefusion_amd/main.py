@@ -135,21 +135,47 @@ class _Scratch:
 
     # ---- the call blocks ----
     def put_aux(self, block, offset, pairs, L, room=_lib.MAX_AUX):
-        """Describe (src, out) tensor pairs as ff_aux_t entries; returns their number."""
+        """Describe (src, out) tensor pairs as ff_aux_t entries; returns their number.  Sources may be `_token_dense` views
+        (the leading dims one uniform stride apart): the stride travels as src_outer_bytes."""
         n = 0
         pack = _lib.AUX_ENTRY.pack_into
+        size = _lib.AUX_ENTRY.size
         for s, o in pairs:
             if n >= room:
                 raise FrameFusionHipError("too many auxiliary tensors")
             if s.ndim == 2:         # [B, L] ids
                 row, outer = s.element_size(), s.shape[0]
+                outer_bytes = 0
             else:                   # [..., L, dh]
                 last = s.shape[-1]
                 row = last * s.element_size()
                 outer = s.numel() // (L * last)
-            pack(block, offset + 32 * n, s.data_ptr(), o.data_ptr(), row, outer)
+                outer_bytes = 0 if s.is_contiguous() else _outer_stride(s) * s.element_size()
+            pack(block, offset + size * n, s.data_ptr(), o.data_ptr(), row, outer, outer_bytes)
             n += 1
         return n
+
+
+def _outer_stride(t: torch.Tensor):
+    """Element stride between consecutive slices of the leading dims of a [..., L, dh] tensor whose rows are dense
+    (stride 1 / dh on the last two axes) when those leading dims are ONE uniform stride apart - None otherwise.  True for
+    contiguous tensors and for the [3, 1, L_out, dh] views a merge call returns for M-RoPE tables (three planes, L_cap rows
+    apart), which therefore go into the next call without a copy."""
+    if t.ndim < 3 or t.stride(-1) != 1 or t.stride(-2) != t.shape[-1]:
+        return None
+    stride = None
+    expect = None                       # stride the next-outer non-trivial dim must have
+    for k in range(t.ndim - 3, -1, -1):
+        if t.shape[k] == 1:
+            continue
+        if stride is None:
+            stride = t.stride(k)
+            expect = stride * t.shape[k]
+        elif t.stride(k) != expect:
+            return None
+        else:
+            expect *= t.shape[k]
+    return stride if stride is not None else t.shape[-2] * t.shape[-1]
 
 
 def _fail(rc: int, what: str, err_bits: int = 0):
@@ -335,9 +361,9 @@ class FrameFusion(nn.Module):
                 if t.ndim not in (3, 4) or t.shape[-2] != L:
                     raise FrameFusionHipError(f"position embedding of shape {tuple(t.shape)} does not have "
                                               f"{L} tokens on its second-to-last axis")
-            if not a.is_contiguous():
+            if not a.is_contiguous() and (_outer_stride(a) is None or a.data_ptr() & 1):
                 a = a.contiguous()
-            if not b.is_contiguous():
+            if not b.is_contiguous() and (_outer_stride(b) is None or b.data_ptr() & 1):
                 b = b.contiguous()
             out_shape = shape[:-2] + (L_cap, shape[-1])
             if b.shape == shape and b.dtype == a.dtype:
@@ -424,8 +450,8 @@ class FrameFusion(nn.Module):
         out = torch.empty((1, L_cap, d), dtype=dtype, device=device)
         ptype_out = torch.empty((1, L_cap), dtype=torch.int64, device=device)
         srcs, outs, rebuild = self._aux_for_positions(position_embeddings, L, L_cap)
-        _lib.AUX_ENTRY.pack_into(call, _lib.MERGE_CALL_AUX_OFFSET, ptype.data_ptr(), ptype_out.data_ptr(), 8, 1)    # patch types
-        n_aux = 1 + sc.put_aux(call, _lib.MERGE_CALL_AUX_OFFSET + 32, zip(srcs, outs), L, room=_lib.MAX_AUX - 1)
+        _lib.AUX_ENTRY.pack_into(call, _lib.MERGE_CALL_AUX_OFFSET, ptype.data_ptr(), ptype_out.data_ptr(), 8, 1, 0)    # patch types
+        n_aux = 1 + sc.put_aux(call, _lib.MERGE_CALL_AUX_OFFSET + _lib.AUX_ENTRY.size, zip(srcs, outs), L, room=_lib.MAX_AUX - 1)
         _PACK_PTR.pack_into(call, 16, out.data_ptr())
         _PACK_I64.pack_into(call, _lib.MERGE_CALL_AUX_OFFSET - 8, n_aux)
         # (the attention mask is gathered behind the call, into a buffer of the OUTPUT length: see below)
@@ -604,7 +630,7 @@ class FrameFusion(nn.Module):
             else:
                 L, last = s.shape[-2], s.shape[-1]
                 row, outer = last * s.element_size(), s.numel() // (L * last)
-            aux[n] = _lib.FFAux(s.data_ptr(), o.data_ptr(), row, outer)
+            aux[n] = _lib.FFAux(s.data_ptr(), o.data_ptr(), row, outer, 0)
         return aux
 
     def position_embedding_handler_at_pruning(self, position_embeddings, keep_indexs):

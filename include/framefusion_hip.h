@@ -177,8 +177,11 @@ enum {
 typedef struct {
     const void* src;     /* [outer, L, row_bytes]                         */
     void* dst;           /* [outer, L_cap, row_bytes]                     */
-    int64_t row_bytes;   /* bytes per token (multiple of 2)               */
+    int64_t row_bytes;   /* bytes per token (>= 1)                        */
     int64_t outer;       /* leading dims folded together (>= 1)           */
+    int64_t src_outer_bytes;  /* bytes from one outer slice of src to the next; 0 = L * row_bytes (dense).  Lets
+                                 the [3, 1, L_out, dh] VIEW a merge call returned for an M-RoPE table - rows dense, the
+                                 three planes L_cap rows apart - go into the next call as it is (ABI v8)           */
 } ff_aux_t;
 
 #define FF_MAX_AUX 4

@@ -60,13 +60,13 @@ static int full_mode(int F, int P, int d, int pre, int L, const std::vector<uint
             for (int i = 0; i < L; ++i)
                 for (int c = 0; c < dh; ++c) tab[w][((size_t)p * L + i) * dh + c] = bf16_of(table_at(w, p, i, c));
     }
-    void *dbase, *dadd, *dout, *dout2, *dpt, *dpt_out, *dpt_out2, *dtab[2], *dtab_out[2], *dtab_in2[2], *dtab_out2[2];
+    void *dbase, *dadd, *dout, *dout2, *dpt, *dpt_out, *dpt_out2, *dtab[2], *dtab_out[2], *dtab_out2[2];
     void *dorder, *dorder_next, *dinv, *dinv_next, *dsim, *dmember, *ddst, *dkeep, *dstats, *dws;
     int64_t* stats_host;
     const size_t wsb = ff_workspace_bytes(L, P), hb = (size_t)L * d * 2, tb = (size_t)planes * L * dh * 2;
     CK(hipMalloc(&dbase, hb)); CK(hipMalloc(&dadd, hb)); CK(hipMalloc(&dout, hb)); CK(hipMalloc(&dout2, hb));
     CK(hipMalloc(&dpt, L * 8)); CK(hipMalloc(&dpt_out, L * 8)); CK(hipMalloc(&dpt_out2, L * 8));
-    for (int w = 0; w < 2; ++w) { CK(hipMalloc(&dtab[w], tb)); CK(hipMalloc(&dtab_out[w], tb)); CK(hipMalloc(&dtab_in2[w], tb)); CK(hipMalloc(&dtab_out2[w], tb)); }
+    for (int w = 0; w < 2; ++w) { CK(hipMalloc(&dtab[w], tb)); CK(hipMalloc(&dtab_out[w], tb)); CK(hipMalloc(&dtab_out2[w], tb)); }
     CK(hipMalloc(&dorder, L * 4)); CK(hipMalloc(&dorder_next, L * 4)); CK(hipMalloc(&dinv, L * 4)); CK(hipMalloc(&dinv_next, L * 4));
     CK(hipMalloc(&dsim, L * 4)); CK(hipMalloc(&dmember, L)); CK(hipMalloc(&ddst, L * 4)); CK(hipMalloc(&dkeep, L));
     CK(hipMalloc(&dstats, FF_STAT_WORDS * 8)); CK(hipMalloc(&dws, wsb));
@@ -102,14 +102,10 @@ static int full_mode(int F, int P, int d, int pre, int L, const std::vector<uint
     call2.hidden = dout; call2.addend = nullptr; call2.hidden_out = dout2; call2.patch_type = (const int64_t*)dpt_out;
     call2.L = l1; call2.L_cap = l1; call2.order_valid = 1; call2.hint_frames = 0; call2.sub = 0.55;
     call2.aux[0] = ff_aux_t{dpt_out, dpt_out2, 8, 1};
-    call2.aux[1] = ff_aux_t{dtab_in2[0], dtab_out2[0], dh * 2, planes};
-    call2.aux[2] = ff_aux_t{dtab_in2[1], dtab_out2[1], dh * 2, planes};
-    // the first call wrote its tables as [planes, L_cap = L, dh]; the second call reads [planes, l1, dh] contiguous:
-    // repack plane by plane (a host that keeps capacity-strided views would pass them through its own gather)
-    for (int w = 0; w < 2; ++w)
-        for (int p = 0; p < planes; ++p)
-            CK(hipMemcpyAsync((char*)dtab_in2[w] + (size_t)p * l1 * dh * 2, (char*)dtab_out[w] + (size_t)p * L * dh * 2,
-                              (size_t)l1 * dh * 2, hipMemcpyDeviceToDevice, st));
+    // the first call wrote its tables as [planes, L_cap = L, dh], of which the first l1 rows of every plane are the second
+    // call's [planes, l1, dh] input: passed as they lie, the planes L rows apart (ff_aux_t.src_outer_bytes, ABI v8)
+    call2.aux[1] = ff_aux_t{dtab_out[0], dtab_out2[0], dh * 2, planes, (int64_t)L * dh * 2};
+    call2.aux[2] = ff_aux_t{dtab_out[1], dtab_out2[1], dh * 2, planes, (int64_t)L * dh * 2};
     const int64_t swaps_before = ctx.swaps;
     FF(ff_ctx_merge(&ctx, &call2, &res[1]));
     CK(hipStreamSynchronize(st));

@@ -125,7 +125,7 @@ def test_context_structures_match_the_header():
     assert _lib.PRUNE_CALL_HEAD.size == _lib.FFPruneCall.aux.offset
     assert _lib.PRUNE_CALL_MASK_OFFSET == _lib.FFPruneCall.mask.offset
     assert _lib.MERGE_RESULT.size == C.sizeof(_lib.FFMergeResult)
-    assert _lib.AUX_ENTRY.size == C.sizeof(_lib.FFAux) == 32
+    assert _lib.AUX_ENTRY.size == C.sizeof(_lib.FFAux) == 40
 
 
 def test_context_calls_validate_before_any_hip_call():

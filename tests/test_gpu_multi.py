@@ -75,7 +75,9 @@ def test_eight_ranks_sharing_one_gpu_over_gloo():
     check_multi(out, 8)
     assert out["collective_backend"] == "gloo"
     assert [r["seed"] for r in out["per_rank"]] == list(range(1234, 1242))            # seed + rank: 8 distinct samples
-    assert len({r["tokens_out"] for r in out["per_rank"]}) > 1                         # ... which reduce differently
+    # ... every rank a different video (the top-k branch cuts all of them to the same length: the samples show in their
+    # threshold counts)
+    assert len({r["similarities_above_threshold"] for r in out["per_rank"]}) == 8
     assert len({r["pid"] for r in out["per_rank"]}) == 8
     n_dev = torch.cuda.device_count()
     assert [r["gpu"] for r in out["per_rank"]] == [r % n_dev for r in range(8)]

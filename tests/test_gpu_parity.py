@@ -689,6 +689,41 @@ def test_determinism():
         assert same_bits(o, outs[0][0]) and torch.equal(p, outs[0][1])
 
 
+@pytest.mark.parametrize("container", ["ids", "rotary", "mrope"])
+def test_compact_outputs_returns_exactly_sized_tensors(container):
+    """FrameFusion(compact_outputs=True): the tensors a merge call returns own exactly their bytes (the reference's
+    `hidden_states[token_mask, :]`, main.py:132-138) instead of being views of input-length buffers; same values."""
+    from framefusion_amd.synth import rotary_tables
+    F, P, d = 16, 48, 1024
+    h, pt = video_tokens(F, P, d, p_change=0.2, sigma_hi=1.5, seed=9, pre=5, post=5, grid=0.125)
+    L = h.shape[1]
+
+    def positions():
+        if container == "ids":
+            return torch.arange(L)[None]
+        return list(rotary_tables(L, 64, torch.bfloat16, mrope=(container == "mrope")))
+
+    got = {}
+    for compact in (False, True):
+        f = ffa.FrameFusion(0.3, 0.6, 0.1, compact_outputs=compact)
+        f.prepare(dev(pt), P, 5, 5 + F * P - 1, F * P, L)
+        pe = positions()
+        pe = [dev(t) for t in pe] if isinstance(pe, list) else dev(pe)
+        out, pos, _ = f(dev(h), pe, None)
+        got[compact] = (out, pos, f.patch_type)
+    out_v, pos_v, pt_v = got[False]
+    out_c, pos_c, pt_c = got[True]
+    L_out = out_c.shape[1]
+    assert 2 * L_out < L                                                       # (the top-k regime of this sample: compaction applies)
+    tensors_c = [out_c, pt_c] + (pos_c if isinstance(pos_c, list) else [pos_c])
+    tensors_v = [out_v, pt_v] + (pos_v if isinstance(pos_v, list) else [pos_v])
+    for c, v in zip(tensors_c, tensors_v):
+        assert c.shape == v.shape and torch.equal(c.cpu().view(torch.uint8) if c.dtype == torch.bfloat16 else c.cpu(),
+                                                  v.cpu().view(torch.uint8) if v.dtype == torch.bfloat16 else v.cpu())
+        assert c.is_contiguous() and c.untyped_storage().nbytes() == c.numel() * c.element_size()
+    assert out_v.untyped_storage().nbytes() == L * d * 2                        # the default: a view of an L-row buffer
+
+
 # ---------------------------------------------------------------------------------------------
 # layout hint: closed-form by-patch order inside the similarity kernel, verified on the device
 # ---------------------------------------------------------------------------------------------
