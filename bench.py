@@ -148,6 +148,9 @@ def main():
     per_rank = dp.gather_records(dist, (rank, dev.index, L, L_out, elapsed / args.steps * 1e3, dp.sample_seed(args.seed, rank),
                                         info["count"]), dev)
     who = dp.gather_identities(dist, dev)          # hostname / pid / PCI address of every rank's GPU: N ranks = N distinct devices?
+    # every rank's kept-token index list, padded to L int32: rank 0 reports a checksum per rank
+    kept_idx = torch.nonzero(ff.last_plan()["keep"]).reshape(-1)
+    kept_all = dp.gather_kept_indices(dist, kept_idx, L, dev)
 
     result = None
     if rank == 0:
@@ -168,7 +171,10 @@ def main():
             "distinct_devices": len({(w.get("hostname"), w.get("pci_bus_id")) for w in who}),
             "per_rank": [{"rank": int(r[0]), "gpu": int(r[1]), "tokens_in": int(r[2]), "tokens_out": int(r[3]),
                           "ms_per_step": r[4], "seed": int(r[5]), "similarities_above_threshold": int(r[6]), "hostname": w.get("hostname"), "pid": w.get("pid"),
-                          "pci_bus_id": w.get("pci_bus_id")} for r, w in zip(per_rank, who)],
+                          "pci_bus_id": w.get("pci_bus_id"),
+                          "kept_indices": {"n": int(kx.numel()), "sum": int(kx.to(torch.int64).sum()),
+                                           "first": kx[:4].tolist(), "last": kx[-4:].tolist()}}
+                         for r, w, kx in zip(per_rank, who, kept_all)],
             "steps": args.steps,
             "warmup": args.warmup,
             "before_the_loop": "1 priming step + per-kernel stage timing (the roofline figure), no idle gap before the warm-up steps",

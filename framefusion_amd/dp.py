@@ -9,7 +9,8 @@ tests) carries three small things, all off the timed path:
   * `broadcast_config`  - rank 0's workload description (seed, shape, step counts) to every rank;
   * `gather_records`    - all_gather of one fixed-size float64 record per rank (L_in, L_out, ms, ...);
   * `aggregate`         - all_reduce MAX of the elapsed time / SUM of the units processed;
-  * `gather_identities` - all_gather_object of (hostname, pid, PCI address of the GPU, IPC mode) per rank.
+  * `gather_identities` - all_gather_object of (hostname, pid, PCI address of the GPU, IPC mode) per rank;
+  * `gather_kept_indices` - all_gather of every rank's kept-token index list, padded to a fixed int32 capacity.
 
 `launch_ranks` turns `python bench.py --gpus N` into N ranks (one per GPU) when the process was not
 started by torch.distributed.run already.
@@ -222,6 +223,27 @@ def aggregate(dist, elapsed_s: float, units: float, device) -> Tuple[float, floa
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(u, op=dist.ReduceOp.SUM)
     return float(t), float(u)
+
+
+def gather_kept_indices(dist, kept: torch.Tensor, capacity: int, device) -> List[torch.Tensor]:
+    """Every rank's kept-token indices (all_gather of the index lists, padded to `capacity` int32 with -1:
+    <= 147 KB per rank at 64 x 576), on every rank, as CPU int32 tensors of their true lengths.  One fixed-size all_gather:
+    a ring over xGMI moves (world - 1) x 147 KB per link, microseconds next to a prefill, and off the timed path."""
+    cd = _comm_device(dist, device)
+    mine = torch.full((capacity,), -1, dtype=torch.int32, device=cd)
+    n = int(kept.numel())
+    if n > capacity:
+        raise ValueError(f"{n} kept indices for a capacity of {capacity}")
+    mine[:n] = kept.to(device=cd, dtype=torch.int32)
+    if dist is None:
+        return [mine[:n].cpu()]
+    parts = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, mine)
+    out = []
+    for p in parts:
+        p = p.cpu()
+        out.append(p[: int((p >= 0).sum())])
+    return out
 
 
 def gather_lengths(dist, l_in: int, l_out: int, device) -> List[Tuple[int, int]]:

@@ -150,10 +150,25 @@ class _Scratch:
                 last = s.shape[-1]
                 row = last * s.element_size()
                 outer = s.numel() // (L * last)
-                outer_bytes = 0 if s.is_contiguous() else _outer_stride(s) * s.element_size()
+                outer_bytes = getattr(s, "_ff_outer_bytes", None)
+                if outer_bytes is None:
+                    outer_bytes = 0 if s.is_contiguous() else _outer_stride(s) * s.element_size()
             pack(block, offset + size * n, s.data_ptr(), o.data_ptr(), row, outer, outer_bytes)
             n += 1
         return n
+
+
+def _token_dense(t: torch.Tensor) -> torch.Tensor:
+    """`t` itself when the merge kernel can read it in place (contiguous, or rows dense and the leading dims one uniform
+    stride apart: `_outer_stride`), else a contiguous copy."""
+    ob = getattr(t, "_ff_outer_bytes", None)
+    if ob is not None or t.is_contiguous():
+        return t
+    st = _outer_stride(t)
+    if st is None:
+        return t.contiguous()
+    t._ff_outer_bytes = st * t.element_size()
+    return t
 
 
 def _outer_stride(t: torch.Tensor):
@@ -361,10 +376,7 @@ class FrameFusion(nn.Module):
                 if t.ndim not in (3, 4) or t.shape[-2] != L:
                     raise FrameFusionHipError(f"position embedding of shape {tuple(t.shape)} does not have "
                                               f"{L} tokens on its second-to-last axis")
-            if not a.is_contiguous() and (_outer_stride(a) is None or a.data_ptr() & 1):
-                a = a.contiguous()
-            if not b.is_contiguous() and (_outer_stride(b) is None or b.data_ptr() & 1):
-                b = b.contiguous()
+            a, b = _token_dense(a), _token_dense(b)
             out_shape = shape[:-2] + (L_cap, shape[-1])
             if b.shape == shape and b.dtype == a.dtype:
                 both = torch.empty((2,) + out_shape, dtype=a.dtype, device=a.device)     # cos and sin: one allocation
@@ -375,8 +387,11 @@ class FrameFusion(nn.Module):
             ax = len(shape) - 2
 
             def rebuild(L_out):
-                position_embeddings[0] = outs[0].narrow(ax, 0, L_out)
-                position_embeddings[1] = outs[1].narrow(ax, 0, L_out)
+                for x in (0, 1):
+                    v = outs[x].narrow(ax, 0, L_out)
+                    # (what put_aux needs to take this view as the next call's source without looking at its strides again)
+                    v._ff_outer_bytes = 0 if v.is_contiguous() else L_cap * v.shape[-1] * v.element_size()
+                    position_embeddings[x] = v
                 return position_embeddings
             return [a, b], outs, rebuild
         if type(position_embeddings) == torch.Tensor:

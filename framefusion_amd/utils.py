@@ -56,7 +56,7 @@ def _launch_last_query(query, key, num, is_causal, scale, want_weights, want_imp
     weights = torch.empty(1, H, num, S, dtype=query.dtype, device=dev) if want_weights else None
     importance = torch.empty(S, dtype=query.dtype, device=dev) if want_importance else None
     ws_bytes = int(lib.ff_last_query_workspace_bytes(code, H, num, S, dh))
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)          # (scores + statistics: dead when the call returns)
     sel_lo, sel_hi, sel_ws, sel_bytes = select if select is not None else (0, 0, None, 0)
     rc = lib.ff_last_query_attention(q_last.data_ptr(), k.data_ptr(), code, H, H_kv, num, S, dh, sh, ss, float(factor),
                                      1 if is_causal else 0, bias.data_ptr() if bias is not None else None,

@@ -46,9 +46,13 @@ def main():
     recs = dp.gather_records(dist, (L, out.shape[1], mine * 1e3 / cfg["steps"], cfg["seed"]), dev)
     t_all, units = dp.aggregate(dist, mine, float((L - out.shape[1]) * cfg["steps"]), dev)
     ids = dp.gather_identities(dist, dev)
+    # the kept-token index lists (every rank keeps a different number): padded all_gather, true lengths back
+    kept = torch.arange(L)[torch.arange(L) % (rank + 2) == 0]
+    kept_all = [k.tolist() for k in dp.gather_kept_indices(dist, kept, L, dev)]
     if rank == 0:
         print(json.dumps(dict(n_gpus=world, ranks=dist.get_world_size() if dist else 1, records=recs, t_max=t_max,
-                              t_all=t_all, units=units, seed=cfg["seed"], steps=cfg["steps"], identities=ids)))
+                              t_all=t_all, units=units, seed=cfg["seed"], steps=cfg["steps"], identities=ids, kept=kept_all,
+                              L=L)))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

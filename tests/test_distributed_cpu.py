@@ -45,6 +45,8 @@ def test_self_launched_two_ranks_over_gloo():
     assert all(r[0] > r[1] for r in recs) and recs[0][1] != recs[1][1]
     assert out["units"] == sum((r[0] - r[1]) * out["steps"] for r in recs)
     assert out["t_max"] == out["t_all"] >= max(r[2] for r in recs) * out["steps"] / 1e3 * 0.5
+    # all_gather of the kept-index lists (padded to L, true lengths restored): rank r kept every (r + 2)-th position
+    assert out["kept"] == [list(range(0, out["L"], 2)), list(range(0, out["L"], 3))]
 
 
 @pytest.mark.timeout(300)
@@ -81,6 +83,9 @@ def test_single_process_helpers():
     assert dp.aggregate(None, 1.25, 7.0, cpu) == (1.25, 7.0)
     assert dp.gather_lengths(None, 10, 4, cpu) == [(10, 4)]
     assert dp.gather_records(None, (1, 2.5), cpu) == [[1.0, 2.5]]
+    assert [k.tolist() for k in dp.gather_kept_indices(None, torch.tensor([0, 3, 4]), 8, cpu)] == [[0, 3, 4]]
+    with pytest.raises(ValueError):
+        dp.gather_kept_indices(None, torch.arange(9), 8, cpu)
     assert dp.broadcast_config(None, dict(seed=3, p=0.5), cpu) == dict(seed=3, p=0.5)
     assert dp.init("gloo") is None
     t_max, mine, out = dp.timed_steps(None, lambda: 7, 3, 1, cpu)

@@ -78,6 +78,9 @@ def test_eight_ranks_sharing_one_gpu_over_gloo():
     # ... every rank a different video (the top-k branch cuts all of them to the same length: the samples show in their
     # threshold counts)
     assert len({r["similarities_above_threshold"] for r in out["per_rank"]}) == 8
+    # the kept-index lists were all_gathered: 8 different ones, each of its rank's output length
+    assert all(r["kept_indices"]["n"] == r["tokens_out"] for r in out["per_rank"])
+    assert len({r["kept_indices"]["sum"] for r in out["per_rank"]}) == 8
     assert len({r["pid"] for r in out["per_rank"]}) == 8
     n_dev = torch.cuda.device_count()
     assert [r["gpu"] for r in out["per_rank"]] == [r % n_dev for r in range(8)]
