@@ -30,13 +30,11 @@ struct LayoutHint {
 
 // kAdd: the rows are T(hidden[i] + addend[i]) - the decoder's residual add fused into the pass (both
 // operands read once here and once by the merge kernel, the sum never touches memory).
-#ifdef FF_K1_OCC8
-#define FF_K1_ATTR __attribute__((amdgpu_waves_per_eu(8, 8), amdgpu_num_sgpr(80)))
-#else
-#define FF_K1_ATTR
-#endif
+// Measured and not shipped (profiles/EXPERIMENTS.md 4.8, 4.13): 8 waves per SIMD instead of 7 (66 VGPRs / 85 SGPRs here;
+// amdgpu_waves_per_eu(8, 8) + amdgpu_num_sgpr(80) = 4 spills): 68.8 vs 59.5 us; the overlap row handed from wave to wave
+// through LDS (two 1 KiB buffers per wave, one barrier per tile) instead of being fetched again: 60.7 vs 59.8 us.
 template <int DT, int kPairs, int kSimThreads, bool kHint, bool kAdd>
-__global__ __launch_bounds__(kSimThreads) FF_K1_ATTR void k_pair_similarity(
+__global__ __launch_bounds__(kSimThreads) void k_pair_similarity(
     const char* __restrict__ hidden, const char* __restrict__ addend, uint32_t row_bytes, const int64_t* __restrict__ ptype,
     const int32_t* __restrict__ order, const int64_t* __restrict__ stats, void* __restrict__ sim,
     int* __restrict__ l0, int* t16_end, float thr, const LayoutHint hint, int32_t* __restrict__ order_out,
