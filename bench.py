@@ -353,6 +353,26 @@ def profiled_traffic(kernel):
     return total, source
 
 
+def profiled_kernel_us(cfg):
+    """Sum of the kernel durations of one back-to-back cascade of configuration `cfg` from the committed per-kernel timeline
+    (profiles/rNN_timeline_<cfg>.txt: rocprofv3 kernel trace of tools/trace_config.py, tools/prof_configs.sh) - the part of
+    `us_back_to_back` that is GPU work; the rest is gaps the host leaves.  Like roofline.traffic it is withheld when the
+    timeline was taken on other kernel sources."""
+    import glob, re
+    from framefusion_amd import _lib
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_timeline_{cfg}.txt")))
+    if not files:
+        return None, None
+    text = open(files[-1]).read()
+    src = {"file": os.path.relpath(files[-1], ROOT)}
+    m = re.search(r"sources ([0-9a-f]{16})", text)
+    if m is None or m.group(1) != _lib.source_hash():
+        src["stale"] = "the kernel sources changed since this timeline was taken: kernel_us withheld"
+        return None, src
+    m = re.search(r"kernel_us ([0-9.]+)", text)
+    return (float(m.group(1)) if m else None), src
+
+
 def two_samples_per_gpu(ffa, dev, F, P, d, p_change, seed, steps, warmup):
     """Two independent samples on ONE GPU at the same time: two threads, each with its own FrameFusion instance, stream and
     sample (the deployment the reference's demo uses for its replicas, llava_video_compare.py:217-223) - the result-block
@@ -464,13 +484,16 @@ def extra_configs(dev):
     import framefusion_amd as ffa
     out = []
     # C2 in the threshold regime (merge, identity, prune)
+    def with_kernel_us(r, cfg):
+        r["kernel_us"], r["kernel_us_source"] = profiled_kernel_us(cfg)
+        return r
     r = cascade(ffa, dev, FRAMES, PATCHES, DIM, 0.5, THRESHOLD, 14, 20, 32, 8, 1, False)
-    out.append({"workload": "C2 cascade: [1, 14+64x576+20, 4096] bf16, p_change=0.5 (threshold branch), thr=0.6", **r})
+    out.append({"workload": "C2 cascade: [1, 14+64x576+20, 4096] bf16, p_change=0.5 (threshold branch), thr=0.6", **with_kernel_us(r, "c2thr")})
     # C3: Qwen2-VL-7B, 128 frames = 64 temporal grids x 195 tokens, M-RoPE containers, num = 4 importance, threshold sweep
     sweep = []
     for thr in (0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9):
         r = cascade(ffa, dev, 64, 195, 3584, 0.5, thr, 15, 12, 28, 4, 4, True, sigma_hi=1.8, reps=4, seed=77)
-        sweep.append({"similarity_lower_bound": thr, **r})
+        sweep.append({"similarity_lower_bound": thr, **(with_kernel_us(r, "c3") if thr == 0.6 else r)})
     tot_us = sum(s["us"] for s in sweep)
     out.append({"workload": "C3: Qwen2-VL-7B shape [1, 15+64x195+12, 3584] bf16, M-RoPE [3,1,L,128], num=4, "
                             "similarity_lower_bound sweep 0.3..0.9 (one prefill cascade each)",
@@ -480,12 +503,12 @@ def extra_configs(dev):
     # C5: LLaVA-Video-72B, d = 8192, H = 64 / H_kv = 8: merge, then importance inside the attention hook + prune
     r = cascade(ffa, dev, 64, 576, 8192, 0.95, THRESHOLD, 14, 20, 64, 8, 1, False, sigma_hi=None)
     out.append({"workload": "C5: LLaVA-Video-72B shape [1, 14+64x576+20, 8192] bf16, H=64/H_kv=8: merge call, fused "
-                            "attention importance + prune", **r})
+                            "attention importance + prune", **with_kernel_us(r, "c5")})
     r = cascade(ffa, dev, 64, 576, 8192, 0.2, THRESHOLD, 14, 20, 64, 8, 1, False, sigma_hi=None)
-    out.append({"workload": "C5 top-k regime: [1, 14+64x576+20, 8192] bf16, one merge call", **r})
+    out.append({"workload": "C5 top-k regime: [1, 14+64x576+20, 8192] bf16, one merge call", **with_kernel_us(r, "c5topk")})
     # the real LLaVA-Video-7B token layout (14 x 15 per frame, d = 3584): the host, not HBM, sets the pace here
     r = cascade(ffa, dev, 64, 210, 3584, 0.2, THRESHOLD, 14, 20, 28, 4, 1, False, sigma_hi=None)
-    out.append({"workload": "LLaVA-Video-7B real shape [1, 14+64x210+20, 3584] bf16, one merge call (top-k)", **r})
+    out.append({"workload": "LLaVA-Video-7B real shape [1, 14+64x210+20, 3584] bf16, one merge call (top-k)", **with_kernel_us(r, "7b")})
     return out
 
 

@@ -469,8 +469,15 @@ class FrameFusion(nn.Module):
         n_aux = 1 + sc.put_aux(call, _lib.MERGE_CALL_AUX_OFFSET + _lib.AUX_ENTRY.size, zip(srcs, outs), L, room=_lib.MAX_AUX - 1)
         _PACK_PTR.pack_into(call, 16, out.data_ptr())
         _PACK_I64.pack_into(call, _lib.MERGE_CALL_AUX_OFFSET - 8, n_aux)
-        # (the attention mask is gathered behind the call, into a buffer of the OUTPUT length: see below)
-        _lib.MASK_TRIPLE.pack_into(call, _lib.MERGE_CALL_MASK_OFFSET, 0, 0, 0)
+        # (the attention mask is gathered behind the call, into a buffer of the OUTPUT length: see below.  The C ABI's other
+        # form - mask + an [L_cap, L_cap] buffer in the call block, gathered by ff_ctx_merge_finish itself - is what a host
+        # without a cheap allocator uses; `_mask_through_call` routes through it for the tests)
+        mask_cap = None
+        if mask_in is not None and self.__dict__.get("_mask_through_call"):
+            mask_cap = torch.empty(1, 1, L_cap, L_cap, dtype=mask_in.dtype, device=mask_in.device)
+            _lib.MASK_TRIPLE.pack_into(call, _lib.MERGE_CALL_MASK_OFFSET, mask_in.data_ptr(), mask_cap.data_ptr(), mask_in.element_size())
+        else:
+            _lib.MASK_TRIPLE.pack_into(call, _lib.MERGE_CALL_MASK_OFFSET, 0, 0, 0)
         # The one device->host hand-off of the call: the plan kernel stores the result block into pinned
         # host memory (sequence word last) BEFORE the merge kernel runs, so the host learns L_out while the
         # second streaming pass is still in flight and returns without waiting for it.
@@ -509,7 +516,9 @@ class FrameFusion(nn.Module):
         # (now the context's current one), so the next merge call of this prefill skips K0
         self.last_call = dict(kind="merge", L_in=L, L_out=L_out, nv=nv, ftn=ftn, count=count, branch=branch,
                               k=k, scratch=sc, dtype=dtype, order=sc.order_next, wait_ns=wait_ns)
-        if attention_mask is not None:                                              # main.py:137-138
+        if mask_cap is not None:
+            attention_mask = mask_cap[:, :, :L_out, :L_out]
+        elif attention_mask is not None:                                            # main.py:137-138
             # gathered now that L_out is known: [1, 1, L_out, L_out] exactly (an input-sized capacity buffer would be
             # 2.7 GB for a bf16 mask at 37 k tokens), on the keep set still sitting in the context
             m = mask_in

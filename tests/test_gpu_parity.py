@@ -891,7 +891,8 @@ def test_position_handlers_take_one_byte_position_tensors(pdtype):
 
 @pytest.mark.parametrize("mdtype", [torch.bfloat16, torch.float32, torch.bool, torch.float64])
 @pytest.mark.parametrize("L", [97, 640, 1531])
-def test_attention_mask_is_gathered_like_the_reference(mdtype, L):
+@pytest.mark.parametrize("through_call", [False, True])
+def test_attention_mask_is_gathered_like_the_reference(mdtype, L, through_call):
     """main.py:137-138 / 99-100: attention_mask[:, :, keep, :][:, :, :, keep] through the two-level gather kernel, every
     element size, lengths whose output rows are and are not whole 16-byte words; merge call and prune call."""
     F, P, d = (L - 7) // 10, 10, 64
@@ -904,7 +905,11 @@ def test_attention_mask_is_gathered_like_the_reference(mdtype, L):
         mask = torch.randn(1, 1, L, L, generator=g).to(mdtype)
     want, mo = harness.run_cascade(orc.OracleFrameFusion(0.3, 0.6, 0.1), h.clone(), pt.clone(), P, torch.arange(L)[None], mask.clone(),
                                    layers=3, heads=2, num=1, start=3, n_visual=F * P)
-    got, mg = harness.run_cascade(ffa.FrameFusion(0.3, 0.6, 0.1), dev(h), dev(pt), P, dev(torch.arange(L)[None]), dev(mask),
+    f = ffa.FrameFusion(0.3, 0.6, 0.1)
+    # through_call: the mask and an [L, L] capacity buffer travel in the call block and ff_ctx_merge_finish gathers (the C
+    # ABI's form for hosts that allocate up front); else FrameFusion.forward's own: an exactly sized buffer, ff_ctx_gather_mask
+    f._mask_through_call = through_call
+    got, mg = harness.run_cascade(f, dev(h), dev(pt), P, dev(torch.arange(L)[None]), dev(mask),
                                   layers=3, heads=2, num=1, start=3, n_visual=F * P)
     assert [r["length"] for r in got] == [r["length"] for r in want] and got[-1]["finish_pruning"]
     assert mg.shape == mo.shape and mg.dtype == mo.dtype
