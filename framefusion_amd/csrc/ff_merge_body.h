@@ -308,7 +308,7 @@ __device__ inline void merge_compact_body(
     if constexpr (kFused) {
         // (the order window above does not depend on the plan: its load is in flight while the workgroup waits)
         dec = wait_for_decision(fw, bx);
-        if ((fw.dbg & 4) && threadIdx.x == 0) fw.dbg_buf[2 * (by * n_main + bx)] = wall_clock64();
+        if ((fw.dbg & 4) && threadIdx.x == 0) fw.dbg_buf[3 * (by * n_main + bx)] = wall_clock64();
         if (col >= row_bytes) return;
     }
     // is slot s (< L) folded into its predecessor?  Stand-alone: the plan kernel's flags.  Fused: the plan's rule
@@ -487,7 +487,7 @@ __device__ inline void merge_compact_body(
     }
     if (open_r >= 0) flush();
     if constexpr (kFused) {
-        if ((fw.dbg & 4) && threadIdx.x == 0) fw.dbg_buf[2 * (by * n_main + bx) + 1] = wall_clock64();
+        if ((fw.dbg & 4) && threadIdx.x == 0) { fw.dbg_buf[3 * (by * n_main + bx) + 1] = wall_clock64(); fw.dbg_buf[3 * (by * n_main + bx) + 2] = (long long)(be - bs) << 32; }
     }
 }
 

@@ -136,6 +136,8 @@ def test_context_calls_validate_before_any_hip_call():
     assert lib.ff_ctx_merge_begin(a(ctx), None) == -1
     assert lib.ff_ctx_merge_begin(a(ctx), a(call)) == -1           # a zeroed context names no scratch
     assert lib.ff_ctx_merge_finish(a(ctx), a(call), None) == -1
+    assert lib.ff_ctx_gather_mask(None, 16, 16, 2, 10, 10, None) == -1
+    assert lib.ff_ctx_gather_mask(a(ctx), 16, 16, 2, 10, 10, None) == -1      # a zeroed context names no scratch
     for f in ("order", "order_next", "inv", "inv_next", "sim", "member", "dst", "keep", "stats", "stats_host", "ws"):
         setattr(ctx, f, 4096)
     ctx.cap = 1024
