@@ -45,7 +45,8 @@ class FFCtx(C.Structure):
                 ("keep", C.c_void_p), ("stats", C.c_void_p), ("stats_host", C.c_void_p), ("ws", C.c_void_p),
                 ("ws_bytes", C.c_size_t),
                 ("seq", C.c_int64), ("order_len", C.c_int64), ("dirty", C.c_int64), ("in_flight", C.c_int64),
-                ("swaps", C.c_int64)]
+                ("swaps", C.c_int64), ("plan_ready", C.c_int64), ("plan_start", C.c_int64), ("plan_n_img", C.c_int64),
+                ("plan_k", C.c_int64)]
 
 
 class FFMergeCall(C.Structure):
@@ -142,6 +143,9 @@ PROTOTYPES = {
     "ff_ctx_expect_tables": (None, [_vp]),
     "ff_abi_sizeof": (_sz, [_i32]),
     "ff_set_fused_launch": (_i32, [_i32]),
+    "ff_set_fused_prune_plan": (_i32, [_i32]),
+    "ff_ctx_last_query_importance": (_i32, [_vp, _vp, _vp, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f64, _i32, _vp, _vp, _i64, _i64,
+                                            _i64, _vp, _sz, _vp]),
     "ff_merge_step": (_i32, [_vp, _vp, _vp, _i32, _i64, _i64, _i64, _vp, _i64, _i32, _f64, _f64, _f64, _vp, _vp, _vp, _vp,
                              _vp, _vp, _vp, _vp, _i64, C.POINTER(FFAux), _i32, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
 }

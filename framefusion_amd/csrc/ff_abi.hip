@@ -195,7 +195,10 @@ extern "C" int ff_prune_step(const void* hidden, const void* addend, void* hidde
         imp = importance;
         have_tables = true;
     }
-    int rc = ff::launch_plan_prune(imp, w_dtype, S, start, n_img, k, member, dst, keep, stats, ws, ws_bytes, have_tables, st);
+    int rc = FF_OK;
+    // (tables_ready == 2: the importance's producer enqueued the plan as well - ff_ctx_last_query_importance)
+    if (!(tables_ready == 2 && H * num == 1))
+        rc = ff::launch_plan_prune(imp, w_dtype, S, start, n_img, k, member, dst, keep, stats, ws, ws_bytes, have_tables, st);
     if (rc) return rc;
     void *za = nullptr, *zb = nullptr;
     size_t zab = 0, zbb = 0;
@@ -240,6 +243,7 @@ static int ctx_clean(ff_ctx_t* c, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     c->dirty = 0;
     c->order_len = 0;          // stats[NV] / stats[FTN] went with the reset: K0 (or the hinted K1) rebuilds them
+    c->plan_ready = 0;
     return FF_OK;
 }
 
@@ -247,6 +251,7 @@ extern "C" int ff_ctx_reset(ff_ctx_t* c, ff_stream_t stream) {
     if (!c) return FF_ERR_ARG;
     c->order_len = 0;
     c->in_flight = 0;
+    c->plan_ready = 0;
     return ctx_clean(c, (hipStream_t)stream);
 }
 
@@ -270,6 +275,7 @@ static int ctx_begin(ff_ctx_t* c, const ff_merge_call_t* a, bool hinted) {
     int rc = ctx_clean(c, st);
     if (rc) return rc;
     const int order_valid = (a->order_valid && c->order_len == a->L) ? 1 : 0;
+    c->plan_ready = 0;
     c->seq += 1;
     c->dirty = 1;                // until finish has enqueued the kernel that clears the select tables
     c->in_flight = 1;
@@ -418,10 +424,14 @@ extern "C" int ff_ctx_prune(ff_ctx_t* c, const ff_prune_call_t* a) {
     if (rc) return rc;
     if (a->mask && !a->mask_out) return FF_ERR_ARG;
     hipStream_t st = (hipStream_t)a->stream;
+    if (a->tables_ready == 2 &&
+        (c->plan_ready != a->S || c->plan_start != a->start || c->plan_n_img != a->n_img || c->plan_k != a->k || a->H * a->num != 1))
+        return FF_ERR_STATE;       // no plan of THIS selection is waiting in the context
     if (!a->tables_ready) {
         rc = ctx_clean(c, st);     // (tables announced by ff_ctx_expect_tables but not used: start from zero)
         if (rc) return rc;
     }
+    c->plan_ready = 0;
     c->dirty = 1;
     c->order_len = 0;              // the sequence changes and no order is maintained through a prune
     rc = ff_prune_step(a->hidden, a->addend, a->hidden_out, (int)a->dtype, a->S, a->d, a->L_cap, a->attn_w, (int)a->w_dtype,

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_num_sgpr(80)))
             unsigned int old = 0;
             if (threadIdx.x == 0) {
                 if (pa.dbg & 2) old = __hip_atomic_fetch_add(pa.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else old = __hip_atomic_fetch_add(pa.arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                else old = __hip_atomic_fetch_add(pa.arrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             }
             old = (unsigned int)__builtin_amdgcn_readfirstlane((int)old);
             if (old == (unsigned int)pa.n_plan - 1u) {

@@ -174,10 +174,10 @@ __device__ inline bool wave_wait_done(const FusedWait& fw, int bx) {
 // everything the plan writes (member, dst, keep - whole cache lines per plan workgroup - and stats) only `stats` has been
 // READ in this launch before the flag (by the plan workgroups), so only its line can sit stale in an XCD's L2: stats is
 // read with agent-scope loads (stat_word), everything else misses and comes from memory, where the plan's release put it.
-__device__ inline void wait_for_plan(const FusedWait& fw, int bx) {
+__device__ inline void wait_for_plan(const FusedWait& fw, int bx, bool nap = true) {
     if (threadIdx.x == 0) {
         const unsigned long long* f = fw.flags + (size_t)(bx & (kFlagCopies - 1)) * kFlagStride;
-        __builtin_amdgcn_s_sleep(100);
+        if (nap) __builtin_amdgcn_s_sleep(100);        // (~3 us: what is waited for takes longer than that)
         for (int spins = 0;; ++spins) {
             if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == fw.seq) break;
             __builtin_amdgcn_s_sleep(2);

@@ -850,9 +850,8 @@ int launch_plan_merge(const void* sim, int dtype, const int32_t* order, const in
     }
 }
 
-int launch_plan_prune(const void* imp, int dtype, int64_t S, int64_t start, int64_t n_img, int64_t k,
-                      uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats, void* ws, size_t ws_bytes,
-                      bool have_tables, hipStream_t st) {
+// the plan parameters of a prune call (top-k over [start, start + n_img)); n_slices is the launcher's
+PlanParams prune_plan_params(int dtype, int64_t start, int64_t n_img, int64_t k) {
     PlanParams pp;
     pp.mode = 1; pp.lo = (int)start; pp.hi = (int)(start + n_img); pp.k_given = k; pp.sub = 0; pp.ratio_lb = 0;
     pp.thr_key = 0xffffffffu; pp.n_slices = 0;
@@ -860,6 +859,13 @@ int launch_plan_prune(const void* imp, int dtype, int64_t S, int64_t start, int6
     const double guess_value = n_img > 0 ? 1.0 / (double)n_img : 1.0;
     pp.p0_guess = (int)(dtype == FF_F32 ? host_thr_key<FF_F32>(guess_value) >> 24
                         : dtype == FF_BF16 ? host_thr_key<FF_BF16>(guess_value) >> 8 : host_thr_key<FF_F16>(guess_value) >> 8);
+    return pp;
+}
+
+int launch_plan_prune(const void* imp, int dtype, int64_t S, int64_t start, int64_t n_img, int64_t k,
+                      uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats, void* ws, size_t ws_bytes,
+                      bool have_tables, hipStream_t st) {
+    const PlanParams pp = prune_plan_params(dtype, start, n_img, k);
     switch (dtype) {
         case FF_F32: return launch_plan<FF_F32>(imp, pp, have_tables, S, S, nullptr, member, keep, dst, stats, ws, ws_bytes, nullptr, 0, st);
         case FF_BF16: return launch_plan<FF_BF16>(imp, pp, have_tables, S, S, nullptr, member, keep, dst, stats, ws, ws_bytes, nullptr, 0, st);

@@ -555,21 +555,24 @@ class FrameFusion(nn.Module):
         return start, n_img
 
     def _expect_importance(self, S: int, dtype, device):
-        """The attention hook is about to compute the importance of a prune call over S tokens: hand out the
-        workspace (as the `select` argument of utils._launch_last_query) in which the importance kernel
-        accumulates the select tables, and a token _prune recognises the tensor by."""
+        """The attention hook is about to compute the importance of a prune call over S tokens: returns
+        (plan, token) - `plan` = (ctx pointer, start, n_img, k, stream) for ff_ctx_last_query_importance, which accumulates
+        the select tables in this instance's workspace and, where it can, enqueues the prune's plan in the same launch;
+        `token` is what _prune recognises the tensor by.  (None, None) when the prune range does not fit S."""
         with torch.cuda.device(device):
             sc, stream = self._scratch_for(device, S)
             start, n_img = self._prune_range(S)
             if n_img < 0 or start < 0 or start + n_img > S:
                 return None, None
+            k = round(n_img * (1 - self._compute_pruning_ratio(self.sparsity_list, self.cost)))      # main.py:73-76
+            if k < 0 or k > n_img:
+                return None, None
             lib = _lib.load()
             _lib.check(lib.ff_ctx_reset(sc.ctx_ptr, stream), "ff_ctx_reset")    # (zeroes the tables if a call died)
             sc.order_gen = None
-            lib.ff_ctx_expect_tables(sc.ctx_ptr)    # until the prune call has consumed (and cleared) the tables
-            token = (id(sc), sc.seq, S, start, n_img, dtype)
+            token = (id(sc), sc.seq + 1, S, start, n_img, dtype, k)             # (the call below advances the sequence number)
             sc.tables_token = token
-            return (start, start + n_img, sc.ws.data_ptr(), sc.ws_bytes), token
+            return (sc.ctx_ptr, start, n_img, k, stream), token
 
     # ---- prune call: main.py:61-101 ----------------------------------------------------------------
     def _prune(self, hidden_states, position_embeddings, attention_mask, self_attn_weights, residual=None):
@@ -606,7 +609,9 @@ class FrameFusion(nn.Module):
         # select tables of exactly this call in the workspace
         H, num = w.shape[1], w.shape[2]
         tables_ready = int(token is not None and token == sc.tables_token and
-                           token == (id(sc), sc.seq, q_len, start, n_img, w.dtype) and H * num == 1)
+                           token == (id(sc), sc.seq, q_len, start, n_img, w.dtype, k) and H * num == 1)
+        if tables_ready and int(sc.ctx.plan_ready) == q_len:
+            tables_ready = 2                 # the hook's kernel enqueued the plan as well: this call only gathers
         sc.tables_token = None
         # nothing is read back (L_out is known): head mean + select tables, plan, gather - one host call
         out = torch.empty((1, L_out, d), dtype=dtype, device=device)

@@ -27,7 +27,7 @@ def get_attr_by_name(obj: Any, name: str) -> Any:
     return node
 
 
-def _launch_last_query(query, key, num, is_causal, scale, want_weights, want_importance, select=None, bias=None):
+def _launch_last_query(query, key, num, is_causal, scale, want_weights, want_importance, plan=None, bias=None):
     _lib.require_gpu(query, "scaled_dot_product_attention")
     if query.ndim != 4 or key.ndim != 4 or query.shape[0] != 1 or key.shape[0] != 1:
         raise FrameFusionHipError("expected query [1, H, L, dh] and key [1, H_kv, S, dh]")
@@ -57,12 +57,19 @@ def _launch_last_query(query, key, num, is_causal, scale, want_weights, want_imp
     importance = torch.empty(S, dtype=query.dtype, device=dev) if want_importance else None
     ws_bytes = int(lib.ff_last_query_workspace_bytes(code, H, num, S, dh))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)          # (scores + statistics: dead when the call returns)
-    sel_lo, sel_hi, sel_ws, sel_bytes = select if select is not None else (0, 0, None, 0)
+    if plan is not None:
+        # the attention hook of an instance whose prune call comes next: importance + select tables (+ the prune's plan)
+        ctx_ptr, start, n_img, k_keep, stream = plan
+        rc = lib.ff_ctx_last_query_importance(ctx_ptr, q_last.data_ptr(), k.data_ptr(), code, H, H_kv, num, S, dh, sh, ss,
+                                              float(factor), 1 if is_causal else 0, bias.data_ptr() if bias is not None else None,
+                                              importance.data_ptr(), start, n_img, k_keep, ws.data_ptr(), ws_bytes, stream or 0)
+        _lib.check(rc, "ff_ctx_last_query_importance")
+        return weights, importance
     rc = lib.ff_last_query_attention(q_last.data_ptr(), k.data_ptr(), code, H, H_kv, num, S, dh, sh, ss, float(factor),
                                      1 if is_causal else 0, bias.data_ptr() if bias is not None else None,
                                      weights.data_ptr() if want_weights else None,
                                      importance.data_ptr() if want_importance else None,
-                                     sel_lo, sel_hi, sel_ws, sel_bytes,
+                                     0, 0, None, 0,
                                      ws.data_ptr(), ws_bytes, _lib.stream_ptr())
     _lib.check(rc, "ff_last_query_attention")
     return weights, importance
@@ -99,12 +106,13 @@ def last_query_importance(query, key, num=1, is_causal=True, scale=None, framefu
     """Fused form for the attention hook: the head/query mean of the weights
     above, shaped [1, 1, 1, S] so that FrameFusion.forward's own mean (main.py:70) is the identity.
     With `framefusion` (the instance whose prune call will consume the result) the importance kernel
-    also accumulates the select tables of that call in the instance's workspace: the prune is then
-    plan + gather, nothing else."""
-    select, token = None, None
+    also accumulates the select tables of that call in the instance's workspace and - 16-bit dtypes, at most
+    65 536 tokens - goes on as the prune's plan in the same launch (ff_ctx_last_query_importance): the prune
+    call is then a gather, nothing else."""
+    plan, token = None, None
     if framefusion is not None and query.is_cuda:
-        select, token = framefusion._expect_importance(key.shape[2], query.dtype, query.device)
-    _, imp = _launch_last_query(query, key, num, is_causal, scale, False, True, select)
+        plan, token = framefusion._expect_importance(key.shape[2], query.dtype, query.device)
+    _, imp = _launch_last_query(query, key, num, is_causal, scale, False, True, plan)
     out = imp[None, None, None, :]
     if token is not None:
         out._ff_tables = token

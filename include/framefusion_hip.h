@@ -388,6 +388,8 @@ typedef struct ff_ctx {
     int64_t dirty;         /* a call died half-way: workspace + stats are reset by the next call        */
     int64_t in_flight;     /* 1 between ff_ctx_merge_begin and ff_ctx_merge_finish                      */
     int64_t swaps;         /* number of order <-> order_next exchanges so far (owner mirrors its views) */
+    int64_t plan_ready;    /* S of the prune call whose PLAN ff_ctx_last_query_importance already enqueued (0: none);  */
+    int64_t plan_start, plan_n_img, plan_k;   /* ... and the selection it was made for (ABI v8)                        */
 } ff_ctx_t;
 
 /* Inputs of one merge call (main.py:104-138).  The same structure goes to begin and finish; the
@@ -457,7 +459,8 @@ typedef struct ff_prune_call {
     void* hidden_out;            /* [L_cap, d]                                                          */
     const void* attn_w;          /* [H, num, S] of w_dtype, or the [S] importance when H * num == 1     */
     int64_t dtype, S, d, L_cap, w_dtype, H, num;
-    int64_t tables_ready;        /* the importance's producer filled the select tables in ctx->ws       */
+    int64_t tables_ready;        /* 1: the importance's producer filled the select tables in ctx->ws;
+                                    2: ... and enqueued the plan (ctx->plan_ready == S): gather only         */
     int64_t start, n_img, k;
     ff_stream_t stream;
     int64_t n_aux;
@@ -467,6 +470,22 @@ typedef struct ff_prune_call {
     int64_t mask_elem_bytes;
 } ff_prune_call_t;
 int ff_ctx_prune(ff_ctx_t* ctx, const ff_prune_call_t* call);
+
+/* The attention hook of a context whose prune call comes next (main.py:61-101 fed by utils.py:27-57): the importance of
+ * the last `num` queries as ff_last_query_attention computes it, the select tables of importance[start, start + n_img),
+ * AND - when ff_set_fused_prune_plan(1); 16-bit dtypes, S <= 65 536, a tiled head size - the prune's plan (top-k of `k` with the lowest-index tie rule,
+ * member / keep / dst / stats of the context) in the same launch as the normalisation: the workgroups that finish the
+ * importances go on as the plan once all of them have arrived (csrc/ff_importance.hip, k_lq_finish_plan).  ctx->plan_ready
+ * says which happened (S: the plan is in the context; 0: tables only).  The prune call that follows passes tables_ready =
+ * 2 (plan_ready == S: it only gathers) or 1.  The context must be clean (ff_ctx_reset first). */
+int ff_ctx_last_query_importance(ff_ctx_t* ctx, const void* q_last, const void* k, int dtype, int64_t H, int64_t H_kv, int64_t num,
+                                 int64_t S, int64_t dh, int64_t k_head_stride, int64_t k_key_stride, double scale, int causal,
+                                 const void* bias, void* importance, int64_t start, int64_t n_img, int64_t k_keep,
+                                 void* ws, size_t ws_bytes, ff_stream_t stream);
+/* 0 (default; FF_FUSED_PRUNE_PLAN=1 in the environment makes it 1): ff_ctx_last_query_importance fills the tables only,
+ * the prune call launches its plan; 1: the plan goes out with the importance kernel as described above (same results;
+ * measured no faster, profiles/EXPERIMENTS.md 4.12).  Returns the previous value (on < 0: only reports). */
+int ff_set_fused_prune_plan(int on);
 
 /* The caller replaced patch_type / starts a new sample: forget the order (and reset the workspace
  * if a call died half-way).  Enqueues at most two memsets on `stream`. */

@@ -74,6 +74,7 @@ def test_error_strings_and_workspace():
     assert lib.ff_last_query_workspace_bytes(bf16, 6, 4, 1000, 24) == 2 * 6 * 4 * 1000 * 4           # odd head size
     assert lib.ff_last_query_workspace_bytes(bf16, 28, 256, 1000, 128) == 2 * 28 * 256 * 1000 * 4    # 7168 rows
     assert lib.ff_set_fused_launch(-1) in (0, 1)                                                      # (reports only)
+    assert lib.ff_set_fused_prune_plan(-1) in (0, 1)
 
 
 def test_argument_validation_without_gpu():
@@ -137,6 +138,8 @@ def test_context_calls_validate_before_any_hip_call():
     assert lib.ff_ctx_merge_begin(a(ctx), a(call)) == -1           # a zeroed context names no scratch
     assert lib.ff_ctx_merge_finish(a(ctx), a(call), None) == -1
     assert lib.ff_ctx_gather_mask(None, 16, 16, 2, 10, 10, None) == -1
+    assert lib.ff_ctx_last_query_importance(None, 16, 16, 1, 4, 4, 1, 10, 64, 0, 0, 0.1, 1, None, 16, 0, 10, 5, 16, 1 << 20, None) == -1
+    assert lib.ff_ctx_last_query_importance(a(ctx), 16, 16, 1, 4, 4, 1, 10, 64, 0, 0, 0.1, 1, None, 16, 0, 10, 5, 16, 1 << 20, None) == -1
     assert lib.ff_ctx_gather_mask(a(ctx), 16, 16, 2, 10, 10, None) == -1      # a zeroed context names no scratch
     for f in ("order", "order_next", "inv", "inv_next", "sim", "member", "dst", "keep", "stats", "stats_host", "ws"):
         setattr(ctx, f, 4096)

@@ -235,3 +235,23 @@ def test_bf16_divide_equals_multiply_by_reciprocal_exhaustively():
     assert n == 1288 and bad == 0
     bad16, _ = mismatches(torch.float16, torch.int16)
     assert bad16 > 0                                   # the reason fp16 keeps the IEEE division
+
+
+def test_outer_stride_of_token_dense_views():
+    """main._outer_stride / _token_dense: which position tensors the merge kernel reads in place (ff_aux_t.src_outer_bytes)
+    and which need a copy - no GPU involved."""
+    from framefusion_amd.main import _outer_stride, _token_dense
+    full = torch.zeros(3, 1, 10, 4)
+    assert _outer_stride(full) == 40 and _token_dense(full) is full
+    view = full.narrow(2, 0, 6)                                  # what a merge call returns for an M-RoPE table
+    assert not view.is_contiguous() and _outer_stride(view) == 40
+    assert _token_dense(view) is view and view._ff_outer_bytes == 40 * 4
+    flat = torch.zeros(1, 10, 4).narrow(1, 0, 6)                 # [1, L_out, dh] of a [1, L_cap, dh] buffer: contiguous as it is
+    assert flat.is_contiguous() and _outer_stride(flat) == 24
+    two = torch.zeros(2, 3, 10, 4)                               # two leading dims, one uniform stride: collapsible
+    assert _outer_stride(two) == 40 and _outer_stride(two.narrow(2, 2, 5)) == 40
+    assert _outer_stride(two[:, ::2]) is None                    # leading dims 120 and 80 apart: not one stride
+    assert _outer_stride(full.transpose(2, 3)) is None           # rows not dense
+    assert _outer_stride(full[..., ::2]) is None
+    gathered = _token_dense(full[..., ::2])
+    assert gathered.is_contiguous() and gathered.shape == (3, 1, 10, 2)
