@@ -17,5 +17,6 @@ for cfg in 7b c3 c5 c5topk c2thr; do
     python tools/timeline_cascade.py "$trace" "$n"
   } > "$out/${tag}_timeline_$cfg.txt"
   cat "$out/${tag}_timeline_$cfg.txt"
+  cp "$out/${tag}_timeline_$cfg.txt" profiles/      # (what bench.py reads extra.configs[*].kernel_us from; committed from gpurun_out afterwards)
   rm -rf "$out/prof_$cfg"
 done
