@@ -15,11 +15,19 @@
 // that order for SAFETY: a waiter gives up after ~0.1 s, sets FF_ERR_BIT_BARRIER and returns - the host then falls back
 // to the three-launch form (ff_abi.hip).
 //
-// Hand-over.  Each plan workgroup, after its last store: barrier, then ONE lane does an acq_rel fetch_add at agent scope
-// on the arrival counter (the release writes this XCD's dirty L2 lines back - the plan wrote ~0.4 MB in all).  The last
-// arriver resets the counter and stores the call's sequence number (host-side counter of the context: strictly
-// increasing, so the flags never need clearing) into 64 flag words 128 bytes apart.  A waiting workgroup polls ONE of
-// the copies with one lane (relaxed, agent scope: the load goes past the non-coherent L2), then every wave acquires.
+// Hand-over (two of them, ff_merge_body.h).  DECISION: plan workgroup 0 publishes (k-th key, tie slot, nv) as soon as it
+// has them; a main workgroup derives its member flags from the similarities itself and requests its first rows.  DONE: each
+// plan workgroup, after its last store: barrier, then ONE lane does a RELEASE fetch_add at agent scope on the arrival
+// counter (the release writes this XCD's dirty L2 lines back - the plan wrote ~0.4 MB in all); the last arriver resets
+// the counter and stores the call's sequence number (host-side counter of the context: strictly increasing, so the flags
+// never need clearing) into 64 flag words 128 bytes apart.  A waiter polls ONE of the copies (relaxed, agent scope: the
+// load goes past the non-coherent L2).  NO acquire fence on the waiting side: `buffer_inv sc1` in every wave of the
+// streaming pass cost 100 us; the one line that can be stale (stats) is read with agent-scope loads instead.
+//
+// Measured (profiles/r04_fused.txt, profiles/EXPERIMENTS.md 4.1-4.6): 141.8 us (DONE only) / 145.8 us (with the early
+// decision) against 137.6-138.2 us for two launches at 64 x 576 x 4096 - the plan runs 3 us slower inside a busy grid, the
+// hand-over costs 1.9 us, and that is more than the launch + dispatch it hides.  OFF unless FF_FUSED=1 /
+// ff_set_fused_launch(1); bit-exact either way (tests/test_gpu_random_sweep.py).
 #include <stdio.h>
 #include <stdlib.h>
 
