@@ -29,7 +29,7 @@ STAT_ERROR = 11
 ERR_BIT_BARRIER, ERR_BIT_LAYOUT = 1, 2
 STAT_WORDS = 32
 MAX_AUX = 4
-ABI_VERSION = 8
+ABI_VERSION = 9
 ERR_DEVICE, ERR_STATE = -5, -6
 
 
@@ -45,8 +45,7 @@ class FFCtx(C.Structure):
                 ("keep", C.c_void_p), ("stats", C.c_void_p), ("stats_host", C.c_void_p), ("ws", C.c_void_p),
                 ("ws_bytes", C.c_size_t),
                 ("seq", C.c_int64), ("order_len", C.c_int64), ("dirty", C.c_int64), ("in_flight", C.c_int64),
-                ("swaps", C.c_int64), ("plan_ready", C.c_int64), ("plan_start", C.c_int64), ("plan_n_img", C.c_int64),
-                ("plan_k", C.c_int64)]
+                ("swaps", C.c_int64), ("last_L", C.c_int64), ("last_l_out", C.c_int64)]
 
 
 class FFMergeCall(C.Structure):
@@ -61,7 +60,7 @@ class FFMergeCall(C.Structure):
                 ("mask", C.c_void_p), ("mask_out", C.c_void_p), ("mask_elem_bytes", C.c_int64)]
 
 
-# head of ff_merge_call_t up to and including n_aux; aux entries (4 x 8 bytes each) and the mask triple follow
+# head of ff_merge_call_t up to and including n_aux; MAX_AUX aux entries (AUX_ENTRY: 5 x 8 bytes each) and the mask triple follow
 MERGE_CALL_HEAD = struct.Struct("=4Q6q3d4qQq")
 MERGE_CALL_AUX_OFFSET = MERGE_CALL_HEAD.size
 AUX_ENTRY = struct.Struct("=2Q3q")
@@ -142,8 +141,6 @@ PROTOTYPES = {
     "ff_ctx_reset": (_i32, [_vp, _vp]),
     "ff_ctx_expect_tables": (None, [_vp]),
     "ff_abi_sizeof": (_sz, [_i32]),
-    "ff_set_fused_launch": (_i32, [_i32]),
-    "ff_set_fused_prune_plan": (_i32, [_i32]),
     "ff_ctx_last_query_importance": (_i32, [_vp, _vp, _vp, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f64, _i32, _vp, _vp, _i64, _i64,
                                             _i64, _vp, _sz, _vp]),
     "ff_merge_step": (_i32, [_vp, _vp, _vp, _i32, _i64, _i64, _i64, _vp, _i64, _i32, _f64, _f64, _f64, _vp, _vp, _vp, _vp,

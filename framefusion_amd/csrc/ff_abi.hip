@@ -27,13 +27,6 @@ int launch_merge_compact(const void* hidden, const void* addend, void* hidden_ou
 int launch_similarity_any(const void* hidden, const void* addend, int dtype, int64_t L, int64_t d, const int64_t* ptype,
                           int32_t* order, int32_t* inv, int64_t* stats, void* sim, int* l0, int* t16_end, double thr,
                           int64_t hint_pre, int64_t hint_patches, int64_t hint_frames, hipStream_t st);
-bool fused_applies(int dtype, int64_t L, const int32_t* inv, const int32_t* order, const int64_t* stats);
-void fused_disable();
-int launch_plan_merge_fused(const void* sim, int dtype, const int32_t* order, const int32_t* inv, int64_t L, double thr, double sub,
-                            double ratio_lb, long long force_k, uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
-                            void* ws, size_t ws_bytes, int64_t* host_mapped, int64_t seq, const void* hidden, const void* addend,
-                            void* hidden_out, int64_t d, int64_t L_cap, int fold, const ff_aux_t* aux_host, int n_aux,
-                            int32_t* order_next, int32_t* inv_next, void* zero_a, size_t zero_a_bytes, hipStream_t st);
 int launch_head_mean(const void* attn_w, int dtype, int64_t H, int64_t num, int64_t S, void* importance,
                      int64_t lo, int64_t hi, int* l0, int* t16_end, hipStream_t st);
 }  // namespace ff
@@ -98,7 +91,7 @@ static int merge_finish(const void* hidden, const void* addend, void* hidden_out
                         const int32_t* order, const int32_t* inv, const void* sim, uint8_t* member, int32_t* dst,
                         uint8_t* keep, int64_t* stats, int64_t* stats_host_mapped, int64_t seq, const ff_aux_t* aux_host,
                         int n_aux, int32_t* order_next, int32_t* inv_next, void* ws, size_t ws_bytes,
-                        ff_stream_t stream, bool allow_fused = false) {
+                        ff_stream_t stream) {
     if (!hidden || !hidden_out || !order || !inv || !sim || !member || !dst || !keep || !stats || !ws) return FF_ERR_ARG;
     if ((order_next == nullptr) != (inv_next == nullptr)) return FF_ERR_ARG;
     if (ws_bytes < ff_workspace_bytes(L, 1)) return FF_ERR_WORKSPACE;
@@ -117,12 +110,6 @@ static int merge_finish(const void* hidden, const void* addend, void* hidden_out
     void *za, *zb;
     size_t zab, zbb;
     ff::table_regions(ws, ws_bytes, L, &za, &zab, &zb, &zbb);
-    // one launch for plan + merge (ff_fused.hip) where it applies: 16-bit activations, <= 65 536 tokens, a call context
-    // (its sequence numbers strictly increase, which the hand-over flag relies on)
-    if (allow_fused && order_next && ff::fused_applies(dtype, L, inv, order, stats))
-        return ff::launch_plan_merge_fused(sim, dtype, order, inv, L, threshold, sub, ratio_lb, force_k, member, dst, keep, stats, ws,
-                                           ws_bytes, stats_host_mapped, seq, hidden, addend, hidden_out, d, L_cap, fold, aux_host,
-                                           n_aux, order_next, inv_next, za, zab, (hipStream_t)stream);
     int rc = ff::launch_plan_merge(sim, dtype, order, inv, L, threshold, sub, ratio_lb, member, dst, keep, stats, ws, ws_bytes,
                                    true, stats_host_mapped, seq, (hipStream_t)stream, force_k);
     if (rc) return rc;
@@ -195,10 +182,7 @@ extern "C" int ff_prune_step(const void* hidden, const void* addend, void* hidde
         imp = importance;
         have_tables = true;
     }
-    int rc = FF_OK;
-    // (tables_ready == 2: the importance's producer enqueued the plan as well - ff_ctx_last_query_importance)
-    if (!(tables_ready == 2 && H * num == 1))
-        rc = ff::launch_plan_prune(imp, w_dtype, S, start, n_img, k, member, dst, keep, stats, ws, ws_bytes, have_tables, st);
+    int rc = ff::launch_plan_prune(imp, w_dtype, S, start, n_img, k, member, dst, keep, stats, ws, ws_bytes, have_tables, st);
     if (rc) return rc;
     void *za = nullptr, *zb = nullptr;
     size_t zab = 0, zbb = 0;
@@ -243,7 +227,7 @@ static int ctx_clean(ff_ctx_t* c, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     c->dirty = 0;
     c->order_len = 0;          // stats[NV] / stats[FTN] went with the reset: K0 (or the hinted K1) rebuilds them
-    c->plan_ready = 0;
+    c->last_L = 0;
     return FF_OK;
 }
 
@@ -251,7 +235,7 @@ extern "C" int ff_ctx_reset(ff_ctx_t* c, ff_stream_t stream) {
     if (!c) return FF_ERR_ARG;
     c->order_len = 0;
     c->in_flight = 0;
-    c->plan_ready = 0;
+    c->last_L = 0;
     return ctx_clean(c, (hipStream_t)stream);
 }
 
@@ -275,7 +259,7 @@ static int ctx_begin(ff_ctx_t* c, const ff_merge_call_t* a, bool hinted) {
     int rc = ctx_clean(c, st);
     if (rc) return rc;
     const int order_valid = (a->order_valid && c->order_len == a->L) ? 1 : 0;
-    c->plan_ready = 0;
+    c->last_L = 0;
     c->seq += 1;
     c->dirty = 1;                // until finish has enqueued the kernel that clears the select tables
     c->in_flight = 1;
@@ -336,7 +320,7 @@ static int ctx_finish_enqueue(ff_ctx_t* c, const ff_merge_call_t* a) {
     int rc = merge_finish(a->hidden, a->addend, a->hidden_out, (int)a->dtype, a->L, a->d, a->L_cap, a->threshold, a->sub,
                           a->ratio_lb, a->force_k < 0 ? -1 : (long long)a->force_k, (int)a->fold, c->order, c->inv, c->sim,
                           c->member, c->dst, c->keep, c->stats, c->stats_host, c->seq, a->aux, (int)a->n_aux, c->order_next,
-                          c->inv_next, c->ws, c->ws_bytes, a->stream, true);
+                          c->inv_next, c->ws, c->ws_bytes, a->stream);
     if (rc) return rc;
     c->dirty = 0;
     return rc;
@@ -373,8 +357,6 @@ extern "C" int ff_ctx_merge_finish(ff_ctx_t* c, const ff_merge_call_t* a, ff_mer
             continue;
         }
         if (err) {
-            // a workgroup of the fused plan + merge launch waited in vain (this call's or the previous one's): three launches from now on
-            if (err & FF_ERR_BIT_BARRIER) ff::fused_disable();
             c->dirty = 1; c->order_len = 0;
             return FF_ERR_DEVICE;
         }
@@ -402,6 +384,8 @@ extern "C" int ff_ctx_merge_finish(ff_ctx_t* c, const ff_merge_call_t* a, ff_mer
     } else {
         c->order_len = a->L;       // nothing folded: the order describes the unchanged sequence
     }
+    c->last_L = a->L;              // (what ff_ctx_gather_mask may be asked for)
+    c->last_l_out = r->l_out;
     return FF_OK;
 }
 
@@ -415,6 +399,8 @@ extern "C" int ff_ctx_gather_mask(ff_ctx_t* c, const void* mask, void* mask_out,
                                   ff_stream_t stream) {
     int rc = ctx_check(c, L);
     if (rc) return rc;
+    // only behind the merge call whose keep set is still in the context: same L, finished, folded something, nothing begun since
+    if (c->in_flight || c->dirty || c->last_L != L || L == 0 || c->last_l_out == L || L_cap < c->last_l_out) return FF_ERR_STATE;
     return ff_gather_mask(mask, mask_out, elem_bytes, L, L_cap, c->dst, c->stats, ff::ws_scratch_ints(c->ws, c->cap), stream);
 }
 
@@ -424,14 +410,12 @@ extern "C" int ff_ctx_prune(ff_ctx_t* c, const ff_prune_call_t* a) {
     if (rc) return rc;
     if (a->mask && !a->mask_out) return FF_ERR_ARG;
     hipStream_t st = (hipStream_t)a->stream;
-    if (a->tables_ready == 2 &&
-        (c->plan_ready != a->S || c->plan_start != a->start || c->plan_n_img != a->n_img || c->plan_k != a->k || a->H * a->num != 1))
-        return FF_ERR_STATE;       // no plan of THIS selection is waiting in the context
+    if (a->tables_ready != 0 && a->tables_ready != 1) return FF_ERR_ARG;
     if (!a->tables_ready) {
         rc = ctx_clean(c, st);     // (tables announced by ff_ctx_expect_tables but not used: start from zero)
         if (rc) return rc;
     }
-    c->plan_ready = 0;
+    c->last_L = 0;
     c->dirty = 1;
     c->order_len = 0;              // the sequence changes and no order is maintained through a prune
     rc = ff_prune_step(a->hidden, a->addend, a->hidden_out, (int)a->dtype, a->S, a->d, a->L_cap, a->attn_w, (int)a->w_dtype,

@@ -16,8 +16,6 @@
 #include <atomic>
 
 #include "ff_common.h"
-#include "ff_merge_body.h"      // the in-grid hand-over (flags, wait_for_plan)
-#include "ff_plan_fast.h"
 
 namespace ff {
 
@@ -695,53 +693,6 @@ __global__ __launch_bounds__(256) void k_lq_finish(const void* __restrict__ scor
     lq_finish_body<DT, KG>(scores, tstats, rows_total, pitch, tiles, S, weights, imp, lo, hi, l0, t16_end, xch, publish, row_ms_dyn);
 }
 
-// ---- finish + the prune's plan in ONE launch (the attention hook of a context whose prune call is due) ----------------
-// The finish above ends with the select tables of the importances complete - which is all the prune's plan kernel waits
-// for.  Here the first ceil(S / 256) workgroups go on as that plan (plan_fast_body, prune mode) once EVERY workgroup has
-// arrived (release + counter; the last arriver raises the flag the plan workgroups poll - the hand-over of ff_fused.hip),
-// and the prune call that follows only gathers.
-// Measured (profiles/EXPERIMENTS.md 4.12): 21.4 us against 13.8 + 7.2 at the Qwen2-VL shape, 30.1 against 14.1 + 9.2 at the
-// 72B shape (548 arrivals on one counter) - no faster, so it is OFF unless ff_set_fused_prune_plan(1) / FF_FUSED_PRUNE_PLAN=1;
-// kept because it is bit-exact and tested, and because ff_ctx_last_query_importance is the hook's entry point either way.
-struct PlanHook {
-    PlanParams pp;                       // prune mode; n_slices set by the launcher
-    uint8_t* member;
-    uint8_t* keep;
-    int32_t* dst;
-    int64_t* stats;
-    unsigned long long* agg;
-    uint32_t* tagword;
-    unsigned int* arrive;
-    unsigned long long* flags;
-    long long seq;
-    int n_plan;
-};
-
-template <int DT, int KG>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_lq_finish_plan(
-    const void* __restrict__ scores, const float2* __restrict__ tstats, int rows_total, int pitch, int tiles, int S,
-    void* __restrict__ imp, int* __restrict__ l0, int* t16_end, unsigned long long* __restrict__ xch, int publish, const PlanHook hk) {
-    static_assert(Act<DT>::kBytes == 2, "the fast plan: 16-bit values");
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
-    lq_finish_body<DT, KG>(scores, tstats, rows_total, pitch, tiles, S, nullptr, imp, hk.pp.lo, hk.pp.hi, l0, t16_end, xch, publish,
-                           (float*)lds_dyn);
-    __syncthreads();                               // my importances and table atomics are issued and acknowledged
-    if (threadIdx.x < kWave) {
-        unsigned int old = 0;
-        if (threadIdx.x == 0) old = __hip_atomic_fetch_add(hk.arrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        old = (unsigned int)__builtin_amdgcn_readfirstlane((int)old);
-        if (old == gridDim.x - 1u) {
-            if (threadIdx.x == 0) __hip_atomic_store(hk.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(hk.flags + (size_t)threadIdx.x * kFlagStride, (unsigned long long)hk.seq, __ATOMIC_RELEASE,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    if ((int)blockIdx.x >= hk.n_plan) return;
-    wait_for_plan(FusedWait{hk.flags, (unsigned long long)hk.seq, hk.stats, nullptr, 0u, 0, nullptr}, (int)blockIdx.x, false);
-    plan_fast_body<DT, kRowSlicesLds, 256>(imp, S, hk.pp, l0, t16_end, hk.stats, nullptr, S, hk.member, hk.keep, hk.dst, hk.agg,
-                                           hk.tagword, nullptr, 0, lds_dyn, (int)blockIdx.x, hk.n_plan);
-}
-
 template <int DT>
 static int launch_lq_general(const void* q, const void* k, KStrides ks, int64_t H, int64_t H_kv, int64_t num, int64_t S, int64_t dh,
                              double scale, int causal, const void* bias, void* weights, void* importance, void* ws, int64_t lo, int64_t hi,
@@ -763,26 +714,9 @@ static int launch_lq_general(const void* q, const void* k, KStrides ks, int64_t 
 
 template <int DT>
 static int launch_lq_finish(void* scores, float2* tstats, unsigned long long* xch, int rows_total, int pitch, int tiles, int64_t S, void* weights,
-                            void* importance, int64_t lo, int64_t hi, int* l0, int* t16_end, hipStream_t st, PlanHook* hook = nullptr) {
+                            void* importance, int64_t lo, int64_t hi, int* l0, int* t16_end, hipStream_t st) {
     const int words = pitch * Act<DT>::kBytes / 16;              // 16-byte words of one key's scores
     const size_t lds = (size_t)rows_total * 2 * sizeof(float);
-    if constexpr (Act<DT>::kBytes == 2) {
-        if (hook && importance && l0 && !weights && S <= (int64_t)kRowSlicesLds * kSelSlice) {
-            static const int publish2 = getenv("FF_LQ_TEST_NO_PUBLISH") ? 0 : 1;
-            hook->pp.n_slices = (int)((S + kSelSlice - 1) / kSelSlice);
-            hook->n_plan = (int)((S + 255) / 256);
-            const size_t lds2 = std::max(lds, plan_fast_lds_bytes(hook->pp.n_slices, 256));
-#define FF_LQ_FINP(KG)                                                                                                            \
-    hipLaunchKernelGGL((k_lq_finish_plan<DT, KG>), dim3((unsigned)((S * KG + 255) / 256)), dim3(256), lds2, st, (const void*)scores, \
-                       (const float2*)tstats, rows_total, pitch, tiles, (int)S, importance, l0, t16_end, xch, publish2, *hook)
-            if (words >= 8) FF_LQ_FINP(4);
-            else if (words >= 4) FF_LQ_FINP(2);
-            else FF_LQ_FINP(1);
-#undef FF_LQ_FINP
-            hook->n_plan = -hook->n_plan;                                  // (tells the caller the plan was enqueued)
-            return (int)hipGetLastError();
-        }
-    }
     // FF_LQ_TEST_NO_PUBLISH (tests only): the row owners stay silent, every workgroup runs into its timeout and folds the
     // rows itself - the results must be the same bits (tests/test_gpu_parity.py::test_importance_owner_timeout_same_bits)
     static const int publish = getenv("FF_LQ_TEST_NO_PUBLISH") ? 0 : 1;
@@ -845,7 +779,7 @@ static int launch_lq_dot(const void* q, const void* k, KStrides ks, int64_t H, i
 template <int DT>
 static int launch_lq(const void* q, const void* k, KStrides ks, int64_t H, int64_t H_kv, int64_t num, int64_t S, int64_t dh,
                      double scale, int causal, const void* bias, void* weights, void* importance, void* ws, int64_t lo, int64_t hi,
-                     int* l0, int* t16_end, hipStream_t st, PlanHook* hook = nullptr) {
+                     int* l0, int* t16_end, hipStream_t st) {
     constexpr int kB = Act<DT>::kBytes;
     const int64_t lpk = dh * kB / 16;
     if (!lq_tiled(kB, H, num, dh)) return launch_lq_general<DT>(q, k, ks, H, H_kv, num, S, dh, scale, causal, bias, weights, importance, ws, lo, hi, l0, t16_end, st);
@@ -866,7 +800,7 @@ static int launch_lq(const void* q, const void* k, KStrides ks, int64_t H, int64
         if ((dh == 64 || dh == 128) && rows <= 8) {
             const int G = dh == 64 ? launch_lq_dot<DT, 1>(q, k, ks, H, H_kv, num, S, (float)scale, causal, bias, pitch, scores, tstats, xch, rows_total, st)
                                    : launch_lq_dot<DT, 2>(q, k, ks, H, H_kv, num, S, (float)scale, causal, bias, pitch, scores, tstats, xch, rows_total, st);
-            return launch_lq_finish<DT>(scores, tstats, xch, rows_total, pitch, G, S, weights, importance, lo, hi, l0, t16_end, st, hook);
+            return launch_lq_finish<DT>(scores, tstats, xch, rows_total, pitch, G, S, weights, importance, lo, hi, l0, t16_end, st);
         }
         if (dh == 64 || dh == 128 || dh == 256) {
             const int64_t zg = (rows + 31) / 32;
@@ -880,7 +814,7 @@ static int launch_lq(const void* q, const void* k, KStrides ks, int64_t H, int64
             else if (dh == 128) FF_LQ_MFMA(8);
             else FF_LQ_MFMA(16);
 #undef FF_LQ_MFMA
-            return launch_lq_finish<DT>(scores, tstats, xch, rows_total, pitch, tiles_m, S, weights, importance, lo, hi, l0, t16_end, st, hook);
+            return launch_lq_finish<DT>(scores, tstats, xch, rows_total, pitch, tiles_m, S, weights, importance, lo, hi, l0, t16_end, st);
         }
     }
     const dim3 grid((unsigned)tiles, (unsigned)H_kv, (unsigned)((rows + kLqRows - 1) / kLqRows));
@@ -897,7 +831,7 @@ static int launch_lq(const void* q, const void* k, KStrides ks, int64_t H, int64
         default: FF_LQ_TILE(64);
     }
 #undef FF_LQ_TILE
-    return launch_lq_finish<DT>(scores, tstats, xch, rows_total, pitch, tiles, S, weights, importance, lo, hi, l0, t16_end, st, hook);
+    return launch_lq_finish<DT>(scores, tstats, xch, rows_total, pitch, tiles, S, weights, importance, lo, hi, l0, t16_end, st);
 }
 
 }  // namespace ff
@@ -923,7 +857,7 @@ extern "C" size_t ff_last_query_workspace_bytes(int dtype, int64_t H, int64_t nu
 static int lq_attention(const void* q_last, const void* k, int dtype, int64_t H, int64_t H_kv,
                         int64_t num, int64_t S, int64_t dh, int64_t k_head_stride, int64_t k_key_stride,
                         double scale, int causal, const void* bias, void* weights, void* importance, int64_t sel_lo, int64_t sel_hi, void* sel_ws,
-                        size_t sel_ws_bytes, void* ws, size_t ws_bytes, ff_stream_t stream, ff::PlanHook* hook) {
+                        size_t sel_ws_bytes, void* ws, size_t ws_bytes, ff_stream_t stream) {
     if (!q_last || !k || !ws || H < 1 || H_kv < 1 || num < 1 || S < 1 || dh < 1) return FF_ERR_ARG;
     if (H % H_kv) return FF_ERR_ARG;
     if (!weights && !importance) return FF_ERR_ARG;
@@ -951,8 +885,8 @@ static int lq_attention(const void* q_last, const void* k, int dtype, int64_t H,
     hipStream_t st = (hipStream_t)stream;
     switch (dtype) {
         case FF_F32: return ff::launch_lq<FF_F32>(q_last, k, ks, H, H_kv, num, S, dh, scale, causal, bias, weights, importance, ws, sel_lo, sel_hi, l0, t16_end, st);
-        case FF_BF16: return ff::launch_lq<FF_BF16>(q_last, k, ks, H, H_kv, num, S, dh, scale, causal, bias, weights, importance, ws, sel_lo, sel_hi, l0, t16_end, st, hook);
-        default: return ff::launch_lq<FF_F16>(q_last, k, ks, H, H_kv, num, S, dh, scale, causal, bias, weights, importance, ws, sel_lo, sel_hi, l0, t16_end, st, hook);
+        case FF_BF16: return ff::launch_lq<FF_BF16>(q_last, k, ks, H, H_kv, num, S, dh, scale, causal, bias, weights, importance, ws, sel_lo, sel_hi, l0, t16_end, st);
+        default: return ff::launch_lq<FF_F16>(q_last, k, ks, H, H_kv, num, S, dh, scale, causal, bias, weights, importance, ws, sel_lo, sel_hi, l0, t16_end, st);
     }
 }
 
@@ -961,33 +895,11 @@ extern "C" int ff_last_query_attention(const void* q_last, const void* k, int dt
                                        double scale, int causal, const void* bias, void* weights, void* importance, int64_t sel_lo, int64_t sel_hi, void* sel_ws,
                                        size_t sel_ws_bytes, void* ws, size_t ws_bytes, ff_stream_t stream) {
     return lq_attention(q_last, k, dtype, H, H_kv, num, S, dh, k_head_stride, k_key_stride, scale, causal, bias, weights, importance, sel_lo,
-                        sel_hi, sel_ws, sel_ws_bytes, ws, ws_bytes, stream, nullptr);
+                        sel_hi, sel_ws, sel_ws_bytes, ws, ws_bytes, stream);
 }
 
-namespace ff {
-PlanParams prune_plan_params(int dtype, int64_t start, int64_t n_img, int64_t k);
-uint32_t* ws_tag(void* ws);
-unsigned long long* ws_agg(void* ws);
-unsigned int* ws_arrive(void* ws);
-unsigned long long* ws_flags(void* ws);
-static std::atomic<int> g_fused_prune_plan{-1};
-static int fused_prune_plan_enabled() {
-    int on = g_fused_prune_plan.load(std::memory_order_relaxed);
-    if (on < 0) {
-        const char* e = getenv("FF_FUSED_PRUNE_PLAN");
-        on = (e && e[0] == '1') ? 1 : 0;          // off unless asked for: measured no faster (profiles/EXPERIMENTS.md 4.12)
-        g_fused_prune_plan.store(on, std::memory_order_relaxed);
-    }
-    return on;
-}
-}  // namespace ff
-
-extern "C" int ff_set_fused_prune_plan(int on) {
-    const int prev = ff::fused_prune_plan_enabled();
-    if (on >= 0) ff::g_fused_prune_plan.store(on ? 1 : 0, std::memory_order_relaxed);
-    return prev;
-}
-
+// The attention hook of a context whose prune call comes next: importance + the select tables of importance[start, start + n_img)
+// accumulated in the context's workspace (the prune call then passes tables_ready = 1).
 extern "C" int ff_ctx_last_query_importance(ff_ctx_t* c, const void* q_last, const void* k, int dtype, int64_t H, int64_t H_kv, int64_t num,
                                             int64_t S, int64_t dh, int64_t k_head_stride, int64_t k_key_stride, double scale, int causal,
                                             const void* bias, void* importance, int64_t start, int64_t n_img, int64_t k_keep,
@@ -996,23 +908,10 @@ extern "C" int ff_ctx_last_query_importance(ff_ctx_t* c, const void* q_last, con
     if (S < 1 || S > c->cap || start < 0 || n_img < 0 || start + n_img > S || k_keep < 0 || k_keep > n_img) return FF_ERR_ARG;
     if (c->ws_bytes < ff_workspace_bytes(c->cap, 1)) return FF_ERR_WORKSPACE;
     if (c->dirty || c->in_flight) return FF_ERR_STATE;             // (the tables must be clean: ff_ctx_reset first)
-    ff::PlanHook hook;
-    hook.pp = ff::prune_plan_params(dtype, start, n_img, k_keep);
-    hook.member = c->member; hook.keep = c->keep; hook.dst = c->dst; hook.stats = c->stats;
-    hook.agg = ff::ws_agg(c->ws); hook.tagword = ff::ws_tag(c->ws); hook.arrive = ff::ws_arrive(c->ws); hook.flags = ff::ws_flags(c->ws);
     c->seq += 1;
-    hook.seq = c->seq;
-    hook.n_plan = 0;
     c->dirty = 1;                                                  // until the prune call has consumed (and cleared) the tables
     c->order_len = 0;
-    c->plan_ready = 0;
-    const bool fuse = ff::fused_prune_plan_enabled() && (((uintptr_t)c->member & 7) == 0) && (((uintptr_t)c->dst | (uintptr_t)c->keep) & 15) == 0;
-    int rc = lq_attention(q_last, k, dtype, H, H_kv, num, S, dh, k_head_stride, k_key_stride, scale, causal, bias, nullptr, importance, start,
-                          start + n_img, c->ws, c->ws_bytes, ws, ws_bytes, stream, fuse ? &hook : nullptr);
-    if (rc) return rc;
-    if (hook.n_plan < 0) {                                         // the plan went out with the normalisation
-        c->plan_ready = S;
-        c->plan_start = start; c->plan_n_img = n_img; c->plan_k = k_keep;
-    }
-    return FF_OK;
+    c->last_L = 0;
+    return lq_attention(q_last, k, dtype, H, H_kv, num, S, dh, k_head_stride, k_key_stride, scale, causal, bias, nullptr, importance, start,
+                        start + n_img, c->ws, c->ws_bytes, ws, ws_bytes, stream);
 }

@@ -30,9 +30,9 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
     const int32_t* __restrict__ dst, const uint8_t* __restrict__ keep, AuxPack aux, int n_main,
     int n_aux_blocks, int n_next_blocks, int32_t* __restrict__ order_next, int32_t* __restrict__ inv_next,
     int64_t* __restrict__ stats, const int64_t* __restrict__ identity_stats, ZeroJob zero, int slots) {
-    merge_compact_body<DT, kAdd, false>(hidden, addend, out, row_bytes, L, L_cap, order, member, fold, dst, keep, aux, n_main,
-                                        n_aux_blocks, n_next_blocks, order_next, inv_next, stats, identity_stats, zero, slots,
-                                        (int)blockIdx.x, (int)blockIdx.y, FusedWait{nullptr, 0ull, nullptr, nullptr, 0u, 0, nullptr});
+    merge_compact_body<DT, kAdd>(hidden, addend, out, row_bytes, L, L_cap, order, member, fold, dst, keep, aux, n_main,
+                                 n_aux_blocks, n_next_blocks, order_next, inv_next, stats, identity_stats, zero, slots,
+                                 (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // ---- square attention-mask gather (main.py:137-138, 99-100): out[r, c] = mask[src[r], src[c]] ----------------

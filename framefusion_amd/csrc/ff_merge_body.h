@@ -1,5 +1,4 @@
-// K4's body as a device function: run by the stand-alone merge kernel (ff_merge.hip, k_merge_compact) and by the
-// fused plan + merge launch (ff_fused.hip).
+// K4's body as a device function (ff_merge.hip, k_merge_compact).
 #pragma once
 
 #include "ff_common.h"
@@ -84,137 +83,19 @@ __device__ inline void zero_by_key(const ZeroJob& z, int t) {
     for (int x = 0; x < kT16Copies; ++x) tab[x * 65536] = 0;
 }
 
-// Fused launch (ff_fused.hip): the workgroups of this body share a grid with the plan's.  Two hand-overs, both through
-// 64 replicated lines of 128 bytes in the workspace (2 048 pollers on ONE word would queue up on one memory channel; a
-// workgroup polls the line its index selects):
-//  * the DECISION (line words 1, 2), published by plan workgroup 0 as soon as it knows the k-th key and the tie slot t*
-//    - two thirds into the plan.  "Is slot t folded?" is a pure function of (similarity[t], t) and the decision, so a main
-//    workgroup derives its member flags from the similarities itself and gets its first row requests out while the
-//    plan is still scanning;
-//  * DONE (line word 0 = the call's sequence number), raised by the last plan workgroup to arrive: dst[] (needed by the
-//    first store), keep / stats (auxiliary rows, next order) and the tables (clearing) wait for this one.
-// Words carry a tag derived from the context's strictly increasing sequence number, so nothing is ever cleared.
-struct FusedWait {
-    const unsigned long long* flags;       // 64 lines, 16 words apart: [done | decision 0 | decision 1 | ...]
-    unsigned long long seq;
-    int64_t* stats;                        // FF_STAT_ERROR gets FF_ERR_BIT_BARRIER if a flag never comes
-    const void* sim;                       // the similarities the decision applies to (activation dtype)
-    uint32_t thr_key;
-    int dbg;
-    long long* dbg_buf;                    // (FF_FUSED_DBG bit 2: per-workgroup phase stamps)
-};
-constexpr int kFlagCopies = 64, kFlagStride = 16;
-
-// decision word 0: tag << 35 | topk (k > 0) << 34 | is_topk << 33 | kth key << 17 | (t* + 1);  word 1: tag << 35 | nv
-__device__ inline unsigned long long decision_tag(unsigned long long seq) { return seq % ((1ull << 29) - 1ull) + 1ull; }
-struct Decision {
-    uint32_t kth;
-    int tstar, nv;
-    bool is_topk, topk;
-};
-__device__ inline void publish_decision(unsigned long long* flags, unsigned long long seq, bool is_topk, bool topk, uint32_t kth,
-                                        int tstar, int nv) {          // one wave; lane = copy
-    const unsigned long long tag = decision_tag(seq) << 35;
-    unsigned long long* line = flags + (size_t)(threadIdx.x & (kFlagCopies - 1)) * kFlagStride;
-    __hip_atomic_store(line + 1, tag | ((unsigned long long)topk << 34) | ((unsigned long long)is_topk << 33) |
-                                 ((unsigned long long)(kth & 0xffffu) << 17) | (unsigned long long)(uint32_t)(tstar + 1),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(line + 2, tag | (unsigned long long)(uint32_t)nv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__device__ inline void flag_timeout(const FusedWait& fw) {
-    atomicOr((unsigned long long*)(fw.stats + FF_STAT_ERROR), (unsigned long long)FF_ERR_BIT_BARRIER);
-}
-
-// whole workgroup (call before the waves diverge): thread 0 polls, the words travel through LDS
-__device__ inline Decision wait_for_decision(const FusedWait& fw, int bx) {
-    __shared__ unsigned long long words[2];
-    if (threadIdx.x == 0) {
-        const unsigned long long* line = fw.flags + (size_t)(bx & (kFlagCopies - 1)) * kFlagStride;
-        const unsigned long long tag = decision_tag(fw.seq);
-        unsigned long long w0 = 0, w1 = 0;
-        __builtin_amdgcn_s_sleep(100);             // (~3 us: the decision takes the plan longer than that from its first instruction)
-        for (int spins = 0;; ++spins) {
-            w0 = __hip_atomic_load(line + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            w1 = __hip_atomic_load(line + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((w0 >> 35) == tag && (w1 >> 35) == tag) break;
-            __builtin_amdgcn_s_sleep(2);
-            if (spins > (1 << 20)) { flag_timeout(fw); w0 = w1 = 0; break; }       // (an empty decision: nothing folds)
-        }
-        words[0] = w0; words[1] = w1;
-    }
-    __syncthreads();
-    const unsigned long long w0 = words[0], w1 = words[1];
-    Decision d;
-    d.tstar = (int)(w0 & 0x1ffffull) - 1;
-    d.kth = (uint32_t)(w0 >> 17) & 0xffffu;
-    d.is_topk = (w0 >> 33) & 1ull;
-    d.topk = (w0 >> 34) & 1ull;
-    d.nv = (int)(w1 & 0x7ffffffull);
-    return d;
-}
-
-// one wave (uniform): DONE seen?  false after the time-out
-__device__ inline bool wave_wait_done(const FusedWait& fw, int bx) {
-    const unsigned long long* f = fw.flags + (size_t)(bx & (kFlagCopies - 1)) * kFlagStride;
-    for (int spins = 0;; ++spins) {
-        const unsigned long long v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__builtin_amdgcn_readfirstlane((int)(v == fw.seq))) return true;
-        __builtin_amdgcn_s_sleep(1);
-        if (spins > (1 << 20)) {
-            if (lane_id() == 0) flag_timeout(fw);
-            return false;
-        }
-    }
-}
-
-// whole workgroup: DONE (the roles that consume keep / dst / stats or clear the tables).
-// No acquire fence behind it: `buffer_inv sc1` by every wave of a streaming kernel cost 100 us at 64 x 576 x 4096 (it empties
-// the L2 under the streams, again and again).  It is not needed either: the kernel started with clean caches, and of
-// everything the plan writes (member, dst, keep - whole cache lines per plan workgroup - and stats) only `stats` has been
-// READ in this launch before the flag (by the plan workgroups), so only its line can sit stale in an XCD's L2: stats is
-// read with agent-scope loads (stat_word), everything else misses and comes from memory, where the plan's release put it.
-__device__ inline void wait_for_plan(const FusedWait& fw, int bx, bool nap = true) {
-    if (threadIdx.x == 0) {
-        const unsigned long long* f = fw.flags + (size_t)(bx & (kFlagCopies - 1)) * kFlagStride;
-        if (nap) __builtin_amdgcn_s_sleep(100);        // (~3 us: what is waited for takes longer than that)
-        for (int spins = 0;; ++spins) {
-            if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == fw.seq) break;
-            __builtin_amdgcn_s_sleep(2);
-            if (spins > (1 << 20)) { flag_timeout(fw); break; }       // the plan never finished: report, do not hang
-        }
-    }
-    __syncthreads();
-    if (fw.dbg & 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-}
-
-// a word of the result block: past the (non-coherent) L2 in the fused launch
-template <bool kFused>
-__device__ inline int64_t stat_word(const int64_t* stats, int which) {
-    if constexpr (kFused) return __hip_atomic_load(stats + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else return stats[which];
-}
-
 // (bx, by): the workgroup's coordinates in the merge kernel's own 2-D grid
-template <int DT, bool kAdd, bool kFused>
+template <int DT, bool kAdd>
 __device__ inline void merge_compact_body(
     const char* __restrict__ hidden, const char* __restrict__ addend, char* __restrict__ out, uint32_t row_bytes, int L, int64_t L_cap,
     const int32_t* __restrict__ order, const uint8_t* __restrict__ member, int fold,
     const int32_t* __restrict__ dst, const uint8_t* __restrict__ keep, const AuxPack& aux, int n_main,
     int n_aux_blocks, int n_next_blocks, int32_t* __restrict__ order_next, int32_t* __restrict__ inv_next,
     int64_t* __restrict__ stats, const int64_t* __restrict__ identity_stats, const ZeroJob& zero, int slots,
-    const int bx, const int by, const FusedWait& fw) {
+    const int bx, const int by) {
     using A = Act<DT>;
     constexpr int E = A::kPer16;
     constexpr int kDepth = 4;                     // row pieces requested per batch (two batches in flight)
     const int lane = lane_id();
-    if constexpr (kFused) {
-        // every role but the main one starts with the plan's outputs (or clears what the plan reads)
-        if (bx >= n_main) {
-            if (by != 0) return;
-            wait_for_plan(fw, bx);
-        }
-    }
     if (bx >= n_main + n_aux_blocks + n_next_blocks) {
         // ---- the select tables of this call have been consumed by the plan kernel: clear them for the
         // next call's producer (runs even when nothing is folded)
@@ -234,7 +115,7 @@ __device__ inline void merge_compact_body(
     }
     // nothing folded (a merge call whose threshold set is empty, main.py:264-266): the reduced
     // sequence IS the input, the caller keeps using its own tensors and this launch writes nothing
-    if (!(kFused && bx < n_main) && identity_stats && stat_word<kFused>(identity_stats, FF_STAT_MERGED) == 0) return;
+    if (identity_stats && identity_stats[FF_STAT_MERGED] == 0) return;
     if (bx >= n_main + n_aux_blocks) {
         // ---- by-patch order of the COMPACTED sequence, for the next merge call (order maintenance):
         // the surviving slots keep their relative by-patch order and dst[] is monotonic in the
@@ -265,9 +146,9 @@ __device__ inline void merge_compact_body(
             }
         }
         if (base + kMergeThreads * 16 >= L && tid == 0) {
-            const int64_t merged = stat_word<kFused>(stats, FF_STAT_MERGED);
-            stats[FF_STAT_NV] = stat_word<kFused>(stats, FF_STAT_NV) - merged;     // the next call (order_valid) skips K0, which would set these
-            stats[FF_STAT_FTN] = stat_word<kFused>(stats, FF_STAT_FTN) - merged;
+            const int64_t merged = stats[FF_STAT_MERGED];
+            stats[FF_STAT_NV] = stats[FF_STAT_NV] - merged;     // the next call (order_valid) skips K0, which would set these
+            stats[FF_STAT_FTN] = stats[FF_STAT_FTN] - merged;
         }
         return;
     }
@@ -292,8 +173,8 @@ __device__ inline void merge_compact_body(
     const int t0 = (n_main - 1 - bx) * slots;
     const int cb = uniform(by * kMergeWaves + wave_id());     // 1 KiB column tile
     const uint32_t col = (uint32_t)cb * 1024u;
-    if (!kFused && col >= row_bytes) return;
-    const uint32_t blk_bytes = col < row_bytes ? min(1024u, row_bytes - col) : 0u;
+    if (col >= row_bytes) return;
+    const uint32_t blk_bytes = min(1024u, row_bytes - col);
     const uint32_t voff = (uint32_t)lane * 16;
     const int t_end = min(t0 + slots, L);
 
@@ -304,26 +185,8 @@ __device__ inline void merge_compact_body(
     const int sl = win0 + lane;
     const bool sl_ok = sl >= 0 && sl < L;
     int ordw = sl_ok ? (order ? order[sl] : sl) : 0;
-    Decision dec{0u, -1, 0, false, false};
-    if constexpr (kFused) {
-        // (the order window above does not depend on the plan: its load is in flight while the workgroup waits)
-        dec = wait_for_decision(fw, bx);
-        if ((fw.dbg & 4) && threadIdx.x == 0) fw.dbg_buf[3 * (by * n_main + bx)] = wall_clock64();
-        if (col >= row_bytes) return;
-    }
-    // is slot s (< L) folded into its predecessor?  Stand-alone: the plan kernel's flags.  Fused: the plan's rule
-    // (plan_fast_body, `folded`) applied to the similarity itself - the flags may not have been written yet.
-    auto is_member = [&](int s) -> bool {
-        if constexpr (kFused && DT != FF_F32) {
-            const uint32_t key = order_key<DT>(A::bits1(fw.sim, s));
-            const bool in = s < dec.nv;
-            const bool sel_topk = dec.topk & in & ((key > dec.kth) | ((key == dec.kth) & (s <= dec.tstar)));
-            const bool sel_thr = in & (key >= fw.thr_key) & (key != 0xffffu);
-            return (dec.is_topk ? sel_topk : sel_thr) & (s > 0);
-        } else {
-            return member[s] != 0;
-        }
-    };
+    // is slot s (< L) folded into its predecessor?  The plan kernel's flags.
+    auto is_member = [&](int s) -> bool { return member[s] != 0; };
     const bool sl_mem = sl_ok ? is_member(sl) : false;
     unsigned long long memw = __ballot(sl_mem);
     const unsigned long long nonmem = __ballot(sl_ok && !sl_mem);
@@ -358,8 +221,7 @@ __device__ inline void merge_compact_body(
     // output rows of my anchors: non-members of [bs, be), all inside the first window (bs < t_end <= win0 + 64 - look, and
     // everything from t_end to be is a member)
     const bool anchor_lane = sl_ok && !sl_mem && sl >= bs && sl < be;
-    const int ordw0 = ordw;                                  // (issue() slides the window: the anchors' rows are the first window's)
-    int dv = (!kFused && anchor_lane) ? dst[ordw] : 0;
+    const int dv = anchor_lane ? dst[ordw] : 0;               // (issue() slides the window: the anchors' rows are the first window's)
 
     auto piece = [&](int i) { return make_rsrc(hidden + (int64_t)i * row_bytes + col, blk_bytes); };
     auto piece2 = [&](int i) { return make_rsrc((kAdd ? addend : hidden) + (int64_t)i * row_bytes + col, blk_bytes); };
@@ -468,17 +330,8 @@ __device__ inline void merge_compact_body(
     int pos = bs;
     issue(b0, pos);
     pos += b0.take;
-    bool have_b1 = false;
-    if constexpr (kFused) {
-        // both batches are requested; the output rows (dst) are the plan's last product: wait for DONE now
-        if (!b0.last) { issue(b1, pos); pos += b1.take; have_b1 = true; }
-        if (!wave_wait_done(fw, bx)) return;
-        if (identity_stats && stat_word<kFused>(identity_stats, FF_STAT_MERGED) == 0) return;       // nothing folded: nothing written
-        dv = anchor_lane ? dst[ordw0] : 0;
-    }
     while (true) {
-        if (!b0.last && !have_b1) { issue(b1, pos); pos += b1.take; }
-        have_b1 = false;
+        if (!b0.last) { issue(b1, pos); pos += b1.take; }
         fold_batch(b0);
         if (b0.last) break;
         if (!b1.last) { issue(b0, pos); pos += b0.take; }
@@ -486,9 +339,6 @@ __device__ inline void merge_compact_body(
         if (b1.last) break;
     }
     if (open_r >= 0) flush();
-    if constexpr (kFused) {
-        if ((fw.dbg & 4) && threadIdx.x == 0) { fw.dbg_buf[3 * (by * n_main + bx) + 1] = wall_clock64(); fw.dbg_buf[3 * (by * n_main + bx) + 2] = (long long)(be - bs) << 32; }
-    }
 }
 
 }  // namespace ff

@@ -624,7 +624,7 @@ __global__ __launch_bounds__(kFastThreads) void k_plan_fast(
     unsigned long long* agg, uint32_t* tagword, int64_t* host_mapped, int64_t seq) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     plan_fast_body<DT, RS, kFastThreads>(values, cap, pp, l0, t16_end, stats, inv, L, member, keep, dst, agg, tagword,
-                                         host_mapped, seq, lds_raw, (int)blockIdx.x, (int)gridDim.x, nullptr);
+                                         host_mapped, seq, lds_raw, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ---- explicit merge set (merge_tokens_and_get_mask, main.py:243-319) --------------------------------
@@ -681,16 +681,14 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const uint8_t* __restrict
     }
 }
 
-// ---- launchers (also used by the fused step in ff_abi.hip) ------------------------------------------
+// ---- launchers (also used by the merge / prune steps in ff_abi.hip) ------------------------------------------
 static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
 
 // Workspace layout: [kL0Ints ints: level-0 tables][16 ints: launch tag][2 x kMaxPlanGroups ints: the
 // workgroup totals][2 x G x 256 ints: fp32 level rows][L ints: inverse order of the stand-alone entry
 // points][K0's per-slice rows, ff_order.hip] ... free ... [G slices of level-1 tables, down from the
 // end];  G = ceil(L / 4096).
-// ... [16 ints: arrival counter of the fused launch][64 flag words of 8 bytes, 128 bytes apart, + 32 ints of alignment slack]
-constexpr int kWsFlagInts = 16 + 64 * 32 + 32;
-constexpr int kWsFixedInts = kL0Ints + 16 + 2 * 512 + kWsFlagInts;          // (room for 512 workgroup totals)
+constexpr int kWsFixedInts = kL0Ints + 16 + 2 * 512;          // (room for 512 workgroup totals)
 size_t plan_ws_front_bytes(int64_t L) {
     const size_t G = (size_t)((L + kSelSlice - 1) / kSelSlice) + 1;
     const size_t b = ((size_t)kWsFixedInts + 2 * G * 256 + (size_t)L + 16) * sizeof(int) + 256;
@@ -704,11 +702,6 @@ int* ws_l0(void* ws) { return (int*)ws; }
 int* ws_t16_end(void* ws, size_t ws_bytes) { return (int*)((char*)ws + (ws_bytes & ~(size_t)15)); }
 uint32_t* ws_tag(void* ws) { return (uint32_t*)((int*)ws + kL0Ints); }
 unsigned long long* ws_agg(void* ws) { return (unsigned long long*)((int*)ws + kL0Ints + 16); }
-// fused plan + merge launch (ff_fused.hip): how many plan workgroups have finished, and the "plan done" flag copies
-unsigned int* ws_arrive(void* ws) { return (unsigned int*)((int*)ws + kL0Ints + 16 + 2 * 512); }
-unsigned long long* ws_flags(void* ws) {
-    return (unsigned long long*)(((uintptr_t)((int*)ws + kL0Ints + 16 + 2 * 512 + 16) + 127) & ~(uintptr_t)127);
-}
 static int* ws_levels(void* ws) { return (int*)ws + kWsFixedInts; }
 int32_t* ws_scratch_ints(void* ws, int64_t L);
 static int32_t* ws_inv(void* ws, int64_t L) {

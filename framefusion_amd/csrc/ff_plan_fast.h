@@ -1,9 +1,7 @@
-// The fast plan (16-bit values, <= 163 840 tokens) as a device function, so that both the stand-alone plan kernel
-// (ff_plan.hip, k_plan_fast) and the fused plan + merge launch (ff_fused.hip) run the same code.
+// The fast plan (16-bit values, <= 163 840 tokens) as a device function: the body of k_plan_fast (ff_plan.hip).
 #pragma once
 
 #include "ff_common.h"
-#include "ff_merge_body.h"      // publish_decision
 
 namespace ff {
 
@@ -54,7 +52,7 @@ __device__ inline void plan_fast_body(
     int64_t* __restrict__ stats, const int32_t* __restrict__ inv, int L,
     uint8_t* __restrict__ member, uint8_t* __restrict__ keep, int32_t* __restrict__ dst,
     unsigned long long* agg, uint32_t* tagword, int64_t* host_mapped, int64_t seq,
-    unsigned char* lds_raw, const int bid, const int nblk, unsigned long long* decision_out = nullptr) {
+    unsigned char* lds_raw, const int bid, const int nblk) {
     using A = Act<DT>;
     static_assert(A::kBytes == 2, "16-bit values only");
     constexpr int NW = NT / kWave, NQ = NT / 256, kSpec = RS / NQ;
@@ -276,8 +274,6 @@ __device__ inline void plan_fast_body(
 #ifdef FF_PLAN_PROBE
     stamp[4] = wall_clock64();
 #endif
-    // fused launch: the merge workgroups only need THIS to start (ff_merge_body.h, "decision")
-    if (decision_out && bid == 0 && wv == 0) publish_decision(decision_out, (unsigned long long)seq, is_topk, topk, kth, tstar, nv);
     // is slot t (raw value bits) folded (mode 0) / dropped (mode 1)?  branch-free
     auto folded = [&](uint32_t bits, int t) -> uint32_t {
         const uint32_t key = order_key<DT>(bits);

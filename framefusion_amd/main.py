@@ -150,9 +150,8 @@ class _Scratch:
                 last = s.shape[-1]
                 row = last * s.element_size()
                 outer = s.numel() // (L * last)
-                outer_bytes = getattr(s, "_ff_outer_bytes", None)
-                if outer_bytes is None:
-                    outer_bytes = 0 if s.is_contiguous() else _outer_stride(s) * s.element_size()
+                # (recomputed from the strides, never taken from an attribute a caller's tensor may carry from an earlier life)
+                outer_bytes = 0 if s.is_contiguous() else _outer_stride(s) * s.element_size()
             pack(block, offset + size * n, s.data_ptr(), o.data_ptr(), row, outer, outer_bytes)
             n += 1
         return n
@@ -161,14 +160,9 @@ class _Scratch:
 def _token_dense(t: torch.Tensor) -> torch.Tensor:
     """`t` itself when the merge kernel can read it in place (contiguous, or rows dense and the leading dims one uniform
     stride apart: `_outer_stride`), else a contiguous copy."""
-    ob = getattr(t, "_ff_outer_bytes", None)
-    if ob is not None or t.is_contiguous():
+    if t.is_contiguous() or _outer_stride(t) is not None:
         return t
-    st = _outer_stride(t)
-    if st is None:
-        return t.contiguous()
-    t._ff_outer_bytes = st * t.element_size()
-    return t
+    return t.contiguous()
 
 
 def _outer_stride(t: torch.Tensor):
@@ -190,7 +184,10 @@ def _outer_stride(t: torch.Tensor):
             return None
         else:
             expect *= t.shape[k]
-    return stride if stride is not None else t.shape[-2] * t.shape[-1]
+    if stride is None:
+        return t.shape[-2] * t.shape[-1]
+    # a broadcast (stride 0) or overlapping leading dim has no plane to read in place: the caller copies
+    return stride if stride >= t.shape[-2] * t.shape[-1] else None
 
 
 def _fail(rc: int, what: str, err_bits: int = 0):
@@ -388,10 +385,7 @@ class FrameFusion(nn.Module):
 
             def rebuild(L_out):
                 for x in (0, 1):
-                    v = outs[x].narrow(ax, 0, L_out)
-                    # (what put_aux needs to take this view as the next call's source without looking at its strides again)
-                    v._ff_outer_bytes = 0 if v.is_contiguous() else L_cap * v.shape[-1] * v.element_size()
-                    position_embeddings[x] = v
+                    position_embeddings[x] = outs[x].narrow(ax, 0, L_out)
                 return position_embeddings
             return [a, b], outs, rebuild
         if type(position_embeddings) == torch.Tensor:
@@ -557,7 +551,7 @@ class FrameFusion(nn.Module):
     def _expect_importance(self, S: int, dtype, device):
         """The attention hook is about to compute the importance of a prune call over S tokens: returns
         (plan, token) - `plan` = (ctx pointer, start, n_img, k, stream) for ff_ctx_last_query_importance, which accumulates
-        the select tables in this instance's workspace and, where it can, enqueues the prune's plan in the same launch;
+        the select tables of the prune in this instance's workspace;
         `token` is what _prune recognises the tensor by.  (None, None) when the prune range does not fit S."""
         with torch.cuda.device(device):
             sc, stream = self._scratch_for(device, S)
@@ -610,8 +604,6 @@ class FrameFusion(nn.Module):
         H, num = w.shape[1], w.shape[2]
         tables_ready = int(token is not None and token == sc.tables_token and
                            token == (id(sc), sc.seq, q_len, start, n_img, w.dtype, k) and H * num == 1)
-        if tables_ready and int(sc.ctx.plan_ready) == q_len:
-            tables_ready = 2                 # the hook's kernel enqueued the plan as well: this call only gathers
         sc.tables_token = None
         # nothing is read back (L_out is known): head mean + select tables, plan, gather - one host call
         out = torch.empty((1, L_out, d), dtype=dtype, device=device)

@@ -58,7 +58,7 @@ def _launch_last_query(query, key, num, is_causal, scale, want_weights, want_imp
     ws_bytes = int(lib.ff_last_query_workspace_bytes(code, H, num, S, dh))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)          # (scores + statistics: dead when the call returns)
     if plan is not None:
-        # the attention hook of an instance whose prune call comes next: importance + select tables (+ the prune's plan)
+        # the attention hook of an instance whose prune call comes next: importance + the select tables of that prune
         ctx_ptr, start, n_img, k_keep, stream = plan
         rc = lib.ff_ctx_last_query_importance(ctx_ptr, q_last.data_ptr(), k.data_ptr(), code, H, H_kv, num, S, dh, sh, ss,
                                               float(factor), 1 if is_causal else 0, bias.data_ptr() if bias is not None else None,
@@ -106,9 +106,8 @@ def last_query_importance(query, key, num=1, is_causal=True, scale=None, framefu
     """Fused form for the attention hook: the head/query mean of the weights
     above, shaped [1, 1, 1, S] so that FrameFusion.forward's own mean (main.py:70) is the identity.
     With `framefusion` (the instance whose prune call will consume the result) the importance kernel
-    also accumulates the select tables of that call in the instance's workspace and - 16-bit dtypes, at most
-    65 536 tokens - goes on as the prune's plan in the same launch (ff_ctx_last_query_importance): the prune
-    call is then a gather, nothing else."""
+    also accumulates the select tables of that call in the instance's workspace (ff_ctx_last_query_importance):
+    the prune call then goes straight to its plan.  `FrameFusion.prune_from_qk` does hook + prune in ONE host call."""
     plan, token = None, None
     if framefusion is not None and query.is_cuda:
         plan, token = framefusion._expect_importance(key.shape[2], query.dtype, query.device)

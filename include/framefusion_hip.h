@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FF_ABI_VERSION 8
+#define FF_ABI_VERSION 9
 
 enum { FF_F32 = 0, FF_BF16 = 1, FF_F16 = 2 };
 
@@ -65,7 +65,7 @@ enum {
 };
 
 enum {
-    FF_ERR_BIT_BARRIER = 1,  /* a workgroup of the plan kernel never saw a predecessor's total (bounded spin) */
+    FF_ERR_BIT_BARRIER = 1,  /* a workgroup of the plan kernel never saw a predecessor's total (bounded look-back) */
     FF_ERR_BIT_LAYOUT = 2    /* the frame-major layout hint of ff_merge_begin does not describe
                                 patch_type: the call's outputs are meaningless, repeat it unhinted  */
 };
@@ -388,8 +388,9 @@ typedef struct ff_ctx {
     int64_t dirty;         /* a call died half-way: workspace + stats are reset by the next call        */
     int64_t in_flight;     /* 1 between ff_ctx_merge_begin and ff_ctx_merge_finish                      */
     int64_t swaps;         /* number of order <-> order_next exchanges so far (owner mirrors its views) */
-    int64_t plan_ready;    /* S of the prune call whose PLAN ff_ctx_last_query_importance already enqueued (0: none);  */
-    int64_t plan_start, plan_n_img, plan_k;   /* ... and the selection it was made for (ABI v8)                        */
+    int64_t last_L;        /* input length of the merge call that finished last and whose keep set is still in
+                              the scratch (0: none) - what ff_ctx_gather_mask may be asked for (ABI v9)         */
+    int64_t last_l_out;    /* ... and its output length                                                         */
 } ff_ctx_t;
 
 /* Inputs of one merge call (main.py:104-138).  The same structure goes to begin and finish; the
@@ -412,7 +413,9 @@ typedef struct ff_merge_call {
     int64_t n_aux;
     ff_aux_t aux[FF_MAX_AUX];
     const void* mask;            /* optional [L, L] attention mask of mask_elem_bytes per element       */
-    void* mask_out;              /* [L_cap, L_cap]                                                      */
+    void* mask_out;              /* [L_cap, L_cap]: written ONLY when the call folded something
+                                    (result->l_out != L); when l_out == L the sequence - and its mask -
+                                    stay as they are and mask_out is left untouched (ABI v8 on)         */
     int64_t mask_elem_bytes;
 } ff_merge_call_t;
 
@@ -443,7 +446,8 @@ int ff_ctx_merge_finish(ff_ctx_t* ctx, const ff_merge_call_t* call, ff_merge_res
 int ff_ctx_merge(ff_ctx_t* ctx, const ff_merge_call_t* call, ff_merge_result_t* result);
 
 /* The attention mask of the merge call that just finished on this context, gathered with its keep set (main.py:137-138):
- * out[r, c] = mask[src[r], src[c]] for the l_out kept positions, row stride L_cap (>= l_out) elements.  For a host that
+ * out[r, c] = mask[src[r], src[c]] for the l_out kept positions, row stride L_cap (>= l_out) elements.  FF_ERR_STATE unless
+ * a merge call over exactly L tokens finished last on this context, folded something (l_out < L) and nothing was begun since.  For a host that
  * sizes mask_out AFTER it knows l_out - pass call->mask = NULL to ff_ctx_merge_finish and call this behind it (what
  * FrameFusion.forward does: an [L, L] capacity buffer for a 37 k-token call would be 2.7 GB).  ff_ctx_merge_finish with
  * call->mask set gathers into the caller's [L_cap, L_cap] buffer itself - after the result is known, and only when the
@@ -459,8 +463,8 @@ typedef struct ff_prune_call {
     void* hidden_out;            /* [L_cap, d]                                                          */
     const void* attn_w;          /* [H, num, S] of w_dtype, or the [S] importance when H * num == 1     */
     int64_t dtype, S, d, L_cap, w_dtype, H, num;
-    int64_t tables_ready;        /* 1: the importance's producer filled the select tables in ctx->ws;
-                                    2: ... and enqueued the plan (ctx->plan_ready == S): gather only         */
+    int64_t tables_ready;        /* 0 / 1; 1: the importance's producer (ff_ctx_last_query_importance) filled the
+                                    select tables in ctx->ws                                                */
     int64_t start, n_img, k;
     ff_stream_t stream;
     int64_t n_aux;
@@ -472,20 +476,13 @@ typedef struct ff_prune_call {
 int ff_ctx_prune(ff_ctx_t* ctx, const ff_prune_call_t* call);
 
 /* The attention hook of a context whose prune call comes next (main.py:61-101 fed by utils.py:27-57): the importance of
- * the last `num` queries as ff_last_query_attention computes it, the select tables of importance[start, start + n_img),
- * AND - when ff_set_fused_prune_plan(1); 16-bit dtypes, S <= 65 536, a tiled head size - the prune's plan (top-k of `k` with the lowest-index tie rule,
- * member / keep / dst / stats of the context) in the same launch as the normalisation: the workgroups that finish the
- * importances go on as the plan once all of them have arrived (csrc/ff_importance.hip, k_lq_finish_plan).  ctx->plan_ready
- * says which happened (S: the plan is in the context; 0: tables only).  The prune call that follows passes tables_ready =
- * 2 (plan_ready == S: it only gathers) or 1.  The context must be clean (ff_ctx_reset first). */
+ * the last `num` queries as ff_last_query_attention computes it AND the select tables of importance[start, start + n_img)
+ * in the context's workspace; the prune call that follows passes attn_w = importance, H = num = 1, tables_ready = 1.
+ * The context must be clean (ff_ctx_reset first).  `ws`: ff_last_query_workspace_bytes(). */
 int ff_ctx_last_query_importance(ff_ctx_t* ctx, const void* q_last, const void* k, int dtype, int64_t H, int64_t H_kv, int64_t num,
                                  int64_t S, int64_t dh, int64_t k_head_stride, int64_t k_key_stride, double scale, int causal,
                                  const void* bias, void* importance, int64_t start, int64_t n_img, int64_t k_keep,
                                  void* ws, size_t ws_bytes, ff_stream_t stream);
-/* 0 (default; FF_FUSED_PRUNE_PLAN=1 in the environment makes it 1): ff_ctx_last_query_importance fills the tables only,
- * the prune call launches its plan; 1: the plan goes out with the importance kernel as described above (same results;
- * measured no faster, profiles/EXPERIMENTS.md 4.12).  Returns the previous value (on < 0: only reports). */
-int ff_set_fused_prune_plan(int on);
 
 /* The caller replaced patch_type / starts a new sample: forget the order (and reset the workspace
  * if a call died half-way).  Enqueues at most two memsets on `stream`. */
@@ -495,13 +492,6 @@ int ff_ctx_reset(ff_ctx_t* ctx, ff_stream_t stream);
  * filled) - ff_last_query_attention with sel_ws = ctx->ws: if the matching ff_ctx_prune never comes,
  * the next call resets the workspace. */
 void ff_ctx_expect_tables(ff_ctx_t* ctx);
-
-/* How ff_ctx_merge_finish enqueues plan + K4: 1 (default; FF_FUSED=0 in the environment makes it 0) = ONE launch
- * whose merge workgroups are dispatched while the plan runs and wait for its flag (16-bit activations, <= 65 536
- * tokens; csrc/ff_fused.hip), 0 = two launches.  Same results either way.  Process-wide; returns the previous
- * value (on < 0: only reports).  The library switches to 0 by itself if a waiting workgroup ever times out
- * (FF_ERR_BIT_BARRIER). */
-int ff_set_fused_launch(int on);
 
 /* sizeof() of the structures above as THIS library was compiled (0: ff_ctx_t, 1: ff_merge_call_t,
  * 2: ff_merge_result_t, 3: ff_prune_call_t, 4: ff_aux_t), so a binding can verify its own layout. */

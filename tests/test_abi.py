@@ -47,7 +47,7 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(_lib.LIB_PATH)
     for name in declared_functions():
         assert hasattr(lib, name), name
-    assert _lib.load().ff_abi_version() == _lib.ABI_VERSION == 8
+    assert _lib.load().ff_abi_version() == _lib.ABI_VERSION == 9
 
 
 def test_stat_enum_matches_binding():
@@ -73,8 +73,8 @@ def test_error_strings_and_workspace():
     assert lib.ff_last_query_workspace_bytes(bf16, 28, 4, 1000, 128) < 2 * 28 * 4 * 1000 * 4
     assert lib.ff_last_query_workspace_bytes(bf16, 6, 4, 1000, 24) == 2 * 6 * 4 * 1000 * 4           # odd head size
     assert lib.ff_last_query_workspace_bytes(bf16, 28, 256, 1000, 128) == 2 * 28 * 256 * 1000 * 4    # 7168 rows
-    assert lib.ff_set_fused_launch(-1) in (0, 1)                                                      # (reports only)
-    assert lib.ff_set_fused_prune_plan(-1) in (0, 1)
+    # ABI v9: the in-grid hand-over paths (one launch for plan + merge, plan inside the importance kernel) are gone
+    assert not hasattr(lib, "ff_set_fused_launch") and not hasattr(lib, "ff_set_fused_prune_plan")
 
 
 def test_argument_validation_without_gpu():

@@ -47,23 +47,6 @@ def test_random_cascades_match_the_oracle(chunk):
     sweep(1000 + chunk)
 
 
-@pytest.mark.parametrize("chunk", range(3))
-def test_random_cascades_match_the_oracle_through_the_fused_launch(chunk):
-    """The same sweep with plan + merge enqueued as ONE launch (csrc/ff_fused.hip: flag hand-over inside the grid, member flags
-    derived from the similarities by the merge workgroups themselves) - off by default because it measured slower
-    (profiles/EXPERIMENTS.md 4.1-4.6), but it must stay bit-exact.  16-bit activations take the fused launch, fp32 draws the
-    two-launch form as always."""
-    from framefusion_amd import _lib
-    lib = _lib.load()
-    prev = lib.ff_set_fused_launch(1)
-    try:
-        assert lib.ff_set_fused_launch(-1) == 1
-        sweep(1000 + chunk)
-        sweep(5000 + chunk)
-    finally:
-        lib.ff_set_fused_launch(prev)
-
-
 def sweep(seed):
     rng = np.random.default_rng(seed)
     done = 0

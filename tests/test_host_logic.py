@@ -245,7 +245,7 @@ def test_outer_stride_of_token_dense_views():
     assert _outer_stride(full) == 40 and _token_dense(full) is full
     view = full.narrow(2, 0, 6)                                  # what a merge call returns for an M-RoPE table
     assert not view.is_contiguous() and _outer_stride(view) == 40
-    assert _token_dense(view) is view and view._ff_outer_bytes == 40 * 4
+    assert _token_dense(view) is view and not hasattr(view, "_ff_outer_bytes")      # (no cached stride on caller tensors)
     flat = torch.zeros(1, 10, 4).narrow(1, 0, 6)                 # [1, L_out, dh] of a [1, L_cap, dh] buffer: contiguous as it is
     assert flat.is_contiguous() and _outer_stride(flat) == 24
     two = torch.zeros(2, 3, 10, 4)                               # two leading dims, one uniform stride: collapsible
@@ -255,3 +255,12 @@ def test_outer_stride_of_token_dense_views():
     assert _outer_stride(full[..., ::2]) is None
     gathered = _token_dense(full[..., ::2])
     assert gathered.is_contiguous() and gathered.shape == (3, 1, 10, 2)
+    # a broadcast leading dim (cos.expand(3, 1, L, dh): strides (0, L*dh, dh, 1)) has ONE plane in memory: reading three planes
+    # "in place" would run past its storage - it must be copied (the round-4 code passed it through with outer stride 0 = dense)
+    one = torch.arange(40.).reshape(1, 1, 10, 4)
+    exp = one.expand(3, 1, 10, 4)
+    assert exp.stride(0) == 0 and _outer_stride(exp) is None
+    dense = _token_dense(exp)
+    assert dense is not exp and dense.is_contiguous() and torch.equal(dense, exp)
+    lap = torch.zeros(100).as_strided((3, 1, 10, 4), (20, 40, 4, 1))          # overlapping planes: copied as well
+    assert _outer_stride(lap) is None and _token_dense(lap).is_contiguous()
