@@ -71,8 +71,27 @@ def parse():
 
 
 def merge_bytes(L_in, L_out, d, elt, head_dim, pe_outer=1, pe_tables=2):
-    """DESIGN.md §3 / SURVEY.md §8d: compulsory HBM traffic of one merge (or prune) call."""
+    """DESIGN.md §3 / SURVEY.md §8d: compulsory HBM traffic of one merge call that folds something."""
     return L_in * d * elt + L_out * d * elt + pe_tables * (L_in + L_out) * head_dim * elt * pe_outer + 8 * (L_in + L_out)
+
+
+def call_bytes(kind, L_in, L_out, nv, d, elt, head_dim, pe_outer=1, pe_tables=2, kv_heads=0):
+    """Compulsory HBM bytes of one FrameFusion.forward call, by what the call has to touch (reference main.py):
+      merge that folds  : every input row read once, every output row written once, cos/sin in + out, 8-byte ints
+                          (main.py:104-138; SURVEY §8d's formula);
+      identity merge    : the similarity pass reads the Nv visual rows; nothing is folded, so nothing is written and the
+                          caller keeps its tensors (main.py:264-266: an empty merge set returns the input);
+      prune             : the K of the last-query importance (H_kv * S * dh), then ONLY the kept rows move - read and
+                          written once each, with their cos/sin rows - plus ~5 bytes per position of importance / keep / dst
+                          (main.py:61-101 gathers keep_indexs; dropped rows are never read: csrc/ff_merge_body.h `fold == DROP`).
+    Rounds 1-4 charged every call (L_in + L_out) rows, which put the C5 prune gather above the 8 TB/s peak."""
+    row = d * elt
+    pe_row = pe_tables * head_dim * elt * pe_outer
+    if kind == "merge" and L_out == L_in:
+        return nv * row
+    if kind == "merge":
+        return merge_bytes(L_in, L_out, d, elt, head_dim, pe_outer, pe_tables)
+    return kv_heads * L_in * head_dim * elt + 2 * L_out * (row + pe_row) + 5 * L_in
 
 
 def algorithmic_bytes(L_in, L_out, nv, d, elt, head_dim, pe_outer=1):
@@ -99,6 +118,9 @@ def main():
         sys.exit(2)
     dev = torch.device("cuda", local % n_dev)
     torch.cuda.set_device(dev)
+    # this rank's threads (interpreter + the C poll loop) onto the cores of its GPU's NUMA node, before anything pinned exists
+    if world > 1 or os.environ.get("FF_DP_BIND") == "1":
+        dp.bind_to_gpu_numa(dev, local)
     if args.force_dist and world == 1:
         os.environ.setdefault("MASTER_PORT", str(dp.free_port()))
     dist = dp.init(args.backend, dev, force=args.force_dist)
@@ -139,15 +161,28 @@ def main():
     step()
     info = dict(ff.last_call)
     kernel_us, dominant, dense_us = stage_times(ff, _lib, hidden, hidden_alt, ptype, cos, sin, P, L, d, info, dev, args.steps)
-    t_max, elapsed, out = dp.timed_steps(dist, step, args.steps, args.warmup, dev)
+    timed = dp.timed_steps(dist, step, args.steps, args.warmup, dev)
+    t_max, elapsed, out = timed
     reduced = L - out.shape[1]
     L_out = out.shape[1]
     info = ff.last_call
     # whole-job numbers: tokens summed over ranks; one record per rank all_gathered for the report
     _, tok_all = dp.aggregate(dist, elapsed, float(reduced * args.steps), dev)
+    su = timed.step_us
     per_rank = dp.gather_records(dist, (rank, dev.index, L, L_out, elapsed / args.steps * 1e3, dp.sample_seed(args.seed, rank),
-                                        info["count"]), dev)
+                                        info["count"], su.get("min", 0.0), su.get("median", 0.0), su.get("p90", 0.0), su.get("max", 0.0)), dev)
     who = dp.gather_identities(dist, dev)          # hostname / pid / PCI address of every rank's GPU: N ranks = N distinct devices?
+    distinct = len({(w.get("hostname"), w.get("pci_bus_id")) for w in who})
+    backend_used = dist.get_backend() if dist is not None else None
+    if world > 1 and not args.oversubscribe and (distinct != world or backend_used != "nccl"):
+        # an N-GPU line must be N devices talking RCCL: anything else is a functional check and has to say so (--oversubscribe)
+        if rank == 0:
+            print(f"bench.py: --gpus {world} ran on {distinct} distinct device(s) over {backend_used}; one rank per GPU over "
+                  f"RCCL (backend nccl) is required unless --oversubscribe is given", file=sys.stderr)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        sys.exit(3)
     # every rank's kept-token index list, padded to L int32: rank 0 reports a checksum per rank
     kept_idx = torch.nonzero(ff.last_plan()["keep"]).reshape(-1)
     kept_all = dp.gather_kept_indices(dist, kept_idx, L, dev)
@@ -168,10 +203,13 @@ def main():
             "rccl_ranks": dist.get_world_size() if dist is not None else 1,
             "collective_backend": (dist.get_backend() if dist is not None else None),
             "ipc_mode": dp.ipc_mode(), "dp_attempt": dp.attempt(),
-            "distinct_devices": len({(w.get("hostname"), w.get("pci_bus_id")) for w in who}),
+            "distinct_devices": distinct,
+            "timed_region": "per rank: opening barrier -> K steps -> the rank's own synchronize; the closing barrier is outside "
+                            "every clock; ms_per_step = max over ranks (all_reduce MAX)",
             "per_rank": [{"rank": int(r[0]), "gpu": int(r[1]), "tokens_in": int(r[2]), "tokens_out": int(r[3]),
                           "ms_per_step": r[4], "seed": int(r[5]), "similarities_above_threshold": int(r[6]), "hostname": w.get("hostname"), "pid": w.get("pid"),
-                          "pci_bus_id": w.get("pci_bus_id"),
+                          "pci_bus_id": w.get("pci_bus_id"), "numa_node": w.get("numa_node"), "cpus": w.get("cpus"),
+                          "step_us": {"min": r[7], "median": r[8], "p90": r[9], "max": r[10]},
                           "kept_indices": {"n": int(kx.numel()), "sum": int(kx.to(torch.int64).sum()),
                                            "first": kx[:4].tolist(), "last": kx[-4:].tolist()}}
                          for r, w, kx in zip(per_rank, who, kept_all)],
@@ -446,10 +484,10 @@ def cascade(ffa, dev, F, P, d, p_change, thr, pre, post, heads, kv_heads, num, m
                 if n_in not in k_of:
                     k_of[n_in] = k_full[:, :, :n_in].contiguous()
                 w = ffa.last_query_importance(q, k_of[n_in], num=num, is_causal=True, framefusion=ff)
-                bytes_alg += kv_heads * n_in * HEAD_DIM * elt
             h, pe, _ = ff(h, pe, None, w)
             calls.append((ff.last_call["kind"], n_in, h.shape[1]))
-            bytes_alg += merge_bytes(n_in, h.shape[1], d, elt, HEAD_DIM, pe_outer)
+            bytes_alg += call_bytes(ff.last_call["kind"], n_in, h.shape[1], ff.last_call["nv"], d, elt, HEAD_DIM, pe_outer,
+                                    kv_heads=kv_heads)
 
     for rep in range(reps + 2):
         torch.cuda.synchronize()
@@ -479,6 +517,8 @@ def cascade(ffa, dev, F, P, d, p_change, thr, pre, post, heads, kv_heads, num, m
     return {"tokens_in": L, "tokens_out": L_final, "calls": [f"{k}:{a}->{b}" for k, a, b in calls], "us": us,
             "us_back_to_back": us_b2b,
             "tokens_reduced_per_s": (L - L_final) / (us * 1e-6), "algorithmic_bytes": bytes_alg,
+            "algorithmic_bytes_rule": "compulsory per call kind (bench.call_bytes): folding merge (L_in + L_out) rows; identity "
+                                      "merge Nv rows read; prune K + 2 x L_out rows",
             "hbm_frac": bytes_alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
             "hbm_frac_back_to_back": bytes_alg / (us_b2b * 1e-6) / 1e9 / HBM_PEAK_GBS}
 

@@ -42,7 +42,13 @@ def main():
         f.prepare(pt, cfg["patches"], 1, L - 2, L - 2, L)
         return f.forward(h, torch.arange(L)[None], None)[0]
 
-    t_max, mine, out = dp.timed_steps(dist, step, cfg["steps"], cfg["warmup"], dev)
+    timed = dp.timed_steps(dist, step, cfg["steps"], cfg["warmup"], dev)
+    t_max, mine, out = timed
+    spreads = [None] * (dist.get_world_size() if dist else 1)
+    if dist is not None:
+        dist.all_gather_object(spreads, timed.step_us)
+    else:
+        spreads = [timed.step_us]
     recs = dp.gather_records(dist, (L, out.shape[1], mine * 1e3 / cfg["steps"], cfg["seed"]), dev)
     t_all, units = dp.aggregate(dist, mine, float((L - out.shape[1]) * cfg["steps"]), dev)
     ids = dp.gather_identities(dist, dev)
@@ -51,7 +57,7 @@ def main():
     kept_all = [k.tolist() for k in dp.gather_kept_indices(dist, kept, L, dev)]
     if rank == 0:
         print(json.dumps(dict(n_gpus=world, ranks=dist.get_world_size() if dist else 1, records=recs, t_max=t_max,
-                              t_all=t_all, units=units, seed=cfg["seed"], steps=cfg["steps"], identities=ids, kept=kept_all,
+                              t_all=t_all, units=units, seed=cfg["seed"], steps=cfg["steps"], identities=ids, kept=kept_all, step_us=spreads,
                               L=L)))
     if dist is not None:
         dist.barrier()

@@ -71,6 +71,55 @@ def test_ranks_fall_back_to_the_other_ipc_mode_when_the_first_collective_fails()
     assert [i["attempt"] for i in out["identities"]] == [0, 0]
 
 
+@pytest.mark.timeout(300)
+def test_the_closing_barrier_is_in_nobodys_time_and_one_failing_rank_takes_all_with_it():
+    """(a) dp.timed_steps stops a rank's clock at its own synchronize, BEFORE the closing barrier: a rank that dawdles 400 ms
+    inside that barrier (FF_DP_SLOW_BARRIER_MS) must not show in t_max.  (b) The join verdicts travel through the store: when
+    the first collective fails on rank 1 ONLY, rank 0 re-executes as well instead of blocking in its next collective."""
+    out = run_worker("--gpus", "2", "--steps", "3", "--warmup", "1", env_extra={"FF_DP_SLOW_BARRIER_MS": "400"})
+    # (both barriers of the timed region are slowed: 0.8 s of wall time that no rank's clock may contain)
+    assert out["t_max"] < 0.35, out["t_max"]
+    assert all(set(s) == {"min", "median", "p90", "max"} for s in out["step_us"])
+    out = run_worker("--gpus", "2", "--steps", "2", "--warmup", "1",
+                     env_extra={"FF_DP_FAIL_FIRST_ATTEMPT": "1", "FF_DP_FAIL_RANK": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert [i["attempt"] for i in out["identities"]] == [1, 1]
+
+
+def test_numa_binding_reads_sysfs(tmp_path):
+    """dp.numa_of_pci / bind_to_gpu_numa against a fake sysfs tree: node and cpulist of the GPU's PCI function, ranks that
+    share a node split its cores, a platform that does not say (-1) changes nothing."""
+    from framefusion_amd import dp
+    sysfs = tmp_path
+    for bdf, node in (("0000:05:00", 0), ("0000:06:00", 0), ("0000:85:00", 1), ("0000:99:00", -1)):
+        d = sysfs / "bus/pci/devices" / (bdf + ".0")
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text(f"{node}\n")
+    mine = sorted(os.sched_getaffinity(0))
+    assert len(mine) >= 4
+    for node, cpus in ((0, mine[: len(mine) // 2]), (1, mine[len(mine) // 2:])):
+        d = sysfs / "devices/system/node" / f"node{node}"
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(dp.compact_cpulist(cpus) + "\n")
+    assert dp.numa_of_pci("0000:05:00", str(sysfs)) == (0, mine[: len(mine) // 2])
+    assert dp.numa_of_pci("0000:99:00", str(sysfs)) == (None, []) and dp.numa_of_pci("0000:77:00", str(sysfs)) == (None, [])
+    assert dp.parse_cpulist("0-3,8,10-11") == [0, 1, 2, 3, 8, 10, 11] and dp.compact_cpulist([0, 1, 2, 3, 8, 10, 11]) == "0-3,8,10-11"
+    devs = ["0000:05:00", "0000:06:00", "0000:85:00"]
+    try:
+        got = dp.bind_to_gpu_numa("0000:85:00", 2, devs, str(sysfs))            # alone on node 1: the whole node
+        assert got["numa_node"] == 1 and sorted(os.sched_getaffinity(0)) == mine[len(mine) // 2:]
+        assert dp.identity(None)["numa_node"] == 1 and dp.identity(None)["cpus"] == dp.compact_cpulist(mine[len(mine) // 2:])
+        os.sched_setaffinity(0, mine)
+        got = dp.bind_to_gpu_numa("0000:06:00", 1, devs, str(sysfs))            # shares node 0 with rank 0: the second half of it
+        half = mine[: len(mine) // 2]
+        assert got["numa_node"] == 0 and sorted(os.sched_getaffinity(0)) == half[len(half) // 2:]
+        os.sched_setaffinity(0, mine)
+        before = dict(dp._BOUND)
+        assert dp.bind_to_gpu_numa("0000:99:00", 0, devs, str(sysfs)) == before and sorted(os.sched_getaffinity(0)) == mine
+    finally:
+        os.sched_setaffinity(0, mine)
+        dp._BOUND.update(numa_node=None, cpus=None)
+
+
 def test_single_rank_does_not_launch():
     out = run_worker("--gpus", "1", "--steps", "2", "--warmup", "0")
     assert out["n_gpus"] == 1 and out["ranks"] == 1 and len(out["records"]) == 1
@@ -88,8 +137,9 @@ def test_single_process_helpers():
         dp.gather_kept_indices(None, torch.arange(9), 8, cpu)
     assert dp.broadcast_config(None, dict(seed=3, p=0.5), cpu) == dict(seed=3, p=0.5)
     assert dp.init("gloo") is None
-    t_max, mine, out = dp.timed_steps(None, lambda: 7, 3, 1, cpu)
-    assert out == 7 and t_max == mine > 0
+    timed = dp.timed_steps(None, lambda: 7, 3, 1, cpu)
+    t_max, mine, out = timed
+    assert out == 7 and t_max == mine > 0 and set(timed.step_us) == {"min", "median", "p90", "max"}
     dp.launch_ranks(1, "unused", [])             # one rank: returns
 
 
@@ -112,6 +162,7 @@ def test_nccl_init_plumbing_without_a_gpu(monkeypatch):
     monkeypatch.setattr(dist, "is_initialized", lambda: False)
     monkeypatch.setattr(dist, "init_process_group", lambda backend, **kw: calls.append((backend, kw)))
     monkeypatch.setattr(dp, "_probe", lambda *a: None)           # (the first collective: nothing to run it on here)
+    monkeypatch.setattr(dp, "_agree", lambda dist_, ok, world, rank: ok)
     monkeypatch.setenv("FF_DP_NO_RETRY", "1")
     for k in ("MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY"):
         monkeypatch.delenv(k, raising=False)
@@ -120,17 +171,21 @@ def test_nccl_init_plumbing_without_a_gpu(monkeypatch):
     monkeypatch.setenv("LOCAL_RANK", "1")
     dev = torch.device("cuda", 1)
     assert dp.init("nccl", dev) is dist
-    assert calls == [("nccl", {"device_id": dev})]                           # world / rank come from the launcher's env
+    import datetime
+    tmo = {"timeout": datetime.timedelta(seconds=120)}                       # (hangs become errors: FF_DP_INIT_TIMEOUT)
+    assert calls == [("nccl", {**tmo, "device_id": dev})]                    # world / rank come from the launcher's env
     assert os.environ["MASTER_ADDR"] == "127.0.0.1"
-    assert "HSA_ENABLE_IPC_MODE_LEGACY" not in os.environ       # init() reports the IPC mode, it does not set it
+    # unset + the HSA runtime not started yet in this process: the documented value is filled in (it still takes effect);
+    # once CUDA is initialised init() only reports the mode
+    assert os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     calls.clear()
-    assert dp.init("gloo", dev) is dist and calls == [("gloo", {})]          # gloo: no device binding
+    assert dp.init("gloo", dev) is dist and calls == [("gloo", tmo)]         # gloo: no device binding
     calls.clear()
     monkeypatch.setenv("WORLD_SIZE", "1")
     monkeypatch.setenv("RANK", "0")
     assert dp.init("nccl", dev) is None and calls == []                      # one process: no group ...
     assert dp.init("nccl", dev, force=True) is dist                          # ... unless asked for: a one-rank RCCL group
-    assert calls == [("nccl", {"world_size": 1, "rank": 0, "device_id": dev})]
+    assert calls == [("nccl", {**tmo, "world_size": 1, "rank": 0, "device_id": dev})]
     monkeypatch.undo()
     if not torch.cuda.is_available():
         env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}

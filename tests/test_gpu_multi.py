@@ -18,10 +18,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(*argv):
+def run_bench(*argv, env_extra=None, expect_rc=0):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True,
                          timeout=600, env=env, cwd=ROOT)
+    if expect_rc:
+        assert res.returncode == expect_rc, (res.returncode, res.stderr[-2000:])
+        return res.stderr
     assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout
@@ -71,9 +75,18 @@ def test_eight_ranks_sharing_one_gpu_over_gloo():
     """The N = 8 control flow of the driver's scaling run, executed once on whatever the box has: 8 processes (rank r -> GPU
     r % device_count) drive the kernels concurrently, rank 0's config is broadcast, 8 records + 8 identities are
     all_gathered, one JSON line comes out.  (RCCL itself needs 8 devices; gloo carries the scalars here.)"""
-    out = run_bench("--gpus", "8", "--steps", "5", "--warmup", "2", "--backend", "gloo", "--oversubscribe")
+    # the last rank dawdles 300 ms inside every barrier (FF_DP_SLOW_BARRIER_MS): the closing barrier of the timed region is
+    # in nobody's clock, so 5 steps of eight ranks sharing one GPU (~1.2 ms each) stay far below it
+    out = run_bench("--gpus", "8", "--steps", "5", "--warmup", "2", "--backend", "gloo", "--oversubscribe",
+                    env_extra={"FF_DP_SLOW_BARRIER_MS": "300"})
     check_multi(out, 8)
     assert out["collective_backend"] == "gloo"
+    assert out["ms_per_step"] * out["steps"] < 150, out["ms_per_step"]
+    for r in out["per_rank"]:
+        su = r["step_us"]
+        assert 0 < su["min"] <= su["median"] <= su["p90"] <= su["max"]
+        assert "numa_node" in r and "cpus" in r             # (None / None where the platform does not say)
+        assert r["ms_per_step"] <= out["ms_per_step"] * (1 + 1e-9)
     assert [r["seed"] for r in out["per_rank"]] == list(range(1234, 1242))            # seed + rank: 8 distinct samples
     # ... every rank a different video (the top-k branch cuts all of them to the same length: the samples show in their
     # threshold counts)
@@ -87,6 +100,16 @@ def test_eight_ranks_sharing_one_gpu_over_gloo():
     assert all(r["hostname"] and r["pci_bus_id"] for r in out["per_rank"])
     assert out["distinct_devices"] == min(8, n_dev)
     assert out["dp_attempt"] == 0 and "HSA_ENABLE_IPC_MODE_LEGACY" in out["ipc_mode"]
+
+
+@pytest.mark.timeout(900)
+def test_an_n_gpu_line_cannot_be_n_ranks_on_one_device():
+    """`--gpus 2` without --oversubscribe must be two devices over RCCL: on a 1-GPU box every rank refuses before anything
+    runs (and, should ranks ever land on one device anyway, the all_gathered identities refuse the line: exit 3)."""
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a 1-GPU box")
+    err = run_bench("--gpus", "2", "--steps", "2", "--warmup", "1", expect_rc=1)       # torch.distributed.run reports its children's failure
+    assert "GPU(s) visible" in err
 
 
 @pytest.mark.timeout(900)

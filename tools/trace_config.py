@@ -16,6 +16,9 @@ CONFIGS = {   # the argument lists of bench.extra_configs
     "c3": dict(F=64, P=195, d=3584, p_change=0.5, thr=0.6, pre=15, post=12, heads=28, kv_heads=4, num=4, mrope=True, sigma_hi=1.8, seed=77),
     "c5": dict(F=64, P=576, d=8192, p_change=0.95, thr=0.6, pre=14, post=20, heads=64, kv_heads=8, num=1, mrope=False, sigma_hi=None, seed=1234),
     "c5topk": dict(F=64, P=576, d=8192, p_change=0.2, thr=0.6, pre=14, post=20, heads=64, kv_heads=8, num=1, mrope=False, sigma_hi=None, seed=1234),
+    "c2": dict(F=64, P=576, d=4096, p_change=0.2, thr=0.6, pre=0, post=0, heads=32, kv_heads=8, num=1, mrope=False, sigma_hi=None, seed=1234),
+    "7b128": dict(F=128, P=210, d=3584, p_change=0.2, thr=0.6, pre=14, post=20, heads=28, kv_heads=4, num=1, mrope=False, sigma_hi=None, seed=1234),
+    "7b32": dict(F=32, P=210, d=3584, p_change=0.2, thr=0.6, pre=14, post=20, heads=28, kv_heads=4, num=1, mrope=False, sigma_hi=None, seed=1234),
     "7b": dict(F=64, P=210, d=3584, p_change=0.2, thr=0.6, pre=14, post=20, heads=28, kv_heads=4, num=1, mrope=False, sigma_hi=None, seed=1234),
 }
 
