@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--dim", type=int, default=DIM)
     ap.add_argument("--p-change", type=float, default=P_CHANGE)
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--samples", type=int, default=0,
+                    help="independent video samples per step over the whole job (default: one per GPU = the headline definition); "
+                         "sample i goes to rank i %% N, a rank that owns two or more keeps two in flight (FrameFusionPair)")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="collective backend for the scalars exchanged off the timed path (nccl = RCCL over xGMI)")
     ap.add_argument("--oversubscribe", action="store_true",
@@ -126,16 +129,20 @@ def main():
     dist = dp.init(args.backend, dev, force=args.force_dist)
     # rank 0's workload description is THE workload: broadcast over RCCL before anything is generated
     cfg = dp.broadcast_config(dist, dict(seed=args.seed, frames=args.frames, patches=args.patches, dim=args.dim,
-                                         p_change=args.p_change, steps=args.steps, warmup=args.warmup), dev)
+                                         p_change=args.p_change, steps=args.steps, warmup=args.warmup, samples=args.samples), dev)
     args.seed, args.frames, args.patches, args.dim = cfg["seed"], cfg["frames"], cfg["patches"], cfg["dim"]
-    args.p_change, args.steps, args.warmup = cfg["p_change"], cfg["steps"], cfg["warmup"]
+    args.p_change, args.steps, args.warmup, args.samples = cfg["p_change"], cfg["steps"], cfg["warmup"], cfg["samples"]
+    mine = dp.shard(args.samples if args.samples > 0 else world, world, rank)        # the samples this rank owns (round-robin)
+    if not mine:
+        print(f"bench.py: --samples {args.samples} leaves rank {rank} without work", file=sys.stderr)
+        sys.exit(2)
 
     import framefusion_amd as ffa
     from framefusion_amd import _lib
     from framefusion_amd.synth import video_tokens, rotary_tables
 
     F, P, d = args.frames, args.patches, args.dim
-    hidden, ptype = video_tokens(F, P, d, p_change=args.p_change, sigma=SIGMA, seed=dp.sample_seed(args.seed, rank),
+    hidden, ptype = video_tokens(F, P, d, p_change=args.p_change, sigma=SIGMA, seed=dp.sample_seed(args.seed, mine[0]),
                                  dtype=torch.bfloat16, device=str(dev))
     L = hidden.shape[1]
     cos, sin = rotary_tables(L, HEAD_DIM, torch.bfloat16, device=str(dev))
@@ -161,9 +168,15 @@ def main():
     step()
     info = dict(ff.last_call)
     kernel_us, dominant, dense_us = stage_times(ff, _lib, hidden, hidden_alt, ptype, cos, sin, P, L, d, info, dev, args.steps)
-    timed = dp.timed_steps(dist, step, args.steps, args.warmup, dev)
+    timed_step, reduced_of = step, (lambda o: L - o.shape[1])
+    if len(mine) > 1:
+        # this rank owns several samples per step (C4 with more samples than GPUs): two in flight at a time, one host thread
+        timed_step, reduced_of = multi_sample_step(ffa, dev, mine, args, F, P, d, L, cos, sin, hidden, hidden_alt, ptype, ff)
+        timed_step()
+    timed = dp.timed_steps(dist, timed_step, args.steps, args.warmup, dev)
     t_max, elapsed, out = timed
-    reduced = L - out.shape[1]
+    reduced = reduced_of(out)
+    out = out[0] if isinstance(out, list) else out
     L_out = out.shape[1]
     info = ff.last_call
     # whole-job numbers: tokens summed over ranks; one record per rank all_gathered for the report
@@ -225,9 +238,11 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"C2: one FrameFusion.forward merge call on [1, {F}x{P}, {d}] bf16, "
                                    f"cost={COST} thr={THRESHOLD} lb={RATIO_LB}, p_change={args.p_change} "
-                                   f"({'top-k' if info['branch'] else 'threshold'} branch), one sample per GPU",
-                       "tokens_in": L, "tokens_out": L_out, "samples_per_gpu_per_step": 1,
-                       "tokens_processed_per_s": world * L * args.steps / t_max,
+                                   f"({'top-k' if info['branch'] else 'threshold'} branch), "
+                                   + ("one sample per GPU" if len(mine) == 1 else f"{len(mine)} samples per GPU, two in flight (FrameFusionPair)"),
+                       "tokens_in": L, "tokens_out": L_out, "samples_per_gpu_per_step": len(mine),
+                       "samples_per_step": args.samples if args.samples > 0 else world,
+                       "tokens_processed_per_s": (args.samples if args.samples > 0 else world) * L * args.steps / t_max,
                        "parallelism": f"dp{world} (independent samples)"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -235,8 +250,8 @@ def main():
                          "algorithmic_bytes": alg[dominant], "kernel_us": dense_us,
                          "kernel_us_own_event_pair": kernel_us[dominant]},
             "kernels_us": kernel_us,
-            "step_roofline": {"algorithmic_bytes": alg["step"], "achieved": alg["step"] / (ms_per_step * 1e-3) / 1e9,
-                              "frac": alg["step"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "step_roofline": {"algorithmic_bytes": alg["step"] * len(mine), "achieved": alg["step"] * len(mine) / (ms_per_step * 1e-3) / 1e9,
+                              "frac": alg["step"] * len(mine) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
         if world == 1 and headline and not args.no_extra:
             # the same step with prepare() fed the way the reference's packers do it: start / end index as 1-element
@@ -264,6 +279,36 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))
+
+
+def multi_sample_step(ffa, dev, mine, args, F, P, d, L, cos, sin, hidden0, hidden0_alt, ptype0, ff0):
+    """(step, reduced_of) for a rank that owns the samples `mine` (indices into the job's sample list): every step reduces
+    all of them - consecutive samples two at a time through FrameFusionPair (one host thread, two streams), an odd one out
+    alone.  Each sample has its own instance and two copies of its input (alternated like the headline loop)."""
+    from framefusion_amd import dp
+    from framefusion_amd.synth import video_tokens
+    work = [dict(h=hidden0, h2=hidden0_alt, pt=ptype0, ff=ff0)]
+    for idx in mine[1:]:
+        h, pt = video_tokens(F, P, d, p_change=args.p_change, sigma=SIGMA, seed=dp.sample_seed(args.seed, idx), dtype=torch.bfloat16,
+                             device=str(dev))
+        work.append(dict(h=h, h2=h.clone(), pt=pt, ff=ffa.FrameFusion(COST, THRESHOLD, RATIO_LB)))
+    pairs = [ffa.FrameFusionPair(work[j]["ff"], work[j + 1]["ff"], dev, sync_with_current=False) for j in range(0, len(work) - 1, 2)]
+    flip = [0]
+
+    def step():
+        flip[0] ^= 1
+        outs = []
+        for w in work:
+            w["ff"].prepare(w["pt"], P, 0, L, L, L)
+        for j, pair in enumerate(pairs):
+            a, b = work[2 * j], work[2 * j + 1]
+            oa, ob = pair((a["h2"] if flip[0] else a["h"], [cos, sin], None), (b["h2"] if flip[0] else b["h"], [cos, sin], None))
+            outs += [oa[0], ob[0]]
+        if len(work) & 1:
+            w = work[-1]
+            outs.append(w["ff"](w["h2"] if flip[0] else w["h"], [cos, sin], None)[0])
+        return outs
+    return step, (lambda outs: sum(L - o.shape[1] for o in outs))
 
 
 def step_spread(step, n):
@@ -451,15 +496,37 @@ def two_samples_per_gpu(ffa, dev, F, P, d, p_change, seed, steps, warmup):
     for th in threads:
         th.join()
     reduced = sum(w["L"] - w["out"].shape[1] for w in work)
-    return {"samples_in_flight": 2, "steps_per_sample": steps, "us_per_pair_of_steps": dt / steps * 1e6,
-            "tokens_reduced_per_s": reduced * steps / dt}
+    threads_res = {"us_per_pair_of_steps": dt / steps * 1e6, "tokens_reduced_per_s": reduced * steps / dt}
+    # the same two samples from ONE host thread: FrameFusionPair -> ff_ctx_merge_pair (both similarity passes, then both plan +
+    # merge pairs enqueued on two streams before either result block is waited for)
+    pair = ffa.FrameFusionPair(work[0]["ff"], work[1]["ff"], dev, sync_with_current=False)
+
+    def pair_step(i):
+        for w in work:
+            w["ff"].prepare(w["pt"], P, 0, w["L"], w["L"], w["L"])
+        return pair(*[(w["h2"] if i & 1 else w["h"], [w["cos"], w["sin"]], None) for w in work])
+    for i in range(warmup):
+        pair_step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        outs = pair_step(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    reduced = sum(w["L"] - o[0].shape[1] for w, o in zip(work, outs))
+    return {"samples_in_flight": 2, "steps_per_sample": steps,
+            "one_host_thread_pair": {"us_per_pair_of_steps": dt / steps * 1e6, "tokens_reduced_per_s": reduced * steps / dt,
+                                     "how": "framefusion_amd.FrameFusionPair (ff_ctx_merge_pair), two HIP streams, no threads"},
+            "two_threads": threads_res,
+            "us_per_pair_of_steps": dt / steps * 1e6, "tokens_reduced_per_s": reduced * steps / dt}
 
 
 def cascade(ffa, dev, F, P, d, p_change, thr, pre, post, heads, kv_heads, num, mrope, sigma_hi=1.6, reps=6, seed=1234,
-            idle_before_b2b_s=0.0):
+            idle_before_b2b_s=0.0, defer=True):
     """Every FrameFusion.forward call of ONE prefill (call A, then call B per layer until merging and pruning are
     finished), the importance of the prune call computed by the HIP attention-hook kernel from synthetic q / K
-    (un-repeated GQA heads).  GPU time of the whole cascade (one synchronise at the end), mean over `reps`."""
+    (un-repeated GQA heads) - `defer`: inside the prune's own host call (the handle the adapters in framefusion_amd/models pass;
+    round 5), else by the hook's own call before it (rounds 1-4).  GPU time of the whole cascade (one synchronise at the end), mean over `reps`."""
     from framefusion_amd.synth import video_tokens, rotary_tables
     h0, pt = video_tokens(F, P, d, p_change=p_change, sigma=SIGMA, sigma_hi=sigma_hi, seed=seed, pre=pre, post=post,
                           dtype=torch.bfloat16, device=str(dev))
@@ -483,7 +550,7 @@ def cascade(ffa, dev, F, P, d, p_change, thr, pre, post, heads, kv_heads, num, m
             if ff.finish_merging and not ff.finish_pruning:            # what the attention hook hands over
                 if n_in not in k_of:
                     k_of[n_in] = k_full[:, :, :n_in].contiguous()
-                w = ffa.last_query_importance(q, k_of[n_in], num=num, is_causal=True, framefusion=ff)
+                w = ffa.last_query_importance(q, k_of[n_in], num=num, is_causal=True, framefusion=ff, defer=defer)
             h, pe, _ = ff(h, pe, None, w)
             calls.append((ff.last_call["kind"], n_in, h.shape[1]))
             bytes_alg += call_bytes(ff.last_call["kind"], n_in, h.shape[1], ff.last_call["nv"], d, elt, HEAD_DIM, pe_outer,

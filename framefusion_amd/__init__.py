@@ -9,9 +9,10 @@ from .interface import (apply_framefusion, get_token_type, replace_framefusion_f
                         register_family, Family)
 from .utils import get_attr_by_name, scaled_dot_product_attention, last_query_importance  # noqa: F401
 from ._lib import FrameFusionHipError, build, load  # noqa: F401
+from .pair import FrameFusionPair  # noqa: F401
 from . import layout, baseline  # noqa: F401
 
 __all__ = ["FrameFusion", "apply_framefusion", "get_token_type", "replace_framefusion_forward",
            "register_family", "Family", "scaled_dot_product_attention", "last_query_importance",
            "get_attr_by_name", "cosine_similarity", "find_contigious_latter_index", "call_b_with_residual",
-           "TEXT_TOKEN", "IGNORE_TOKEN", "FrameFusionHipError", "build", "load", "layout", "baseline"]
+           "TEXT_TOKEN", "IGNORE_TOKEN", "FrameFusionPair", "FrameFusionHipError", "build", "load", "layout", "baseline"]

@@ -91,6 +91,16 @@ PRUNE_CALL_AUX_OFFSET = PRUNE_CALL_HEAD.size
 PRUNE_CALL_MASK_OFFSET = PRUNE_CALL_AUX_OFFSET + MAX_AUX * AUX_ENTRY.size
 
 
+class FFLqArgs(C.Structure):
+    """ff_lq_args_t (every member 8 bytes wide: LQ_ARGS.pack_into)."""
+    _fields_ = [("q_last", C.c_void_p), ("k", C.c_void_p), ("dtype", C.c_int64), ("H", C.c_int64), ("H_kv", C.c_int64),
+                ("num", C.c_int64), ("dh", C.c_int64), ("k_head_stride", C.c_int64), ("k_key_stride", C.c_int64),
+                ("scale", C.c_double), ("causal", C.c_int64), ("bias", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t)]
+
+
+LQ_ARGS = struct.Struct("=2Q7qdq3Q")
+
+
 class FFSegment(C.Structure):
     _fields_ = [("begin", C.c_int32), ("count", C.c_int32), ("first", C.c_int32), ("period", C.c_int32)]
 
@@ -136,7 +146,9 @@ PROTOTYPES = {
     "ff_ctx_merge_begin": (_i32, [_vp, _vp]),
     "ff_ctx_merge_finish": (_i32, [_vp, _vp, _vp]),
     "ff_ctx_merge": (_i32, [_vp, _vp, _vp]),
+    "ff_ctx_merge_pair": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "ff_ctx_prune": (_i32, [_vp, _vp]),
+    "ff_ctx_prune_from_qk": (_i32, [_vp, _vp, _vp]),
     "ff_ctx_gather_mask": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "ff_ctx_reset": (_i32, [_vp, _vp]),
     "ff_ctx_expect_tables": (None, [_vp]),
@@ -248,7 +260,7 @@ def load():
     got = lib.ff_abi_version()
     if got != ABI_VERSION:
         raise FrameFusionHipError(f"ABI mismatch: library {got}, binding {ABI_VERSION}")
-    for which, cls in enumerate((FFCtx, FFMergeCall, FFMergeResult, FFPruneCall, FFAux)):
+    for which, cls in enumerate((FFCtx, FFMergeCall, FFMergeResult, FFPruneCall, FFAux, FFLqArgs)):
         if lib.ff_abi_sizeof(which) != C.sizeof(cls):
             raise FrameFusionHipError(f"ABI mismatch: sizeof({cls.__name__}) is {C.sizeof(cls)} here, "
                                       f"{lib.ff_abi_sizeof(which)} in the library")

@@ -246,6 +246,7 @@ extern "C" size_t ff_abi_sizeof(int which) {
         case 2: return sizeof(ff_merge_result_t);
         case 3: return sizeof(ff_prune_call_t);
         case 4: return sizeof(ff_aux_t);
+        case 5: return sizeof(ff_lq_args_t);
         default: return 0;
     }
 }
@@ -326,19 +327,18 @@ static int ctx_finish_enqueue(ff_ctx_t* c, const ff_merge_call_t* a) {
     return rc;
 }
 
-extern "C" int ff_ctx_merge_finish(ff_ctx_t* c, const ff_merge_call_t* a, ff_merge_result_t* r) {
-    if (!a || !r) return FF_ERR_ARG;
-    int rc = ctx_check(c, a->L);
-    if (rc) return rc;
-    if (!c->in_flight) return FF_ERR_STATE;
-    if (a->mask && !a->mask_out) return FF_ERR_ARG;
+// everything of a finish that follows the argument checks; `enqueued`: plan + K4 of the first attempt are already on the stream
+static int ctx_finish(ff_ctx_t* c, const ff_merge_call_t* a, ff_merge_result_t* r, bool enqueued) {
+    int rc;
     c->in_flight = 0;
     hipStream_t st = (hipStream_t)a->stream;
     r->unhinted = 0;
     r->wait_ns = 0;
     for (int attempt = 0;; ++attempt) {
-        rc = ctx_finish_enqueue(c, a);
-        if (rc) { c->dirty = 1; c->order_len = 0; return rc; }
+        if (!(enqueued && attempt == 0)) {
+            rc = ctx_finish_enqueue(c, a);
+            if (rc) { c->dirty = 1; c->order_len = 0; return rc; }
+        }
         int64_t waited = 0;
         rc = ctx_wait(c, st, &waited);
         r->wait_ns += waited;
@@ -389,6 +389,49 @@ extern "C" int ff_ctx_merge_finish(ff_ctx_t* c, const ff_merge_call_t* a, ff_mer
     return FF_OK;
 }
 
+static int ctx_finish_check(ff_ctx_t* c, const ff_merge_call_t* a, ff_merge_result_t* r) {
+    if (!a || !r) return FF_ERR_ARG;
+    int rc = ctx_check(c, a->L);
+    if (rc) return rc;
+    if (!c->in_flight) return FF_ERR_STATE;
+    if (a->mask && !a->mask_out) return FF_ERR_ARG;
+    return FF_OK;
+}
+
+extern "C" int ff_ctx_merge_finish(ff_ctx_t* c, const ff_merge_call_t* a, ff_merge_result_t* r) {
+    int rc = ctx_finish_check(c, a, r);
+    if (rc) return rc;
+    return ctx_finish(c, a, r, false);
+}
+
+// Two samples in flight from ONE host thread: both similarity passes, then both plan + merge pairs are enqueued (each sample
+// on its own stream) before either result is waited for, so one sample's plan bubble and kernel ramps sit under the other's
+// streaming pass.  Returns the first failure; on FF_OK both results are valid.  When sample A fails after B was begun, B is
+// still finished (its scratch stays consistent) and A's code is returned.
+extern "C" int ff_ctx_merge_pair(ff_ctx_t* ca, const ff_merge_call_t* a, ff_merge_result_t* ra,
+                                 ff_ctx_t* cb, const ff_merge_call_t* b, ff_merge_result_t* rb) {
+    if (!ca || !cb || ca == cb || !a || !b || !ra || !rb) return FF_ERR_ARG;
+    if (a->stream == b->stream) return FF_ERR_ARG;          // (one stream would serialise the pair: use two calls then)
+    int rc = ff_ctx_merge_begin(ca, a);
+    if (rc) return rc;
+    rc = ctx_finish_check(ca, a, ra);
+    if (rc) { ca->in_flight = 0; ca->dirty = 1; ca->order_len = 0; return rc; }
+    rc = ff_ctx_merge_begin(cb, b);
+    if (!rc) rc = ctx_finish_check(cb, b, rb);
+    if (rc) {                                               // B never started: A goes on alone, B's failure is reported
+        if (cb) { cb->in_flight = 0; cb->dirty = 1; cb->order_len = 0; }
+        const int rca = ctx_finish(ca, a, ra, false);
+        return rca ? rca : rc;
+    }
+    int ea = ctx_finish_enqueue(ca, a);
+    if (ea) { ca->in_flight = 0; ca->dirty = 1; ca->order_len = 0; }
+    int eb = ctx_finish_enqueue(cb, b);
+    if (eb) { cb->in_flight = 0; cb->dirty = 1; cb->order_len = 0; }
+    const int rca = ea ? ea : ctx_finish(ca, a, ra, true);
+    const int rcb = eb ? eb : ctx_finish(cb, b, rb, true);
+    return rca ? rca : rcb;
+}
+
 extern "C" int ff_ctx_merge(ff_ctx_t* c, const ff_merge_call_t* a, ff_merge_result_t* r) {
     int rc = ff_ctx_merge_begin(c, a);
     if (rc) return rc;
@@ -427,4 +470,31 @@ extern "C" int ff_ctx_prune(ff_ctx_t* c, const ff_prune_call_t* a) {
         rc = ff_gather_mask(a->mask, a->mask_out, a->mask_elem_bytes, a->S, a->L_cap, c->dst, c->stats,
                             ff::ws_scratch_ints(c->ws, c->cap), a->stream);
     return rc;
+}
+
+// hook + prune from one host call: importance (+ select tables) -> plan -> gather, all enqueued here
+extern "C" int ff_ctx_prune_from_qk(ff_ctx_t* c, const ff_prune_call_t* a, const ff_lq_args_t* q) {
+    if (!a || !q) return FF_ERR_ARG;
+    int rc = ctx_check(c, a->S);
+    if (rc) return rc;
+    if (c->in_flight) return FF_ERR_STATE;
+    if (a->S < 1 || a->start < 0 || a->n_img < 0 || a->start + a->n_img > a->S || a->k < 0 || a->k > a->n_img) return FF_ERR_ARG;
+    if (q->dtype != FF_F32 && q->dtype != FF_BF16 && q->dtype != FF_F16) return FF_ERR_ARG;
+    rc = ctx_clean(c, (hipStream_t)a->stream);          // (select tables zero on entry)
+    if (rc) return rc;
+    c->seq += 1;
+    c->dirty = 1;                                       // until the prune below has enqueued the kernel that clears the tables
+    c->order_len = 0;
+    c->last_L = 0;
+    rc = ff_last_query_attention(q->q_last, q->k, (int)q->dtype, q->H, q->H_kv, q->num, a->S, q->dh, q->k_head_stride, q->k_key_stride,
+                                 q->scale, (int)q->causal, q->bias, nullptr, c->sim, a->start, a->start + a->n_img, c->ws, c->ws_bytes,
+                                 q->ws, q->ws_bytes, a->stream);
+    if (rc) return rc;
+    ff_prune_call_t b = *a;
+    b.attn_w = c->sim;
+    b.w_dtype = q->dtype;
+    b.H = 1;
+    b.num = 1;
+    b.tables_ready = 1;
+    return ff_ctx_prune(c, &b);
 }

@@ -21,6 +21,7 @@ from torch import nn
 
 from . import _lib
 from ._lib import FrameFusionHipError
+from .utils import LastQuery
 
 TEXT_TOKEN = -1
 IGNORE_TOKEN = -2
@@ -60,6 +61,9 @@ class _Scratch:
         self.pcall_ptr = C.addressof(self.pcall)
         self.res = _lib.FFMergeResult()
         self.res_ptr = C.addressof(self.res)
+        self.lqargs = _lib.FFLqArgs()
+        self.lqargs_ptr = C.addressof(self.lqargs)
+        self.lq_ws = None               # workspace of the importance kernels (grow-only; prune_from_qk)
         self.order_gen = None           # patch_type generation the context's by-patch order belongs to
         self.tables_token = None
         self.last_stream = None
@@ -412,15 +416,29 @@ class FrameFusion(nn.Module):
         before any output tensor exists (the allocations below overlap it), ff_ctx_merge_finish enqueues
         plan + merge and waits - in C, interpreter lock released - for the 256-byte result block the plan
         kernel publishes before the second streaming pass starts."""
-        _lib.require_gpu(hidden_states, "FrameFusion.forward")
         lib = _lib.load()
+        st = self._merge_prepare(hidden_states, position_embeddings, attention_mask, residual)
+        sc = st["sc"]
+        rc = lib.ff_ctx_merge_begin(sc.ctx_ptr, sc.call_ptr)
+        if rc:
+            _fail(rc, "merge")
+        self._merge_outputs(st)
+        # The one device->host hand-off of the call: the plan kernel stores the result block into pinned
+        # host memory (sequence word last) BEFORE the merge kernel runs, so the host learns L_out while the
+        # second streaming pass is still in flight and returns without waiting for it.
+        rc = lib.ff_ctx_merge_finish(sc.ctx_ptr, sc.call_ptr, sc.res_ptr)
+        return self._merge_complete(st, rc)
+
+    def _merge_prepare(self, hidden_states, position_embeddings, attention_mask, residual=None):
+        """Validation + the input half of the call block (everything ff_ctx_merge_begin reads), on PyTorch's current stream."""
+        _lib.require_gpu(hidden_states, "FrameFusion.forward")
         bsz, L, d = hidden_states.shape
         assert bsz == 1, "Only support batch size 1"                                # main.py:203
         device = hidden_states.device
         dtype = hidden_states.dtype
         code = _dtype_code(hidden_states)
         hidden = hidden_states if hidden_states.is_contiguous() else hidden_states.contiguous()
-        addend_ptr = 0
+        addend_ptr, addend = 0, None
         if residual is not None:
             addend = residual if residual.is_contiguous() else residual.contiguous()
             addend_ptr = addend.data_ptr()
@@ -446,36 +464,43 @@ class FrameFusion(nn.Module):
             hint = self.__dict__.get("_layout_hint")
             if hint is not None and hint[0] + hint[1] * P <= L:
                 hint_pre, hint_frames = hint
-        call = sc.call
-        _lib.MERGE_CALL_HEAD.pack_into(call, 0, hidden.data_ptr(), addend_ptr, 0, ptype.data_ptr(), code, L, d, L, P,
+        _lib.MERGE_CALL_HEAD.pack_into(sc.call, 0, hidden.data_ptr(), addend_ptr, 0, ptype.data_ptr(), code, L, d, L, P,
                                        order_valid, self._threshold_for(dtype), sub, self.ratio_lower_bound, -1,
                                        _lib.FOLD_SEQUENTIAL, hint_pre, hint_frames, stream or 0, 0)
         sc.order_gen = None                  # until the call has come back
-        rc = lib.ff_ctx_merge_begin(sc.ctx_ptr, sc.call_ptr)
-        if rc:
-            _fail(rc, "merge")
+        return dict(sc=sc, stream=stream, L=L, d=d, dtype=dtype, device=device, hidden=hidden, addend=addend, ptype=ptype,
+                    hidden_states=hidden_states, position_embeddings=position_embeddings, attention_mask=attention_mask,
+                    mask_in=mask_in, residual=residual)
 
+    def _merge_outputs(self, st):
+        """The output half of the call block (read by ff_ctx_merge_finish only): allocated while the similarity pass runs."""
+        sc, L, d, dtype, device, ptype = st["sc"], st["L"], st["d"], st["dtype"], st["device"], st["ptype"]
+        call = sc.call
         L_cap = L
         out = torch.empty((1, L_cap, d), dtype=dtype, device=device)
         ptype_out = torch.empty((1, L_cap), dtype=torch.int64, device=device)
-        srcs, outs, rebuild = self._aux_for_positions(position_embeddings, L, L_cap)
+        srcs, outs, rebuild = self._aux_for_positions(st["position_embeddings"], L, L_cap)
         _lib.AUX_ENTRY.pack_into(call, _lib.MERGE_CALL_AUX_OFFSET, ptype.data_ptr(), ptype_out.data_ptr(), 8, 1, 0)    # patch types
         n_aux = 1 + sc.put_aux(call, _lib.MERGE_CALL_AUX_OFFSET + _lib.AUX_ENTRY.size, zip(srcs, outs), L, room=_lib.MAX_AUX - 1)
         _PACK_PTR.pack_into(call, 16, out.data_ptr())
         _PACK_I64.pack_into(call, _lib.MERGE_CALL_AUX_OFFSET - 8, n_aux)
-        # (the attention mask is gathered behind the call, into a buffer of the OUTPUT length: see below.  The C ABI's other
-        # form - mask + an [L_cap, L_cap] buffer in the call block, gathered by ff_ctx_merge_finish itself - is what a host
-        # without a cheap allocator uses; `_mask_through_call` routes through it for the tests)
-        mask_cap = None
+        # (the attention mask is gathered behind the call, into a buffer of the OUTPUT length: see _merge_complete.  The C
+        # ABI's other form - mask + an [L_cap, L_cap] buffer in the call block, gathered by ff_ctx_merge_finish itself - is
+        # what a host without a cheap allocator uses; `_mask_through_call` routes through it for the tests)
+        mask_cap, mask_in = None, st["mask_in"]
         if mask_in is not None and self.__dict__.get("_mask_through_call"):
             mask_cap = torch.empty(1, 1, L_cap, L_cap, dtype=mask_in.dtype, device=mask_in.device)
             _lib.MASK_TRIPLE.pack_into(call, _lib.MERGE_CALL_MASK_OFFSET, mask_in.data_ptr(), mask_cap.data_ptr(), mask_in.element_size())
         else:
             _lib.MASK_TRIPLE.pack_into(call, _lib.MERGE_CALL_MASK_OFFSET, 0, 0, 0)
-        # The one device->host hand-off of the call: the plan kernel stores the result block into pinned
-        # host memory (sequence word last) BEFORE the merge kernel runs, so the host learns L_out while the
-        # second streaming pass is still in flight and returns without waiting for it.
-        rc = lib.ff_ctx_merge_finish(sc.ctx_ptr, sc.call_ptr, sc.res_ptr)
+        st.update(out=out, ptype_out=ptype_out, srcs=srcs, rebuild=rebuild, mask_cap=mask_cap, L_cap=L_cap)
+
+    def _merge_complete(self, st, rc):
+        """The result block -> the state machine of main.py:112-138 and the returned views."""
+        lib = _lib.load()
+        sc, L, dtype, stream = st["sc"], st["L"], st["dtype"], st["stream"]
+        hidden_states, position_embeddings, attention_mask, residual = (st["hidden_states"], st["position_embeddings"],
+                                                                        st["attention_mask"], st["residual"])
         nv, ftn, count, branch, k, L_out, err, unhinted, wait_ns = _lib.MERGE_RESULT.unpack_from(sc.res)
         if unhinted:
             # patch_type is not the frame-major layout the prepare() scalars suggested (e.g. text between
@@ -510,18 +535,19 @@ class FrameFusion(nn.Module):
         # (now the context's current one), so the next merge call of this prefill skips K0
         self.last_call = dict(kind="merge", L_in=L, L_out=L_out, nv=nv, ftn=ftn, count=count, branch=branch,
                               k=k, scratch=sc, dtype=dtype, order=sc.order_next, wait_ns=wait_ns)
+        mask_cap, L_cap = st["mask_cap"], st["L_cap"]
         if mask_cap is not None:
             attention_mask = mask_cap[:, :, :L_out, :L_out]
         elif attention_mask is not None:                                            # main.py:137-138
             # gathered now that L_out is known: [1, 1, L_out, L_out] exactly (an input-sized capacity buffer would be
             # 2.7 GB for a bf16 mask at 37 k tokens), on the keep set still sitting in the context
-            m = mask_in
+            m = st["mask_in"]
             mask_out = torch.empty(1, 1, L_out, L_out, dtype=m.dtype, device=m.device)
             rc = lib.ff_ctx_gather_mask(sc.ctx_ptr, m.data_ptr(), mask_out.data_ptr(), m.element_size(), L, L_out, stream or 0)
             if rc:
                 _fail(rc, "merge (attention mask)")
             attention_mask = mask_out
-        hidden_out, ptype_new, pos_new = out.narrow(1, 0, L_out), ptype_out.narrow(1, 0, L_out), rebuild(L_out)
+        hidden_out, ptype_new, pos_new = st["out"].narrow(1, 0, L_out), st["ptype_out"].narrow(1, 0, L_out), st["rebuild"](L_out)
         if self.compact_outputs and 2 * L_out < L_cap:
             hidden_out, ptype_new = hidden_out.clone(), ptype_new.clone()
             if type(pos_new) == list:
@@ -581,19 +607,28 @@ class FrameFusion(nn.Module):
         sc, stream = self._scratch_for(device, q_len)
 
         w = self_attn_weights                                                       # main.py:69-70
-        _lib.require_gpu(w, "FrameFusion.forward(self_attn_weights)")
-        if w.ndim != 4 or w.shape[0] != 1 or w.shape[-1] != q_len:
-            raise FrameFusionHipError(f"self_attn_weights of shape {tuple(w.shape)} is not [1, H, num, {q_len}]")
-        # the head mean and the top-k run in the WEIGHTS' dtype (main.py:69-76: torch.mean / topk of the
-        # tensor the attention hook handed over), whatever the activation dtype is
-        w_code = _lib.DTYPE_CODE.get(w.dtype)
-        if w_code is None:
-            raise FrameFusionHipError(f"unsupported attention-weight dtype {w.dtype} (fp32 / bf16 / fp16 only)")
-        token = getattr(w, "_ff_tables", None)
-        if not w.is_contiguous():
-            w = w.contiguous()
-        if w.data_ptr() & 15:
-            w = w.clone()
+        lq = w if type(w) is LastQuery else None
+        if lq is not None:
+            # the hook handed over q_last / K instead of weights (last_query_importance(..., defer=True)): importance, plan
+            # and gather go out in ONE host call below
+            if lq.S != q_len or lq.device != device:
+                raise FrameFusionHipError(f"the deferred importance covers {lq.S} keys on {lq.device}, the sequence has {q_len} tokens on {device}")
+            w_code, token, w_ptr, w_dtype = lq.code, None, 0, lq.dtype
+        else:
+            _lib.require_gpu(w, "FrameFusion.forward(self_attn_weights)")
+            if w.ndim != 4 or w.shape[0] != 1 or w.shape[-1] != q_len:
+                raise FrameFusionHipError(f"self_attn_weights of shape {tuple(w.shape)} is not [1, H, num, {q_len}]")
+            # the head mean and the top-k run in the WEIGHTS' dtype (main.py:69-76: torch.mean / topk of the
+            # tensor the attention hook handed over), whatever the activation dtype is
+            w_code = _lib.DTYPE_CODE.get(w.dtype)
+            if w_code is None:
+                raise FrameFusionHipError(f"unsupported attention-weight dtype {w.dtype} (fp32 / bf16 / fp16 only)")
+            token = getattr(w, "_ff_tables", None)
+            if not w.is_contiguous():
+                w = w.contiguous()
+            if w.data_ptr() & 15:
+                w = w.clone()
+            w_ptr, w_dtype = w.data_ptr(), w.dtype
         pruning_ratio = self._compute_pruning_ratio(self.sparsity_list, self.cost)  # main.py:73
         k = round(n_img * (1 - pruning_ratio))                                      # main.py:76
         if k < 0 or k > n_img:
@@ -603,7 +638,7 @@ class FrameFusion(nn.Module):
         # select tables of exactly this call in the workspace
         H, num = w.shape[1], w.shape[2]
         tables_ready = int(token is not None and token == sc.tables_token and
-                           token == (id(sc), sc.seq, q_len, start, n_img, w.dtype, k) and H * num == 1)
+                           token == (id(sc), sc.seq, q_len, start, n_img, w_dtype, k) and H * num == 1)
         sc.tables_token = None
         # nothing is read back (L_out is known): head mean + select tables, plan, gather - one host call
         out = torch.empty((1, L_out, d), dtype=dtype, device=device)
@@ -614,7 +649,7 @@ class FrameFusion(nn.Module):
             addend_ptr = addend.data_ptr()
         call = sc.pcall
         n_aux = sc.put_aux(call, _lib.PRUNE_CALL_AUX_OFFSET, zip(srcs, outs), q_len)
-        _lib.PRUNE_CALL_HEAD.pack_into(call, 0, hidden.data_ptr(), addend_ptr, out.data_ptr(), w.data_ptr(), code, q_len, d,
+        _lib.PRUNE_CALL_HEAD.pack_into(call, 0, hidden.data_ptr(), addend_ptr, out.data_ptr(), w_ptr, code, q_len, d,
                                        L_out, w_code, H, num, tables_ready, start, n_img, k, stream or 0, n_aux)
         mask_out = None
         if attention_mask is not None:
@@ -624,12 +659,35 @@ class FrameFusion(nn.Module):
         else:
             _lib.MASK_TRIPLE.pack_into(call, _lib.PRUNE_CALL_MASK_OFFSET, 0, 0, 0)
         sc.order_gen = None
-        rc = lib.ff_ctx_prune(sc.ctx_ptr, sc.pcall_ptr)
+        if lq is not None:
+            need = int(lib.ff_last_query_workspace_bytes(lq.code, lq.H, lq.num, q_len, lq.dh))
+            if sc.lq_ws is None or sc.lq_ws.numel() < need:
+                if sc.lq_ws is not None and sc.last_stream is not None:
+                    sc.lq_ws.record_stream(sc.last_stream)
+                sc.lq_ws = torch.empty(need, dtype=torch.uint8, device=device)
+            _lib.LQ_ARGS.pack_into(sc.lqargs, 0, lq.q_last.data_ptr(), lq.k.data_ptr(), lq.code, lq.H, lq.H_kv, lq.num, lq.dh, lq.sh, lq.ss,
+                                   lq.factor, 1 if lq.is_causal else 0, lq.bias.data_ptr() if lq.bias is not None else 0,
+                                   sc.lq_ws.data_ptr(), sc.lq_ws.numel())
+            rc = lib.ff_ctx_prune_from_qk(sc.ctx_ptr, sc.pcall_ptr, sc.lqargs_ptr)
+        else:
+            rc = lib.ff_ctx_prune(sc.ctx_ptr, sc.pcall_ptr)
         if rc:
             _fail(rc, "prune")
         self.finish_pruning = True                                                  # main.py:101
-        self.last_call = dict(kind="prune", L_in=q_len, L_out=L_out, k=k, nv=q_len, scratch=sc, dtype=w.dtype)
+        self.last_call = dict(kind="prune", L_in=q_len, L_out=L_out, k=k, nv=q_len, scratch=sc, dtype=w_dtype)
         return out, rebuild(L_out), mask_out
+
+    def prune_from_qk(self, hidden_states, position_embeddings, attention_mask, query, key, num=1, is_causal=True, scale=None,
+                      residual=None):
+        """The prune call (main.py:61-101) fed by the attention hook's INPUTS instead of its output: ``query`` [1, H, L, dh] /
+        ``key`` [1, H_kv, S, dh] of the layer (un-repeated GQA keys, utils.py:27-57 semantics).  Importance, select, gather =
+        one crossing of the C ABI (``ff_ctx_prune_from_qk``), nothing read back.  Equal to
+        ``forward(hidden, pos, mask, last_query_importance(query, key, num, is_causal, scale, framefusion=self))``."""
+        bsz, q_len, _ = hidden_states.size()
+        if not (q_len > 1 and self.finish_merging == True and self.finish_pruning == False):
+            raise FrameFusionHipError("prune_from_qk: no prune is due (finish_merging must be set, finish_pruning not)")
+        return self.forward(hidden_states, position_embeddings, attention_mask,
+                            LastQuery(query, key, num, is_causal, scale), residual=residual)
 
     # ---- the reference's public position handlers: main.py:142-178 ----------------------------------------------
     def _handler_tensors(self, position_embeddings):

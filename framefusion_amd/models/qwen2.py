@@ -4,8 +4,9 @@ Same protocol as the reference's ``framefusion/models/qwen2/modeling_qwen2.py``:
   * decoder layer: FrameFusion call A before attention at layer 0 (:45-46), call B after attention +
     residual at every layer (:67); the layer returns ``(hidden, position_embeddings, mask)`` (:85);
   * attention: importance of the last query captured only while
-    ``finish_merging and not finish_pruning`` (:166-178) - here straight from the un-repeated GQA
-    keys through the HIP kernel, as the head-averaged ``[1, 1, 1, S]`` tensor;
+    ``finish_merging and not finish_pruning`` (:166-178) - here as a ``LastQuery`` handle (q_last + the
+    un-repeated GQA keys, which stay in the KV cache): the prune call of the same layer computes the
+    head-averaged importance itself, in the same host call as its select and gather;
   * model loop: position embeddings as a mutable ``[cos, sin]`` list threaded back from every layer
     (:263-266, :304-305); per-layer KV lengths differ after a reduction, which DynamicCache allows.
 
@@ -39,7 +40,7 @@ def qwen2_attention_forward(self, hidden_states, position_embeddings, attention_
     ff = self.framefusion
     if q_len > 1 and ff.finish_merging and not ff.finish_pruning:            # modeling_qwen2.py:168
         importance = last_query_importance(query_states, key_states, num=1, is_causal=attention_mask is None,
-                                           scale=self.scaling, framefusion=ff)
+                                           scale=self.scaling, framefusion=ff, defer=True)
 
     attention_interface = ALL_ATTENTION_FUNCTIONS.get_interface(self.config._attn_implementation, eager_attention_forward)
     attn_output, _ = attention_interface(self, query_states, key_states, value_states, attention_mask,

@@ -41,7 +41,7 @@ def qwen2vl_attention_forward(self, hidden_states, attention_mask=None, position
     ff = self.framefusion
     if q_len > 1 and ff.finish_merging and not ff.finish_pruning:            # modeling_qwen2_vl.py:291
         importance = last_query_importance(query_states, key_states, num=NUM_IMPORTANCE_QUERIES,
-                                           is_causal=attention_mask is None, scale=self.scaling, framefusion=ff)
+                                           is_causal=attention_mask is None, scale=self.scaling, framefusion=ff, defer=True)
 
     attention_interface = ALL_ATTENTION_FUNCTIONS.get_interface(self.config._attn_implementation, eager_attention_forward)
     attn_output, _ = attention_interface(self, query_states, key_states, value_states, attention_mask,

@@ -27,30 +27,53 @@ def get_attr_by_name(obj: Any, name: str) -> Any:
     return node
 
 
+class LastQuery:
+    """What the attention hook knows about the last `num` queries, prepared for the kernels: q_last [H, num, dh] contiguous,
+    the keys read in place where their layout allows (`k`, element strides `sh` / `ss`), sizes, dtype code, scale.  Handed to
+    ``FrameFusion.forward(..., self_attn_weights=LastQuery)`` by ``last_query_importance(..., defer=True)``: the prune call then
+    computes the importance itself, in the same host call as its plan and gather (``ff_ctx_prune_from_qk``)."""
+    __slots__ = ("q_last", "k", "sh", "ss", "H", "H_kv", "num", "S", "dh", "code", "factor", "is_causal", "bias", "dtype", "device")
+
+    def __init__(self, query, key, num, is_causal, scale, bias=None):
+        _lib.require_gpu(query, "scaled_dot_product_attention")
+        if query.ndim != 4 or key.ndim != 4 or query.shape[0] != 1 or key.shape[0] != 1:
+            raise FrameFusionHipError("expected query [1, H, L, dh] and key [1, H_kv, S, dh]")
+        H, dh = query.shape[1], query.shape[3]
+        H_kv, S = key.shape[1], key.shape[2]
+        num = min(num, query.shape[2])
+        if H % H_kv:
+            raise FrameFusionHipError(f"{H} query heads are not a multiple of {H_kv} kv heads")
+        code = _lib.DTYPE_CODE.get(query.dtype)
+        if code is None or key.dtype != query.dtype:
+            raise FrameFusionHipError(f"unsupported dtypes {query.dtype} / {key.dtype}")
+        self.q_last = query[0, :, -num:, :].contiguous()
+        # the keys as they are: [H_kv, S, dh] contiguous, or the transposed view of a k_proj output ([S, H_kv, dh] in
+        # memory: what transformers' attention hands over before the cache concatenates anything) - any layout with
+        # contiguous rows and 16-byte aligned strides is read in place, a copy of K is the exception
+        k = key[0]
+        esz = k.element_size()
+        sh, ss, sd = k.stride()
+        if (sd != 1 or (sh * esz) & 15 or (ss * esz) & 15 or ss < dh or k.data_ptr() & 15
+                or ((S - 1) * ss + dh) * esz >= (1 << 32) or (H_kv > 1 and sh < dh)):
+            k = k.contiguous()
+            sh, ss = S * dh, dh
+        self.k, self.sh, self.ss = k, sh, ss
+        self.H, self.H_kv, self.num, self.S, self.dh, self.code = H, H_kv, num, S, dh, code
+        self.factor = float(1 / math.sqrt(dh) if scale is None else scale)
+        self.is_causal, self.bias = bool(is_causal), bias
+        self.dtype, self.device = query.dtype, query.device
+
+    # (what FrameFusion._prune asks of a weights tensor)
+    @property
+    def shape(self):
+        return (1, self.H, self.num, self.S)
+
+
 def _launch_last_query(query, key, num, is_causal, scale, want_weights, want_importance, plan=None, bias=None):
-    _lib.require_gpu(query, "scaled_dot_product_attention")
-    if query.ndim != 4 or key.ndim != 4 or query.shape[0] != 1 or key.shape[0] != 1:
-        raise FrameFusionHipError("expected query [1, H, L, dh] and key [1, H_kv, S, dh]")
+    lq = LastQuery(query, key, num, is_causal, scale, bias)
     lib = _lib.load()
-    H, dh = query.shape[1], query.shape[3]
-    H_kv, S = key.shape[1], key.shape[2]
-    num = min(num, query.shape[2])
-    if H % H_kv:
-        raise FrameFusionHipError(f"{H} query heads are not a multiple of {H_kv} kv heads")
-    code = _lib.DTYPE_CODE.get(query.dtype)
-    if code is None or key.dtype != query.dtype:
-        raise FrameFusionHipError(f"unsupported dtypes {query.dtype} / {key.dtype}")
-    q_last = query[0, :, -num:, :].contiguous()
-    # the keys as they are: [H_kv, S, dh] contiguous, or the transposed view of a k_proj output ([S, H_kv, dh] in
-    # memory: what transformers' attention hands over before the cache concatenates anything) - any layout with
-    # contiguous rows and 16-byte aligned strides is read in place, a copy of K is the exception
-    k = key[0]
-    esz = k.element_size()
-    sh, ss, sd = k.stride()
-    if (sd != 1 or (sh * esz) & 15 or (ss * esz) & 15 or ss < dh or k.data_ptr() & 15
-            or ((S - 1) * ss + dh) * esz >= (1 << 32) or (H_kv > 1 and sh < dh)):
-        k = k.contiguous()
-        sh, ss = S * dh, dh
+    q_last, k, sh, ss = lq.q_last, lq.k, lq.sh, lq.ss
+    H, H_kv, num, S, dh, code = lq.H, lq.H_kv, lq.num, lq.S, lq.dh, lq.code
     factor = 1 / math.sqrt(dh) if scale is None else scale
     dev = query.device
     weights = torch.empty(1, H, num, S, dtype=query.dtype, device=dev) if want_weights else None
@@ -102,12 +125,18 @@ def scaled_dot_product_attention(query, key, value, num=1, attn_mask=None, dropo
     return weights
 
 
-def last_query_importance(query, key, num=1, is_causal=True, scale=None, framefusion=None) -> torch.Tensor:
+def last_query_importance(query, key, num=1, is_causal=True, scale=None, framefusion=None, defer=False):
     """Fused form for the attention hook: the head/query mean of the weights
     above, shaped [1, 1, 1, S] so that FrameFusion.forward's own mean (main.py:70) is the identity.
     With `framefusion` (the instance whose prune call will consume the result) the importance kernel
     also accumulates the select tables of that call in the instance's workspace (ff_ctx_last_query_importance):
-    the prune call then goes straight to its plan.  `FrameFusion.prune_from_qk` does hook + prune in ONE host call."""
+    the prune call then goes straight to its plan.  `defer=True` returns a `LastQuery` handle instead of a tensor and launches
+    nothing: passed to ``FrameFusion.forward`` as ``self_attn_weights`` (what the adapters in models/ do) it makes hook +
+    prune ONE host call - `FrameFusion.prune_from_qk` is the same thing by name."""
+    if defer:
+        # nothing is launched here: the prune call that receives this handle enqueues importance + plan + gather in ONE
+        # crossing of the C ABI (K stays where it is - the layer's KV cache - until then)
+        return LastQuery(query, key, num, is_causal, scale)
     plan, token = None, None
     if framefusion is not None and query.is_cuda:
         plan, token = framefusion._expect_importance(key.shape[2], query.dtype, query.device)

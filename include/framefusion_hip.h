@@ -445,6 +445,14 @@ int ff_ctx_merge_begin(ff_ctx_t* ctx, const ff_merge_call_t* call);
 int ff_ctx_merge_finish(ff_ctx_t* ctx, const ff_merge_call_t* call, ff_merge_result_t* result);
 int ff_ctx_merge(ff_ctx_t* ctx, const ff_merge_call_t* call, ff_merge_result_t* result);
 
+/* Two samples in flight from ONE host thread (ABI v9; the reference's way to use one GPU for two samples is two replicas on two
+ * threads, script/demo/llava_video_compare.py:217-223): `a` on `ctx_a`, `b` on `ctx_b`, two DIFFERENT contexts and two DIFFERENT
+ * streams.  Enqueues K1(a), K1(b), plan + K4 (a), plan + K4 (b), then waits for a's and b's result blocks - one sample's plan
+ * bubble and kernel ramps run under the other's streaming pass.  Output fields of both calls must be set on entry.  Results are
+ * what two independent ff_ctx_merge calls give, bit for bit.  Returns the first failure (both results valid on FF_OK). */
+int ff_ctx_merge_pair(ff_ctx_t* ctx_a, const ff_merge_call_t* a, ff_merge_result_t* result_a,
+                      ff_ctx_t* ctx_b, const ff_merge_call_t* b, ff_merge_result_t* result_b);
+
 /* The attention mask of the merge call that just finished on this context, gathered with its keep set (main.py:137-138):
  * out[r, c] = mask[src[r], src[c]] for the l_out kept positions, row stride L_cap (>= l_out) elements.  FF_ERR_STATE unless
  * a merge call over exactly L tokens finished last on this context, folded something (l_out < L) and nothing was begun since.  For a host that
@@ -484,6 +492,24 @@ int ff_ctx_last_query_importance(ff_ctx_t* ctx, const void* q_last, const void* 
                                  const void* bias, void* importance, int64_t start, int64_t n_img, int64_t k_keep,
                                  void* ws, size_t ws_bytes, ff_stream_t stream);
 
+/* Hook + prune in ONE host call (ABI v9): what the two calls above do back to back - importance of the last `num` queries
+ * into the context's `sim` scratch, its select tables, the prune's plan, the gather - for a host that still holds q_last and K
+ * when the prune is due (K sits in the layer's KV cache; modeling_qwen2.py:166-178 computes the weights inside attention and
+ * main.py:61-101 consumes them after the residual add: nothing in between touches either).  Three launches (four for head
+ * sizes off the tiled path), no read-back.  `call`: as ff_ctx_prune; its attn_w / w_dtype / H / num / tables_ready are ignored
+ * (the importance has the dtype of q / K).  All members 8 bytes wide. */
+typedef struct ff_lq_args {
+    const void* q_last;          /* [H, num, dh] contiguous                                              */
+    const void* k;               /* keys, as ff_last_query_attention                                     */
+    int64_t dtype, H, H_kv, num, dh, k_head_stride, k_key_stride;
+    double scale;
+    int64_t causal;
+    const void* bias;            /* optional [num, S]                                                    */
+    void* ws;                    /* ff_last_query_workspace_bytes(dtype, H, num, S, dh) bytes            */
+    size_t ws_bytes;
+} ff_lq_args_t;
+int ff_ctx_prune_from_qk(ff_ctx_t* ctx, const ff_prune_call_t* call, const ff_lq_args_t* lq);
+
 /* The caller replaced patch_type / starts a new sample: forget the order (and reset the workspace
  * if a call died half-way).  Enqueues at most two memsets on `stream`. */
 int ff_ctx_reset(ff_ctx_t* ctx, ff_stream_t stream);
@@ -494,7 +520,7 @@ int ff_ctx_reset(ff_ctx_t* ctx, ff_stream_t stream);
 void ff_ctx_expect_tables(ff_ctx_t* ctx);
 
 /* sizeof() of the structures above as THIS library was compiled (0: ff_ctx_t, 1: ff_merge_call_t,
- * 2: ff_merge_result_t, 3: ff_prune_call_t, 4: ff_aux_t), so a binding can verify its own layout. */
+ * 2: ff_merge_result_t, 3: ff_prune_call_t, 4: ff_aux_t, 5: ff_lq_args_t), so a binding can verify its own layout. */
 size_t ff_abi_sizeof(int which);
 
 #ifdef __cplusplus

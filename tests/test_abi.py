@@ -101,12 +101,12 @@ def test_context_structures_match_the_header():
     sizes, every member is 8 bytes wide and in the header's order, and the packed-struct formats the host fills
     them with land on the right offsets."""
     lib = _lib.load()
-    for which, cls in enumerate((_lib.FFCtx, _lib.FFMergeCall, _lib.FFMergeResult, _lib.FFPruneCall, _lib.FFAux)):
+    for which, cls in enumerate((_lib.FFCtx, _lib.FFMergeCall, _lib.FFMergeResult, _lib.FFPruneCall, _lib.FFAux, _lib.FFLqArgs)):
         assert lib.ff_abi_sizeof(which) == C.sizeof(cls), cls.__name__
     assert lib.ff_abi_sizeof(99) == 0
     text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
     for cname, cls in (("ff_ctx", _lib.FFCtx), ("ff_merge_call", _lib.FFMergeCall), ("ff_merge_result", _lib.FFMergeResult),
-                       ("ff_prune_call", _lib.FFPruneCall)):
+                       ("ff_prune_call", _lib.FFPruneCall), ("ff_lq_args", _lib.FFLqArgs)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s_t;" % (cname, cname), text, flags=re.S).group(1)
         names = []
         for decl in body.split(";"):
@@ -127,6 +127,7 @@ def test_context_structures_match_the_header():
     assert _lib.PRUNE_CALL_MASK_OFFSET == _lib.FFPruneCall.mask.offset
     assert _lib.MERGE_RESULT.size == C.sizeof(_lib.FFMergeResult)
     assert _lib.AUX_ENTRY.size == C.sizeof(_lib.FFAux) == 40
+    assert _lib.LQ_ARGS.size == C.sizeof(_lib.FFLqArgs) == 112
 
 
 def test_context_calls_validate_before_any_hip_call():
@@ -154,6 +155,13 @@ def test_context_calls_validate_before_any_hip_call():
     pc.S = 4096
     assert lib.ff_ctx_prune(a(ctx), a(pc)) == -1
     assert lib.ff_ctx_prune(a(ctx), None) == -1
+    lq = _lib.FFLqArgs()
+    assert lib.ff_ctx_prune_from_qk(a(ctx), a(pc), None) == -1 and lib.ff_ctx_prune_from_qk(a(ctx), None, a(lq)) == -1
+    assert lib.ff_ctx_prune_from_qk(a(ctx), a(pc), a(lq)) == -1            # S beyond the scratch
+    pc.S, pc.start, pc.n_img, pc.k = 512, 4, 600, 5
+    assert lib.ff_ctx_prune_from_qk(a(ctx), a(pc), a(lq)) == -1            # start + n_img > S
+    pc.n_img, lq.dtype = 100, 7
+    assert lib.ff_ctx_prune_from_qk(a(ctx), a(pc), a(lq)) == -1            # unknown dtype: before any HIP call
     assert lib.ff_ctx_reset(None, None) == -1
     assert len(lib.ff_error_string(_lib.ERR_DEVICE)) > 4 and len(lib.ff_error_string(_lib.ERR_STATE)) > 4
 

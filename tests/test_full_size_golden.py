@@ -261,6 +261,19 @@ def test_hip_matches_reference_full_size_prune(name):
     assert torch.equal(pg3, pg) and torch.equal(hg3, hg)
     # ... and the workspace is clean again: a merge call on the same instance behaves
     assert not f3._scratch[("cuda", 0)].dirty
+    # hook + prune as ONE host call (prune_from_qk / the deferred handle the adapters pass): same kept set, same rows
+    f4 = ffa.FrameFusion(0.3, 0.6, 0.1)
+    f4.prepare(torch.zeros(1, S, dtype=torch.long, device=DEV), 1, start, start + n_img, img_len, orig_len,
+               finish_merging=True, sparsity_list=list(g[f"{name}/sparsity"]))
+    hg4, pg4, _ = f4.prune_from_qk(hd, torch.arange(S, device=DEV)[None], None, qd, kd, num=num, is_causal=True)
+    assert f4.finish_pruning and torch.equal(pg4, pg) and torch.equal(hg4, hg) and not f4._scratch[("cuda", 0)].dirty
+    f4.prepare(torch.zeros(1, S, dtype=torch.long, device=DEV), 1, start, start + n_img, img_len, orig_len,
+               finish_merging=True, sparsity_list=list(g[f"{name}/sparsity"]))
+    handle = ffa.last_query_importance(qd, kd, num=num, is_causal=True, framefusion=f4, defer=True)
+    hg5, pg5, _ = f4(hd, torch.arange(S, device=DEV)[None], None, handle)
+    assert torch.equal(pg5, pg) and torch.equal(hg5, hg)
+    with pytest.raises(ffa.FrameFusionHipError):
+        f4.prune_from_qk(hd, torch.arange(S, device=DEV)[None], None, qd, kd, num=num)       # no prune is due any more
     # the unfused form (weights [1, H, num, S] -> head mean inside the prune call) keeps the same tokens
     f2 = ffa.FrameFusion(0.3, 0.6, 0.1)
     f2.prepare(torch.zeros(1, S, dtype=torch.long, device=DEV), 1, start, start + n_img, img_len, orig_len,

@@ -103,6 +103,18 @@ def test_eight_ranks_sharing_one_gpu_over_gloo():
 
 
 @pytest.mark.timeout(900)
+def test_two_samples_per_gpu_go_through_the_pair():
+    """`--samples 2` on one GPU: the rank owns two samples per step and keeps both in flight (FrameFusionPair); the line says so
+    and its value counts both."""
+    out = run_bench("--samples", "2", "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-extra")
+    cfg = out["config"]
+    assert cfg["samples_per_gpu_per_step"] == 2 and cfg["samples_per_step"] == 2 and "FrameFusionPair" in cfg["workload"]
+    one = cfg["tokens_in"] - cfg["tokens_out"]
+    assert out["value"] == pytest.approx(2 * one / (out["ms_per_step"] * 1e-3), rel=1e-6)
+    assert out["value"] > 1.5e8                               # (one sample per step runs at ~1.9e8 on an MI355X)
+
+
+@pytest.mark.timeout(900)
 def test_an_n_gpu_line_cannot_be_n_ranks_on_one_device():
     """`--gpus 2` without --oversubscribe must be two devices over RCCL: on a 1-GPU box every rank refuses before anything
     runs (and, should ranks ever land on one device anyway, the all_gathered identities refuse the line: exit 3)."""

@@ -1034,3 +1034,55 @@ def test_hook_importance_feeds_the_prune_with_tables(dtype, H, Hk, num, S, d):
         f4.sparsity_list = [0.4, 0.3]
         out5, pos5, _ = f4(h, torch.arange(S, device=DEV)[None], None, imp_c.clone())
         assert torch.equal(pos4, pos5) and same_bits(out4.cpu(), out5.cpu()) and pos4.shape != pos1.shape
+
+
+@pytest.mark.parametrize("dtype,H,Hk,num,S,d,dh,container,with_res,with_mask", [
+    (torch.bfloat16, 8, 2, 1, 3000, 128, 128, "qwen2", False, False),
+    (torch.float16, 12, 4, 4, 5555, 64, 64, "mrope", True, False),
+    (torch.float32, 4, 4, 2, 900, 96, 32, "ids", False, True),
+    (torch.bfloat16, 6, 3, 4, 1300, 256, 24, "qwen2", True, True),          # odd head size: the general importance path
+])
+def test_prune_from_qk_equals_hook_then_prune(dtype, H, Hk, num, S, d, dh, container, with_res, with_mask):
+    """One host call (ff_ctx_prune_from_qk: importance -> plan -> gather) against the two-call form
+    (last_query_importance(..., framefusion=ff) then forward): same kept set, same rows, same gathered containers, a clean
+    workspace afterwards - for every dtype, both importance paths, every position container, with the residual add and an
+    attention mask."""
+    g = torch.Generator().manual_seed(S + dh)
+    q = harness.snap(torch.randn(1, H, num + 3, dh, generator=g), dtype).to(DEV)
+    k = harness.snap(torch.randn(1, Hk, S, dh, generator=g), dtype).to(DEV)
+    h = torch.randn(1, S, d, generator=g).to(dtype).to(DEV)
+    res = torch.randn(1, S, d, generator=g).to(dtype).to(DEV) if with_res else None
+    mask = torch.randn(1, 1, S, S, generator=g).to(dtype).to(DEV) if with_mask else None
+    start, n_img = 7, S - 19
+
+    def pos():
+        if container == "ids":
+            return torch.arange(S, device=DEV)[None]
+        return [t.to(DEV) for t in rotary_tables(S, 16, dtype, mrope=(container == "mrope"))]
+
+    def fresh():
+        f = ffa.FrameFusion(0.3, 0.6, 0.1)
+        f.prepare(torch.zeros(1, S, dtype=torch.long, device=DEV), 1, start, start + n_img, n_img, S,
+                  finish_merging=True, finish_pruning=False, sparsity_list=[0.4, 0.2])
+        return f
+    f1 = fresh()
+    imp = ffa.last_query_importance(q, k, num=num, is_causal=True, framefusion=f1)
+    o1, p1, m1 = f1(h, pos(), mask, imp, residual=res)
+    f2 = fresh()
+    o2, p2, m2 = f2.prune_from_qk(h, pos(), mask, q, k, num=num, is_causal=True, residual=res)
+    assert f2.finish_pruning and not f2._scratch[("cuda", 0)].dirty
+    assert o1.shape == o2.shape and same_bits(o1.cpu(), o2.cpu())
+    if container == "ids":
+        assert torch.equal(p1, p2)
+    else:
+        assert all(same_bits(a.cpu(), b.cpu()) for a, b in zip(p1, p2))
+    assert (m1 is None) == (m2 is None) and (m1 is None or same_bits(m1.cpu(), m2.cpu()))
+    # the instance is reusable: a second prefill through the same scratch (grow-only importance workspace) gives the same bits
+    f2.prepare(torch.zeros(1, S, dtype=torch.long, device=DEV), 1, start, start + n_img, n_img, S,
+               finish_merging=True, finish_pruning=False, sparsity_list=[0.4, 0.2])
+    o3, _, _ = f2(h, pos(), mask, ffa.last_query_importance(q, k, num=num, is_causal=True, framefusion=f2, defer=True), residual=res)
+    assert same_bits(o3.cpu(), o2.cpu())
+    # a handle for another length is refused before anything is enqueued
+    f3 = fresh()
+    with pytest.raises(ffa.FrameFusionHipError):
+        f3(h[:, :-1], pos(), None, ffa.last_query_importance(q, k, num=num, is_causal=True, defer=True))
