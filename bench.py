@@ -173,6 +173,7 @@ def main():
         # this rank owns several samples per step (C4 with more samples than GPUs): two in flight at a time, one host thread
         timed_step, reduced_of = multi_sample_step(ffa, dev, mine, args, F, P, d, L, cos, sin, hidden, hidden_alt, ptype, ff)
         timed_step()
+        timed_step.drain()
     timed = dp.timed_steps(dist, timed_step, args.steps, args.warmup, dev)
     t_max, elapsed, out = timed
     reduced = reduced_of(out)
@@ -292,22 +293,34 @@ def multi_sample_step(ffa, dev, mine, args, F, P, d, L, cos, sin, hidden0, hidde
         h, pt = video_tokens(F, P, d, p_change=args.p_change, sigma=SIGMA, seed=dp.sample_seed(args.seed, idx), dtype=torch.bfloat16,
                              device=str(dev))
         work.append(dict(h=h, h2=h.clone(), pt=pt, ff=ffa.FrameFusion(COST, THRESHOLD, RATIO_LB)))
-    pairs = [ffa.FrameFusionPair(work[j]["ff"], work[j + 1]["ff"], dev, sync_with_current=False) for j in range(0, len(work) - 1, 2)]
-    flip = [0]
+    # consecutive samples alternate between the two streams of a pair; a sample's call is collected only after the NEXT
+    # sample's call has been submitted - across step boundaries too, so the last call of a step is collected by the next step
+    # (`drain` collects the very last one: inside the timed region, before the closing synchronize)
+    pairs = []
+    for j in range(0, len(work), 2):
+        second = work[j + 1]["ff"] if j + 1 < len(work) else ffa.FrameFusion(COST, THRESHOLD, RATIO_LB)      # (odd one out: half a pair)
+        pairs.append(ffa.FrameFusionPair(work[j]["ff"], second, dev, sync_with_current=False))
+    flip, waiting, last = [0], [], [None] * len(work)
+
+    def collect_one():
+        j = waiting.pop(0)
+        last[j] = pairs[j // 2].collect(j & 1)[0]
 
     def step():
         flip[0] ^= 1
-        outs = []
-        for w in work:
+        for j, w in enumerate(work):
             w["ff"].prepare(w["pt"], P, 0, L, L, L)
-        for j, pair in enumerate(pairs):
-            a, b = work[2 * j], work[2 * j + 1]
-            oa, ob = pair((a["h2"] if flip[0] else a["h"], [cos, sin], None), (b["h2"] if flip[0] else b["h"], [cos, sin], None))
-            outs += [oa[0], ob[0]]
-        if len(work) & 1:
-            w = work[-1]
-            outs.append(w["ff"](w["h2"] if flip[0] else w["h"], [cos, sin], None)[0])
-        return outs
+            pairs[j // 2].submit(j & 1, w["h2"] if flip[0] else w["h"], [cos, sin], None)
+            waiting.append(j)
+            if len(waiting) > 1:
+                collect_one()
+        return last
+
+    def drain():
+        while waiting:
+            collect_one()
+        return last
+    step.drain = drain
     return step, (lambda outs: sum(L - o.shape[1] for o in outs))
 
 
@@ -497,26 +510,28 @@ def two_samples_per_gpu(ffa, dev, F, P, d, p_change, seed, steps, warmup):
         th.join()
     reduced = sum(w["L"] - w["out"].shape[1] for w in work)
     threads_res = {"us_per_pair_of_steps": dt / steps * 1e6, "tokens_reduced_per_s": reduced * steps / dt}
-    # the same two samples from ONE host thread: FrameFusionPair -> ff_ctx_merge_pair (both similarity passes, then both plan +
-    # merge pairs enqueued on two streams before either result block is waited for)
+    # the same two samples from ONE host thread: FrameFusionPair - sample 1's call is submitted (ff_ctx_merge_submit, its own
+    # stream) before sample 0's is collected and vice versa: always one call enqueued ahead of the one being waited for
     pair = ffa.FrameFusionPair(work[0]["ff"], work[1]["ff"], dev, sync_with_current=False)
 
-    def pair_step(i):
-        for w in work:
+    def calls(n):
+        for i in range(2 * n):
+            w = work[i & 1]
             w["ff"].prepare(w["pt"], P, 0, w["L"], w["L"], w["L"])
-        return pair(*[(w["h2"] if i & 1 else w["h"], [w["cos"], w["sin"]], None) for w in work])
-    for i in range(warmup):
-        pair_step(i)
+            yield (i & 1, w["h2"] if (i >> 1) & 1 else w["h"], [w["cos"], w["sin"]], None)
+    for _ in pair.run(calls(warmup)):
+        pass
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(steps):
-        outs = pair_step(i)
+    outs = [None, None]
+    for i, o in enumerate(pair.run(calls(steps))):
+        outs[i & 1] = o
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     reduced = sum(w["L"] - o[0].shape[1] for w, o in zip(work, outs))
     return {"samples_in_flight": 2, "steps_per_sample": steps,
             "one_host_thread_pair": {"us_per_pair_of_steps": dt / steps * 1e6, "tokens_reduced_per_s": reduced * steps / dt,
-                                     "how": "framefusion_amd.FrameFusionPair (ff_ctx_merge_pair), two HIP streams, no threads"},
+                                     "how": "framefusion_amd.FrameFusionPair (ff_ctx_merge_submit / _collect), two HIP streams, no threads"},
             "two_threads": threads_res,
             "us_per_pair_of_steps": dt / steps * 1e6, "tokens_reduced_per_s": reduced * steps / dt}
 
@@ -779,7 +794,18 @@ def e2e_prefill(dev, shape="7b", frames=64, pre=14, post=20, regimes=((P_CHANGE,
         hip_ff.similarity_lower_bound = thr
         eager = _EagerFrameFusion(orc.OracleFrameFusion(COST, thr, RATIO_LB))
         install(hip_ff)
-        hip_ms, hip_lengths = prefill(lambda: hip_ff.prepare(pt, patches, pre, pre + n_vis - 1, n_vis, L))
+        # both output forms (INTEGRATION.md "Output buffers"): exactly sized tensors like the reference's (compact_outputs, the
+        # default since round 5) and views of input-length buffers (the opt-in fast path) - prefill time and peak memory of each
+        modes = {}
+        for compact in (True, False):
+            hip_ff.compact_outputs = compact
+            torch.cuda.synchronize()
+            torch.cuda.reset_peak_memory_stats(dev)
+            base = torch.cuda.memory_allocated(dev)
+            ms, lens = prefill(lambda: hip_ff.prepare(pt, patches, pre, pre + n_vis - 1, n_vis, L))
+            modes[compact] = (ms, lens, (torch.cuda.max_memory_allocated(dev) - base) / 2 ** 30)
+        hip_ff.compact_outputs = type(hip_ff)().compact_outputs          # back to the class default for the legs below
+        hip_ms, hip_lengths, _ = modes[hip_ff.compact_outputs]
         # wall time of the FrameFusion.forward calls of this build (each bracketed by synchronise: launch-from-idle and drain
         # included - an upper bound of what they add to the prefill)
         calls = []
@@ -805,7 +831,11 @@ def e2e_prefill(dev, shape="7b", frames=64, pre=14, post=20, regimes=((P_CHANGE,
             eager.time_s = 0.0
             eager.prepare(pt, patches, pre, pre + n_vis - 1, n_vis, L)
         eager_ms, eager_lengths = prefill(prep_eager)
-        results.append({"p_change": p_change, "similarity_lower_bound": thr, "hip_prefill_ms": hip_ms, "eager_reference_prefill_ms": eager_ms,
+        results.append({"p_change": p_change, "similarity_lower_bound": thr, "hip_prefill_ms": hip_ms,
+                        "hip_prefill_ms_exact_outputs": modes[True][0], "hip_prefill_ms_view_outputs": modes[False][0],
+                        "prefill_peak_gib_above_weights_exact_outputs": modes[True][2],
+                        "prefill_peak_gib_above_weights_view_outputs": modes[False][2],
+                        "eager_reference_prefill_ms": eager_ms,
                         "prefill_speedup_vs_dense": dense_ms / hip_ms, "prefill_speedup_vs_eager_reference": eager_ms / hip_ms,
                         "framefusion_calls": hip_ff_calls, "hip_ms_inside_framefusion": hip_ff_ms,
                         "eager_ms_inside_framefusion": eager.time_s * 1e3,

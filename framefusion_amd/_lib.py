@@ -146,7 +146,8 @@ PROTOTYPES = {
     "ff_ctx_merge_begin": (_i32, [_vp, _vp]),
     "ff_ctx_merge_finish": (_i32, [_vp, _vp, _vp]),
     "ff_ctx_merge": (_i32, [_vp, _vp, _vp]),
-    "ff_ctx_merge_pair": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "ff_ctx_merge_submit": (_i32, [_vp, _vp]),
+    "ff_ctx_merge_collect": (_i32, [_vp, _vp, _vp]),
     "ff_ctx_prune": (_i32, [_vp, _vp]),
     "ff_ctx_prune_from_qk": (_i32, [_vp, _vp, _vp]),
     "ff_ctx_gather_mask": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp]),

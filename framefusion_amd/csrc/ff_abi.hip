@@ -404,32 +404,23 @@ extern "C" int ff_ctx_merge_finish(ff_ctx_t* c, const ff_merge_call_t* a, ff_mer
     return ctx_finish(c, a, r, false);
 }
 
-// Two samples in flight from ONE host thread: both similarity passes, then both plan + merge pairs are enqueued (each sample
-// on its own stream) before either result is waited for, so one sample's plan bubble and kernel ramps sit under the other's
-// streaming pass.  Returns the first failure; on FF_OK both results are valid.  When sample A fails after B was begun, B is
-// still finished (its scratch stays consistent) and A's code is returned.
-extern "C" int ff_ctx_merge_pair(ff_ctx_t* ca, const ff_merge_call_t* a, ff_merge_result_t* ra,
-                                 ff_ctx_t* cb, const ff_merge_call_t* b, ff_merge_result_t* rb) {
-    if (!ca || !cb || ca == cb || !a || !b || !ra || !rb) return FF_ERR_ARG;
-    if (a->stream == b->stream) return FF_ERR_ARG;          // (one stream would serialise the pair: use two calls then)
-    int rc = ff_ctx_merge_begin(ca, a);
+// A merge call in two halves that do NOT wait in between: submit = begin + plan + K4 enqueued (outputs allocated up front),
+// collect = the wait for the result block + the context's bookkeeping.  A host thread that submits sample B (on another
+// stream) before it collects sample A keeps two samples in flight: A's plan bubble and kernel ramps sit under B's streaming
+// pass (what two replicas on two threads achieve in the reference's demo, llava_video_compare.py:217-223).
+extern "C" int ff_ctx_merge_submit(ff_ctx_t* c, const ff_merge_call_t* a) {
+    int rc = ff_ctx_merge_begin(c, a);
     if (rc) return rc;
-    rc = ctx_finish_check(ca, a, ra);
-    if (rc) { ca->in_flight = 0; ca->dirty = 1; ca->order_len = 0; return rc; }
-    rc = ff_ctx_merge_begin(cb, b);
-    if (!rc) rc = ctx_finish_check(cb, b, rb);
-    if (rc) {                                               // B never started: A goes on alone, B's failure is reported
-        if (cb) { cb->in_flight = 0; cb->dirty = 1; cb->order_len = 0; }
-        const int rca = ctx_finish(ca, a, ra, false);
-        return rca ? rca : rc;
-    }
-    int ea = ctx_finish_enqueue(ca, a);
-    if (ea) { ca->in_flight = 0; ca->dirty = 1; ca->order_len = 0; }
-    int eb = ctx_finish_enqueue(cb, b);
-    if (eb) { cb->in_flight = 0; cb->dirty = 1; cb->order_len = 0; }
-    const int rca = ea ? ea : ctx_finish(ca, a, ra, true);
-    const int rcb = eb ? eb : ctx_finish(cb, b, rb, true);
-    return rca ? rca : rcb;
+    if (a->mask && !a->mask_out) rc = FF_ERR_ARG;
+    if (!rc) rc = ctx_finish_enqueue(c, a);
+    if (rc) { c->in_flight = 0; c->dirty = 1; c->order_len = 0; }
+    return rc;
+}
+
+extern "C" int ff_ctx_merge_collect(ff_ctx_t* c, const ff_merge_call_t* a, ff_merge_result_t* r) {
+    int rc = ctx_finish_check(c, a, r);
+    if (rc) return rc;
+    return ctx_finish(c, a, r, true);
 }
 
 extern "C" int ff_ctx_merge(ff_ctx_t* c, const ff_merge_call_t* a, ff_merge_result_t* r) {

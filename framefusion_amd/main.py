@@ -40,6 +40,7 @@ def _round_to(value: float, dtype: torch.dtype) -> float:
     return float(torch.tensor(value, dtype=dtype))
 
 
+_ONE_CROSSING_BYTES = 64 << 20      # merge calls over less than this go out as one ff_ctx_merge (see FrameFusion._merge)
 _get_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
 _PACK_PTR = struct.Struct("=Q")
 _PACK_I64 = struct.Struct("=q")
@@ -243,6 +244,7 @@ class FrameFusion(nn.Module):
         state["_scratch"] = {}
         state["_host_ints"] = {}
         state["last_call"] = None
+        state["_ticket"] = None
         return state
 
     def __deepcopy__(self, memo):
@@ -419,6 +421,12 @@ class FrameFusion(nn.Module):
         lib = _lib.load()
         st = self._merge_prepare(hidden_states, position_embeddings, attention_mask, residual)
         sc = st["sc"]
+        if st["L"] * st["d"] * hidden_states.element_size() <= _ONE_CROSSING_BYTES:
+            # a short similarity pass (< ~20 us) would be over before the outputs below exist: the host, not the kernel, would
+            # set the pace (9.7 us of idle GPU between K1 and the plan in the second call of the Qwen2-VL cascade,
+            # profiles/r04_timeline_c3.txt).  Outputs first, then ONE crossing that enqueues all three launches back to back.
+            self._merge_outputs(st)
+            return self._merge_complete(st, lib.ff_ctx_merge(sc.ctx_ptr, sc.call_ptr, sc.res_ptr))
         rc = lib.ff_ctx_merge_begin(sc.ctx_ptr, sc.call_ptr)
         if rc:
             _fail(rc, "merge")
@@ -428,6 +436,41 @@ class FrameFusion(nn.Module):
         # second streaming pass is still in flight and returns without waiting for it.
         rc = lib.ff_ctx_merge_finish(sc.ctx_ptr, sc.call_ptr, sc.res_ptr)
         return self._merge_complete(st, rc)
+
+    # ---- the same call in two halves (FrameFusionPair): everything enqueued by submit, the wait in collect ------------------------
+    def submit(self, hidden_states, position_embeddings, attention_mask, self_attn_weights=None, residual=None):
+        """``forward`` without its wait: a merge call is enqueued in full (similarity, plan, merge: one crossing of the C ABI,
+        ``ff_ctx_merge_submit``) on PyTorch's current stream and a ticket comes back at once; ``collect(ticket)`` waits for the
+        result block and returns what ``forward`` would have.  Any other call (prune, nothing to do) runs at once and the ticket
+        carries its result.  Between submit and collect the instance must not be touched (no prepare(), no other call)."""
+        dev = hidden_states.device
+        if dev.type == "cuda" and dev.index != _get_device():
+            with torch.cuda.device(dev):
+                return self.submit(hidden_states, position_embeddings, attention_mask, self_attn_weights, residual)
+        if self.__dict__.get("_ticket") is not None:
+            raise FrameFusionHipError("submit(): the previous call of this instance has not been collected")
+        q_len = hidden_states.shape[1]
+        if not (q_len > 1 and not self.finish_merging):
+            return {"done": self.forward(hidden_states, position_embeddings, attention_mask, self_attn_weights, residual)}
+        st = self._merge_prepare(hidden_states, position_embeddings, attention_mask, residual)
+        self._merge_outputs(st)
+        sc = st["sc"]
+        rc = _lib.load().ff_ctx_merge_submit(sc.ctx_ptr, sc.call_ptr)
+        if rc:
+            _fail(rc, "merge")
+        self._ticket = st
+        return st
+
+    def collect(self, ticket):
+        if "done" in ticket:
+            return ticket["done"]
+        if self.__dict__.get("_ticket") is not ticket:
+            raise FrameFusionHipError("collect(): not the ticket of this instance's call in flight")
+        self._ticket = None
+        sc = ticket["sc"]
+        with torch.cuda.device(ticket["device"]):
+            rc = _lib.load().ff_ctx_merge_collect(sc.ctx_ptr, sc.call_ptr, sc.res_ptr)
+            return self._merge_complete(ticket, rc)
 
     def _merge_prepare(self, hidden_states, position_embeddings, attention_mask, residual=None):
         """Validation + the input half of the call block (everything ff_ctx_merge_begin reads), on PyTorch's current stream."""

@@ -3,38 +3,57 @@
 The reference uses one GPU for two samples by running two model replicas on two Python threads, never sharing a
 ``FrameFusion`` instance (script/demo/llava_video_compare.py:217-223, 310-313).  A merge call of this build leaves the chip
 idle for the ~9 us of its plan kernel and for the ramp / drain of its two streaming passes; with a second, independent sample
-on a second HIP stream those bubbles sit under the other sample's streaming pass.  ``FrameFusionPair`` does that without
-threads: one crossing of the C ABI (``ff_ctx_merge_pair``) enqueues K1(a), K1(b), plan + K4 (a), plan + K4 (b) - each sample
-on its own stream - and only then waits for the two result blocks.  Results are those of two independent instances, bit for
-bit (tests/test_gpu_pair.py); each instance keeps its own scratch, state machine and by-patch order.
+on a second HIP stream, half a call out of phase, those bubbles sit under the other sample's streaming pass.
+
+``FrameFusionPair`` does that without threads, on top of ``FrameFusion.submit`` / ``collect`` (``ff_ctx_merge_submit`` /
+``ff_ctx_merge_collect``: a merge call enqueued in full, the wait for its result block split off): the host submits sample B
+on stream 1 BEFORE it collects sample A on stream 0, then submits the next A before it collects B, and so on - always one
+call enqueued ahead of the one being waited for.  Submitting both samples together and collecting both (lock step) was built
+first and measured SLOWER than two calls one after the other (332 vs 270 us per two calls at 64 x 576 x 4096: the two
+similarity passes compete and both plan bubbles coincide); what pays is the phase shift, which the alternation below
+creates and keeps.  Results are those of two independent instances, bit for bit (tests/test_gpu_pair.py); each instance
+keeps its own scratch, state machine and by-patch order.
 """
 from __future__ import annotations
 
 import torch
 
 from . import _lib
-from .main import FrameFusion, _fail
+from .main import FrameFusion
 
 
 class FrameFusionPair:
-    """``pair = FrameFusionPair(ff_a, ff_b)``; ``out_a, out_b = pair(args_a, args_b)`` with ``args_x`` the positional arguments
-    of ``FrameFusion.forward`` for that sample ``(hidden_states, position_embeddings, attention_mask[, self_attn_weights])``.
+    """``pair = FrameFusionPair(ff_a, ff_b)``.
 
-    When both calls are merge calls on the same device they go out as one ``ff_ctx_merge_pair``; anything else (a prune, a call
-    after the reductions have finished, a decode step, different devices) runs as two ordinary calls, each still on its own
-    stream.  ``sync_with_current`` (default): the pair's streams first wait for PyTorch's current stream (the inputs were
-    produced there) and the current stream then waits for both samples (the outputs are consumed there) - no host
-    synchronisation either way.  A caller that keeps each sample on its pair stream itself (``pair.streams``) passes False and
-    gets full pipelining across consecutive pairs as well."""
+    * ``pair.submit(x, hidden, position_embeddings, attention_mask[, self_attn_weights])`` enqueues the call of sample
+      ``x`` (0 or 1) on that sample's stream and returns at once; ``pair.collect(x)`` waits for it and returns what
+      ``FrameFusion.forward`` returns.  Keep the other sample submitted while you collect one.
+    * ``pair.run(calls)``: ``calls`` yields ``(x, hidden, position_embeddings, attention_mask[, self_attn_weights])`` with
+      x alternating 0, 1, 0, 1, ...; yields the results in the same order, one call late (the call behind a result is
+      already enqueued when the result is waited for).
+
+    The sample streams (``pair.streams``) first wait for PyTorch's current stream at every submit (the inputs were produced
+    there); ``collect`` makes the current stream wait for the sample's stream (the outputs are consumed there) - device-side
+    dependencies only, never a host synchronisation.  ``sync_with_current=False`` leaves both out for a caller that keeps each
+    sample's tensors on its pair stream itself."""
 
     def __init__(self, ff_a: FrameFusion, ff_b: FrameFusion, device=None, sync_with_current: bool = True):
         if ff_a is ff_b:
             raise _lib.FrameFusionHipError("FrameFusionPair needs two different FrameFusion instances (one per sample)")
-        self.a, self.b = ff_a, ff_b
+        self.ffs = (ff_a, ff_b)
         self.sync_with_current = sync_with_current
         self._streams = {}
+        self._pending = [None, None]          # (ticket, device) of each sample's call in flight
         if device is not None:
             self.streams_for(torch.device(device))
+
+    @property
+    def a(self):
+        return self.ffs[0]
+
+    @property
+    def b(self):
+        return self.ffs[1]
 
     def streams_for(self, device):
         key = (device.type, device.index)
@@ -45,83 +64,50 @@ class FrameFusionPair:
 
     @property
     def streams(self):
-        """(stream of sample a, stream of sample b) on the current device."""
+        """(stream of sample 0, stream of sample 1) on the current device."""
         return self.streams_for(torch.device("cuda", torch.cuda.current_device()))
 
-    @staticmethod
-    def _is_merge(ff, args):
-        h = args[0]
-        return h.is_cuda and h.shape[1] > 1 and not ff.finish_merging
-
-    def __call__(self, args_a, args_b):
-        return self.forward(args_a, args_b)
-
-    def forward(self, args_a, args_b):
-        ha, hb = args_a[0], args_b[0]
-        _lib.require_gpu(ha, "FrameFusionPair.forward")
-        _lib.require_gpu(hb, "FrameFusionPair.forward")
-        dev = ha.device
-        if hb.device != dev:
-            return self.a(*args_a), self.b(*args_b)
+    def submit(self, x, hidden_states, position_embeddings, attention_mask, self_attn_weights=None, residual=None):
+        _lib.require_gpu(hidden_states, "FrameFusionPair.submit")
+        if self._pending[x] is not None:
+            raise _lib.FrameFusionHipError(f"sample {x} already has a call in flight: collect({x}) first")
+        dev = hidden_states.device
         with torch.cuda.device(dev):
-            sa, sb = self.streams_for(dev)
-            cur = torch.cuda.current_stream(dev)
+            s = self.streams_for(dev)[x]
             if self.sync_with_current:
-                sa.wait_stream(cur)
-                sb.wait_stream(cur)
-            both_merge = self._is_merge(self.a, args_a) and self._is_merge(self.b, args_b)
-            if not both_merge:
-                with torch.cuda.stream(sa):
-                    out_a = self.a(*args_a)
-                with torch.cuda.stream(sb):
-                    out_b = self.b(*args_b)
-            else:
-                out_a, out_b = self._merge_pair(args_a, args_b, sa, sb)
-            if self.sync_with_current:
-                cur.wait_stream(sa)
-                cur.wait_stream(sb)
-                for out in (out_a, out_b):          # allocated on a pair stream, consumed on the caller's
-                    for t in (out[0], out[2], *(out[1] if type(out[1]) == list else [out[1]])):
-                        if isinstance(t, torch.Tensor):
-                            t.record_stream(cur)
-            return out_a, out_b
+                s.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(s):
+                ticket = self.ffs[x].submit(hidden_states, position_embeddings, attention_mask, self_attn_weights, residual)
+        self._pending[x] = (ticket, dev)
 
-    def _merge_pair(self, args_a, args_b, sa, sb):
-        lib = _lib.load()
-        a, b = self.a, self.b
-        with torch.cuda.stream(sa):
-            st_a = a._merge_prepare(*args_a[:3], residual=None)
-            a._merge_outputs(st_a)
-        try:
-            with torch.cuda.stream(sb):
-                st_b = b._merge_prepare(*args_b[:3], residual=None)
-                b._merge_outputs(st_b)
-        except Exception:
-            # sample b never started: a goes alone
-            with torch.cuda.stream(sa):
-                sc = st_a["sc"]
-                rc = lib.ff_ctx_merge(sc.ctx_ptr, sc.call_ptr, sc.res_ptr)
-                a._merge_complete(st_a, rc)
-            raise
-        ca, cb = st_a["sc"], st_b["sc"]
-        if ca is cb or st_a["stream"] == st_b["stream"]:
-            raise _lib.FrameFusionHipError("the two samples of a pair need their own scratch and their own stream")
-        rc = lib.ff_ctx_merge_pair(ca.ctx_ptr, ca.call_ptr, ca.res_ptr, cb.ctx_ptr, cb.call_ptr, cb.res_ptr)
-        # each sample's own verdict: the error word of ITS result block, else the pair's return code where the block says nothing
-        err_a = int(ca.res.error)
-        first = None
-        outs = []
-        for ff, st, stream in ((a, st_a, sa), (b, st_b, sb)):
-            sc = st["sc"]
-            with torch.cuda.stream(stream):
-                try:
-                    bad = rc if (rc and (int(sc.res.error) or int(sc.ctx.dirty))) else 0
-                    outs.append(ff._merge_complete(st, bad))
-                except Exception as e:                  # noqa: BLE001 (finish the other sample's bookkeeping first)
-                    first = first or e
-                    outs.append(None)
-        if first is not None:
-            raise first
-        if rc:
-            _fail(rc, "merge pair", err_a)
-        return outs[0], outs[1]
+    def collect(self, x):
+        if self._pending[x] is None:
+            raise _lib.FrameFusionHipError(f"sample {x} has no call in flight")
+        ticket, dev = self._pending[x]
+        self._pending[x] = None
+        with torch.cuda.device(dev):
+            s = self.streams_for(dev)[x]
+            with torch.cuda.stream(s):
+                out = self.ffs[x].collect(ticket)
+            if self.sync_with_current:
+                cur = torch.cuda.current_stream(dev)
+                cur.wait_stream(s)
+                for t in (out[0], out[2], *(out[1] if type(out[1]) == list else [out[1]])):      # allocated on the sample's stream
+                    if isinstance(t, torch.Tensor):
+                        t.record_stream(cur)
+        return out
+
+    def run(self, calls):
+        """Generator: results of `calls` in order, each collected after the NEXT call has been submitted."""
+        waiting = None
+        for call in calls:
+            x = call[0]
+            if waiting is not None and waiting == x:
+                yield self.collect(waiting)           # (two calls of the same sample in a row: nothing to overlap with)
+                waiting = None
+            self.submit(x, *call[1:])
+            if waiting is not None:
+                yield self.collect(waiting)
+            waiting = x
+        if waiting is not None:
+            yield self.collect(waiting)

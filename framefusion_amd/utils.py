@@ -68,6 +68,12 @@ class LastQuery:
     def shape(self):
         return (1, self.H, self.num, self.S)
 
+    def weights(self) -> torch.Tensor:
+        """The [1, H, num, S] attention weights the handle stands for (utils.py:27-57), materialised - for code that wants to
+        look at them (tests, the oracle): the prune itself never needs the tensor."""
+        w, _ = _launch_last_query(self.q_last[None], self.k[None], self.num, self.is_causal, self.factor, True, False, bias=self.bias)
+        return w
+
 
 def _launch_last_query(query, key, num, is_causal, scale, want_weights, want_importance, plan=None, bias=None):
     lq = LastQuery(query, key, num, is_causal, scale, bias)

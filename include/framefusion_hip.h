@@ -445,13 +445,14 @@ int ff_ctx_merge_begin(ff_ctx_t* ctx, const ff_merge_call_t* call);
 int ff_ctx_merge_finish(ff_ctx_t* ctx, const ff_merge_call_t* call, ff_merge_result_t* result);
 int ff_ctx_merge(ff_ctx_t* ctx, const ff_merge_call_t* call, ff_merge_result_t* result);
 
-/* Two samples in flight from ONE host thread (ABI v9; the reference's way to use one GPU for two samples is two replicas on two
- * threads, script/demo/llava_video_compare.py:217-223): `a` on `ctx_a`, `b` on `ctx_b`, two DIFFERENT contexts and two DIFFERENT
- * streams.  Enqueues K1(a), K1(b), plan + K4 (a), plan + K4 (b), then waits for a's and b's result blocks - one sample's plan
- * bubble and kernel ramps run under the other's streaming pass.  Output fields of both calls must be set on entry.  Results are
- * what two independent ff_ctx_merge calls give, bit for bit.  Returns the first failure (both results valid on FF_OK). */
-int ff_ctx_merge_pair(ff_ctx_t* ctx_a, const ff_merge_call_t* a, ff_merge_result_t* result_a,
-                      ff_ctx_t* ctx_b, const ff_merge_call_t* b, ff_merge_result_t* result_b);
+/* ff_ctx_merge without the wait in the middle (ABI v9): submit = begin + plan + K4, all enqueued (every output field of `call`
+ * set on entry); collect = the wait for the result block and the context's bookkeeping (order swap, layout retry, mask gather) -
+ * same `call`.  Nothing else may use the context in between.  For a host thread that keeps TWO samples in flight (two contexts,
+ * two streams): submit(B) before collect(A), so that A's plan bubble and kernel ramps run under B's streaming pass - the
+ * reference's way to load one GPU with two samples is two replicas on two threads (script/demo/llava_video_compare.py:217-223).
+ * Results are those of ff_ctx_merge, bit for bit. */
+int ff_ctx_merge_submit(ff_ctx_t* ctx, const ff_merge_call_t* call);
+int ff_ctx_merge_collect(ff_ctx_t* ctx, const ff_merge_call_t* call, ff_merge_result_t* result);
 
 /* The attention mask of the merge call that just finished on this context, gathered with its keep set (main.py:137-138):
  * out[r, c] = mask[src[r], src[c]] for the l_out kept positions, row stride L_cap (>= l_out) elements.  FF_ERR_STATE unless

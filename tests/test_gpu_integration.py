@@ -32,7 +32,9 @@ class Shadow:
         o.prepare(ff.patch_type.cpu(), ff.patch_num, ff.image_token_start_index, ff.image_token_end_index,
                   ff.image_token_length, ff.original_length, ff.finish_merging, ff.finish_pruning, list(ff.sparsity_list))
         L = hidden.shape[1]
-        ho, po, _ = o.forward(hidden.cpu(), torch.arange(L)[None], None, None if attn_w is None else attn_w.cpu())
+        # (the adapters hand the prune a LastQuery handle - q_last + K - instead of weights: the oracle gets the weights it stands for)
+        w_ref = attn_w.weights() if isinstance(attn_w, ffa.utils.LastQuery) else attn_w
+        ho, po, _ = o.forward(hidden.cpu(), torch.arange(L)[None], None, None if w_ref is None else w_ref.cpu())
         was_active = (not ff.finish_merging) or (not ff.finish_pruning)
         out = self.inner(fused_in, pos, mask, attn_w, residual)
         if was_active and (ff.last_call is not None):

@@ -54,21 +54,28 @@ def run_independent(ff, s, layers):
 
 
 def run_paired(pair, sa, sb, layers):
+    """Both prefills interleaved through the pair: sample 1's call is submitted before sample 0's is collected and vice
+    versa - always one call enqueued ahead of the one being waited for."""
     logs = ([], [])
-    ga, gb = prefill(pair.a, sa, None, layers), prefill(pair.b, sb, None, layers)
-    args = [next(ga), next(gb)]
+    gens = (prefill(pair.a, sa, None, layers), prefill(pair.b, sb, None, layers))
+    args = [next(gens[0]), next(gens[1])]
+    alive = [True, True]
+    x = 0
     while True:
-        outs = pair(args[0], args[1])
-        done = 0
-        for x, (ff, g) in enumerate(((pair.a, ga), (pair.b, gb))):
-            logs[x].append((outs[x][0], outs[x][1], bool(ff.finish_merging), bool(ff.finish_pruning), list(ff.sparsity_list)))
+        if alive[x] and pair._pending[x] is None:
+            pair.submit(x, *args[x])
+        y = 1 - x
+        if pair._pending[y] is not None:
+            out = pair.collect(y)
+            ff = pair.ffs[y]
+            logs[y].append((out[0], out[1], bool(ff.finish_merging), bool(ff.finish_pruning), list(ff.sparsity_list)))
             try:
-                args[x] = g.send(outs[x])
+                args[y] = gens[y].send(out)
             except StopIteration:
-                done += 1
-        if done:
-            assert done == 2
+                alive[y] = False
+        if pair._pending[0] is None and pair._pending[1] is None and not (alive[0] or alive[1]):
             return logs
+        x = y
 
 
 def equal_logs(got, want):
@@ -115,13 +122,18 @@ def test_pair_at_the_headline_size_and_with_a_mask():
         o, pe, _ = f(s["h"], list(s["pos"]), None)
         want.append((o.clone(), [t.clone() for t in pe], f.patch_type.clone()))
     pair = FrameFusionPair(ffa.FrameFusion(0.3, 0.6, 0.1), ffa.FrameFusion(0.3, 0.6, 0.1))
-    for rep in range(3):
-        for f, s in zip((pair.a, pair.b), ss):
-            f.prepare(s["pt"], P, 0, s["L"], s["L"], s["L"])
-        outs = pair((ss[0]["h"], list(ss[0]["pos"]), None), (ss[1]["h"], list(ss[1]["pos"]), None))
-        for (o, pe, _), (wo, wpe, wpt), f in zip(outs, want, (pair.a, pair.b)):
-            assert torch.equal(o, wo) and all(torch.equal(x, y) for x, y in zip(pe, wpe)) and torch.equal(f.patch_type, wpt)
-            assert f.finish_merging and f.finish_pruning
+
+    def calls(n):
+        for i in range(n):
+            x = i & 1
+            pair.ffs[x].prepare(ss[x]["pt"], P, 0, ss[x]["L"], ss[x]["L"], ss[x]["L"])
+            yield (x, ss[x]["h"], list(ss[x]["pos"]), None)
+    for i, (o, pe, _) in enumerate(pair.run(calls(6))):
+        wo, wpe, wpt = want[i & 1]
+        f = pair.ffs[i & 1]
+        assert torch.equal(o, wo) and all(torch.equal(x, y) for x, y in zip(pe, wpe))
+        assert f.finish_merging and f.finish_pruning
+    assert torch.equal(pair.a.patch_type, want[0][2]) and torch.equal(pair.b.patch_type, want[1][2])
     assert want[0][0].shape == want[1][0].shape and not torch.equal(want[0][0], want[1][0])          # two different videos
     # masks: gathered behind each sample's call on its own stream
     sa = sample(6, 20, 64, 0.4, seed=5, pre=2, post=3, dtype=torch.bfloat16, container="qwen2")
@@ -136,29 +148,44 @@ def test_pair_at_the_headline_size_and_with_a_mask():
     pair = FrameFusionPair(ffa.FrameFusion(0.3, 0.6, 0.1), ffa.FrameFusion(0.3, 0.6, 0.1))
     for f, s in zip((pair.a, pair.b), (sa, sb)):
         f.prepare(s["pt"], s["P"], s["pre"], s["pre"] + s["n"], s["n"], s["L"])
-    outs = pair((sa["h"], list(sa["pos"]), masks[0]), (sb["h"], list(sb["pos"]), masks[1]))
+    pair.submit(0, sa["h"], list(sa["pos"]), masks[0])
+    pair.submit(1, sb["h"], list(sb["pos"]), masks[1])
+    outs = [pair.collect(0), pair.collect(1)]
     for (o, pe, m), (wo, wpe, wm) in zip(outs, want):
         assert same_bits(o.cpu(), wo.cpu()) and same_bits(m.cpu(), wm.cpu()) and m.shape[-1] == o.shape[1]
 
 
-def test_pair_refuses_one_instance_twice_and_reports_a_bad_sample():
+def test_pair_refuses_misuse_and_survives_a_bad_sample():
     f = ffa.FrameFusion(0.3, 0.6, 0.1)
     with pytest.raises(ffa.FrameFusionHipError):
         FrameFusionPair(f, f)
     sa = sample(6, 20, 64, 0.4, seed=5, pre=2, post=3, dtype=torch.bfloat16, container="qwen2")
     pair = FrameFusionPair(ffa.FrameFusion(0.3, 0.6, 0.1), ffa.FrameFusion(0.3, 0.6, 0.1))
-    for ff in (pair.a, pair.b):
+    for ff in pair.ffs:
         ff.prepare(sa["pt"], sa["P"], sa["pre"], sa["pre"] + sa["n"], sa["n"], sa["L"])
-    bad = sa["h"][:, :-1]                                  # patch_type does not cover this sequence
+    pair.submit(0, sa["h"], list(sa["pos"]), None)
     with pytest.raises(ffa.FrameFusionHipError):
-        pair((sa["h"], list(sa["pos"]), None), (bad, list(sa["pos"]), None))
-    torch.cuda.synchronize()
-    # sample a was completed on its own and both instances stay usable
-    assert pair.a.last_call["L_in"] == sa["L"]
+        pair.submit(0, sa["h"], list(sa["pos"]), None)                    # sample 0 already has a call in flight
+    with pytest.raises(ffa.FrameFusionHipError):
+        pair.a.submit(sa["h"], list(sa["pos"]), None)                     # ... and so has its instance
+    with pytest.raises(ffa.FrameFusionHipError):
+        pair.collect(1)                                                   # nothing in flight for sample 1
+    bad = sa["h"][:, :-1]                                                 # patch_type does not cover this sequence
+    with pytest.raises(ffa.FrameFusionHipError):
+        pair.submit(1, bad, list(sa["pos"]), None)
+    oa = pair.collect(0)                                                  # sample 0 is unaffected
     want = ffa.FrameFusion(0.3, 0.6, 0.1)
     want.prepare(sa["pt"], sa["P"], sa["pre"], sa["pre"] + sa["n"], sa["n"], sa["L"])
     wo = want(sa["h"], list(sa["pos"]), None)[0]
-    for ff in (pair.a, pair.b):
+    assert same_bits(oa[0].cpu(), wo.cpu())
+    # both instances stay usable; submit / collect on a plain instance (PyTorch's current stream) equals forward
+    for ff in pair.ffs:
         ff.prepare(sa["pt"], sa["P"], sa["pre"], sa["pre"] + sa["n"], sa["n"], sa["L"])
-    oa, ob = pair((sa["h"], list(sa["pos"]), None), (sa["h"], list(sa["pos"]), None))
-    assert same_bits(oa[0].cpu(), wo.cpu()) and same_bits(ob[0].cpu(), wo.cpu())
+    pair.submit(1, sa["h"], list(sa["pos"]), None)
+    pair.submit(0, sa["h"], list(sa["pos"]), None)
+    assert same_bits(pair.collect(1)[0].cpu(), wo.cpu()) and same_bits(pair.collect(0)[0].cpu(), wo.cpu())
+    solo = ffa.FrameFusion(0.3, 0.6, 0.1)
+    solo.prepare(sa["pt"], sa["P"], sa["pre"], sa["pre"] + sa["n"], sa["n"], sa["L"])
+    t = solo.submit(sa["h"], list(sa["pos"]), None)
+    assert same_bits(solo.collect(t)[0].cpu(), wo.cpu())
+    torch.cuda.synchronize()
