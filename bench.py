@@ -483,6 +483,29 @@ def two_samples_per_gpu(ffa, dev, F, P, d, p_change, seed, steps, warmup):
         cos, sin = rotary_tables(L, HEAD_DIM, torch.bfloat16, device=str(dev))
         work.append(dict(h=h, h2=h.clone(), pt=pt, cos=cos, sin=sin, L=L, ff=ffa.FrameFusion(COST, THRESHOLD, RATIO_LB),
                          stream=torch.cuda.Stream(device=dev), out=None))
+    # the same two samples from ONE host thread: FrameFusionPair - sample 1's call is submitted (ff_ctx_merge_submit, its own
+    # stream) before sample 0's is collected and vice versa: always one call enqueued ahead of the one being waited for
+    pair = ffa.FrameFusionPair(work[0]["ff"], work[1]["ff"], dev, sync_with_current=False)
+
+    def calls(n):
+        for i in range(2 * n):
+            w = work[i & 1]
+            w["ff"].prepare(w["pt"], P, 0, w["L"], w["L"], w["L"])
+            yield (i & 1, w["h2"] if (i >> 1) & 1 else w["h"], [w["cos"], w["sin"]], None)
+    for _ in pair.run(calls(warmup)):
+        pass
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outs = [None, None]
+    for i, o in enumerate(pair.run(calls(steps))):
+        outs[i & 1] = o
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    reduced = sum(w["L"] - o[0].shape[1] for w, o in zip(work, outs))
+    pair_res = {"us_per_pair_of_steps": dt / steps * 1e6, "tokens_reduced_per_s": reduced * steps / dt,
+                "how": "framefusion_amd.FrameFusionPair (ff_ctx_merge_submit / _collect), two HIP streams, no threads"}
+    for w in work:                      # the threads get fresh instances (their own streams)
+        w["ff"] = ffa.FrameFusion(COST, THRESHOLD, RATIO_LB)
     start, stop = threading.Barrier(3), threading.Barrier(3)
 
     def run(w):
@@ -510,30 +533,8 @@ def two_samples_per_gpu(ffa, dev, F, P, d, p_change, seed, steps, warmup):
         th.join()
     reduced = sum(w["L"] - w["out"].shape[1] for w in work)
     threads_res = {"us_per_pair_of_steps": dt / steps * 1e6, "tokens_reduced_per_s": reduced * steps / dt}
-    # the same two samples from ONE host thread: FrameFusionPair - sample 1's call is submitted (ff_ctx_merge_submit, its own
-    # stream) before sample 0's is collected and vice versa: always one call enqueued ahead of the one being waited for
-    pair = ffa.FrameFusionPair(work[0]["ff"], work[1]["ff"], dev, sync_with_current=False)
-
-    def calls(n):
-        for i in range(2 * n):
-            w = work[i & 1]
-            w["ff"].prepare(w["pt"], P, 0, w["L"], w["L"], w["L"])
-            yield (i & 1, w["h2"] if (i >> 1) & 1 else w["h"], [w["cos"], w["sin"]], None)
-    for _ in pair.run(calls(warmup)):
-        pass
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    outs = [None, None]
-    for i, o in enumerate(pair.run(calls(steps))):
-        outs[i & 1] = o
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    reduced = sum(w["L"] - o[0].shape[1] for w, o in zip(work, outs))
-    return {"samples_in_flight": 2, "steps_per_sample": steps,
-            "one_host_thread_pair": {"us_per_pair_of_steps": dt / steps * 1e6, "tokens_reduced_per_s": reduced * steps / dt,
-                                     "how": "framefusion_amd.FrameFusionPair (ff_ctx_merge_submit / _collect), two HIP streams, no threads"},
-            "two_threads": threads_res,
-            "us_per_pair_of_steps": dt / steps * 1e6, "tokens_reduced_per_s": reduced * steps / dt}
+    return {"samples_in_flight": 2, "steps_per_sample": steps, "one_host_thread_pair": pair_res, "two_threads": threads_res,
+            "us_per_pair_of_steps": pair_res["us_per_pair_of_steps"], "tokens_reduced_per_s": pair_res["tokens_reduced_per_s"]}
 
 
 def cascade(ffa, dev, F, P, d, p_change, thr, pre, post, heads, kv_heads, num, mrope, sigma_hi=1.6, reps=6, seed=1234,

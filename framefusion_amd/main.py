@@ -683,6 +683,28 @@ class FrameFusion(nn.Module):
         tables_ready = int(token is not None and token == sc.tables_token and
                            token == (id(sc), sc.seq, q_len, start, n_img, w_dtype, k) and H * num == 1)
         sc.tables_token = None
+        one_crossing = False
+        if lq is not None:
+            need = int(lib.ff_last_query_workspace_bytes(lq.code, lq.H, lq.num, q_len, lq.dh))
+            if sc.lq_ws is None or sc.lq_ws.numel() < need:
+                if sc.lq_ws is not None and sc.last_stream is not None:
+                    sc.lq_ws.record_stream(sc.last_stream)
+                sc.lq_ws = torch.empty(need, dtype=torch.uint8, device=device)
+            one_crossing = bool(self.__dict__.get("_prune_one_crossing"))
+            if not one_crossing:
+                # the importance kernels go out NOW, before any output tensor exists: the allocations and descriptors below
+                # (~30 us of host work) run under them.  (ff_ctx_prune_from_qk - importance, plan and gather enqueued by one
+                # crossing at the END of this function - is the form for a host whose preparation is cheap; here it left the
+                # GPU idle while Python prepared: 166-169 vs 156 us per Qwen2-VL cascade, profiles/EXPERIMENTS.md 5.4.)
+                if sc.ctx.dirty:
+                    _lib.check(lib.ff_ctx_reset(sc.ctx_ptr, stream or 0), "ff_ctx_reset")
+                rc = lib.ff_ctx_last_query_importance(sc.ctx_ptr, lq.q_last.data_ptr(), lq.k.data_ptr(), lq.code, lq.H, lq.H_kv, lq.num,
+                                                      q_len, lq.dh, lq.sh, lq.ss, lq.factor, 1 if lq.is_causal else 0,
+                                                      lq.bias.data_ptr() if lq.bias is not None else None, sc.sim32.data_ptr(),
+                                                      start, n_img, k, sc.lq_ws.data_ptr(), sc.lq_ws.numel(), stream or 0)
+                if rc:
+                    _fail(rc, "prune (importance)")
+                w_ptr, H, num, tables_ready = sc.sim32.data_ptr(), 1, 1, 1
         # nothing is read back (L_out is known): head mean + select tables, plan, gather - one host call
         out = torch.empty((1, L_out, d), dtype=dtype, device=device)
         srcs, outs, rebuild = self._aux_for_positions(position_embeddings, q_len, L_out)
@@ -702,12 +724,7 @@ class FrameFusion(nn.Module):
         else:
             _lib.MASK_TRIPLE.pack_into(call, _lib.PRUNE_CALL_MASK_OFFSET, 0, 0, 0)
         sc.order_gen = None
-        if lq is not None:
-            need = int(lib.ff_last_query_workspace_bytes(lq.code, lq.H, lq.num, q_len, lq.dh))
-            if sc.lq_ws is None or sc.lq_ws.numel() < need:
-                if sc.lq_ws is not None and sc.last_stream is not None:
-                    sc.lq_ws.record_stream(sc.last_stream)
-                sc.lq_ws = torch.empty(need, dtype=torch.uint8, device=device)
+        if one_crossing:
             _lib.LQ_ARGS.pack_into(sc.lqargs, 0, lq.q_last.data_ptr(), lq.k.data_ptr(), lq.code, lq.H, lq.H_kv, lq.num, lq.dh, lq.sh, lq.ss,
                                    lq.factor, 1 if lq.is_causal else 0, lq.bias.data_ptr() if lq.bias is not None else 0,
                                    sc.lq_ws.data_ptr(), sc.lq_ws.numel())

@@ -1082,6 +1082,13 @@ def test_prune_from_qk_equals_hook_then_prune(dtype, H, Hk, num, S, d, dh, conta
                finish_merging=True, finish_pruning=False, sparsity_list=[0.4, 0.2])
     o3, _, _ = f2(h, pos(), mask, ffa.last_query_importance(q, k, num=num, is_causal=True, framefusion=f2, defer=True), residual=res)
     assert same_bits(o3.cpu(), o2.cpu())
+    # the single-crossing form of the C ABI (ff_ctx_prune_from_qk: importance, plan and gather enqueued by ONE call; the Python
+    # host launches the importance early instead and uses two)
+    f4 = fresh()
+    f4._prune_one_crossing = True
+    o4, p4, m4 = f4.prune_from_qk(h, pos(), mask, q, k, num=num, is_causal=True, residual=res)
+    assert same_bits(o4.cpu(), o2.cpu()) and not f4._scratch[("cuda", 0)].dirty
+    assert (m4 is None) == (m2 is None) and (m4 is None or same_bits(m4.cpu(), m2.cpu()))
     # a handle for another length is refused before anything is enqueued
     f3 = fresh()
     with pytest.raises(ffa.FrameFusionHipError):
