@@ -470,10 +470,11 @@ def profiled_kernel_us(cfg):
 
 
 def two_samples_per_gpu(ffa, dev, F, P, d, p_change, seed, steps, warmup):
-    """Two independent samples on ONE GPU at the same time: two threads, each with its own FrameFusion instance, stream and
-    sample (the deployment the reference's demo uses for its replicas, llava_video_compare.py:217-223) - the result-block
-    poll runs in C with the interpreter lock released, so one sample's similarity / merge pass fills the other's plan-kernel
-    bubble and kernel ramps.  Whole-GPU throughput of `steps` steps per thread; NOT the headline (one sample per GPU)."""
+    """Two independent samples in flight on ONE GPU, two ways: from ONE host thread through FrameFusionPair (submit / collect,
+    two HIP streams), and from two threads, each with its own FrameFusion instance, stream and sample (the deployment the
+    reference's demo uses for its replicas, llava_video_compare.py:217-223; the result-block poll runs in C with the interpreter
+    lock released).  Either way one sample's similarity / merge pass fills the other's plan-kernel bubble and kernel ramps.
+    Whole-GPU throughput of `steps` steps per sample; NOT the headline (one sample per GPU per step)."""
     import threading
     from framefusion_amd.synth import video_tokens, rotary_tables
     work = []
@@ -483,58 +484,74 @@ def two_samples_per_gpu(ffa, dev, F, P, d, p_change, seed, steps, warmup):
         cos, sin = rotary_tables(L, HEAD_DIM, torch.bfloat16, device=str(dev))
         work.append(dict(h=h, h2=h.clone(), pt=pt, cos=cos, sin=sin, L=L, ff=ffa.FrameFusion(COST, THRESHOLD, RATIO_LB),
                          stream=torch.cuda.Stream(device=dev), out=None))
-    # the same two samples from ONE host thread: FrameFusionPair - sample 1's call is submitted (ff_ctx_merge_submit, its own
-    # stream) before sample 0's is collected and vice versa: always one call enqueued ahead of the one being waited for
-    pair = ffa.FrameFusionPair(work[0]["ff"], work[1]["ff"], dev, sync_with_current=False)
+    def fresh():
+        for w in work:
+            w["ff"] = ffa.FrameFusion(COST, THRESHOLD, RATIO_LB)
 
-    def calls(n):
-        for i in range(2 * n):
-            w = work[i & 1]
-            w["ff"].prepare(w["pt"], P, 0, w["L"], w["L"], w["L"])
-            yield (i & 1, w["h2"] if (i >> 1) & 1 else w["h"], [w["cos"], w["sin"]], None)
-    for _ in pair.run(calls(warmup)):
-        pass
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    outs = [None, None]
-    for i, o in enumerate(pair.run(calls(steps))):
-        outs[i & 1] = o
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    reduced = sum(w["L"] - o[0].shape[1] for w, o in zip(work, outs))
-    pair_res = {"us_per_pair_of_steps": dt / steps * 1e6, "tokens_reduced_per_s": reduced * steps / dt,
-                "how": "framefusion_amd.FrameFusionPair (ff_ctx_merge_submit / _collect), two HIP streams, no threads"}
-    for w in work:                      # the threads get fresh instances (their own streams)
-        w["ff"] = ffa.FrameFusion(COST, THRESHOLD, RATIO_LB)
-    start, stop = threading.Barrier(3), threading.Barrier(3)
+    def one_thread():
+        # FrameFusionPair - sample 1's call is submitted (ff_ctx_merge_submit, its own stream) before sample 0's is collected and
+        # vice versa: always one call enqueued ahead of the one being waited for
+        pair = ffa.FrameFusionPair(work[0]["ff"], work[1]["ff"], dev, sync_with_current=False)
 
-    def run(w):
-        torch.cuda.set_device(dev)
-        with torch.cuda.stream(w["stream"]):
-            def step(i):
+        def calls(n):
+            for i in range(2 * n):
+                w = work[i & 1]
                 w["ff"].prepare(w["pt"], P, 0, w["L"], w["L"], w["L"])
-                return w["ff"](w["h2"] if i & 1 else w["h"], [w["cos"], w["sin"]], None)[0]
-            for i in range(warmup):
-                step(i)
-            w["stream"].synchronize()
-            start.wait()
-            for i in range(steps):
-                w["out"] = step(i)
-            w["stream"].synchronize()
-            stop.wait()
-    threads = [threading.Thread(target=run, args=(w,)) for w in work]
-    for th in threads:
-        th.start()
-    start.wait()
-    t0 = time.perf_counter()
-    stop.wait()
-    dt = time.perf_counter() - t0
-    for th in threads:
-        th.join()
-    reduced = sum(w["L"] - w["out"].shape[1] for w in work)
-    threads_res = {"us_per_pair_of_steps": dt / steps * 1e6, "tokens_reduced_per_s": reduced * steps / dt}
-    return {"samples_in_flight": 2, "steps_per_sample": steps, "one_host_thread_pair": pair_res, "two_threads": threads_res,
-            "us_per_pair_of_steps": pair_res["us_per_pair_of_steps"], "tokens_reduced_per_s": pair_res["tokens_reduced_per_s"]}
+                yield (i & 1, w["h2"] if (i >> 1) & 1 else w["h"], [w["cos"], w["sin"]], None)
+        for _ in pair.run(calls(warmup)):
+            pass
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        outs = [None, None]
+        for i, o in enumerate(pair.run(calls(steps))):
+            outs[i & 1] = o
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return dt, sum(w["L"] - o[0].shape[1] for w, o in zip(work, outs))
+
+    def two_threads():
+        start, stop = threading.Barrier(3), threading.Barrier(3)
+
+        def run(w):
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(w["stream"]):
+                def step(i):
+                    w["ff"].prepare(w["pt"], P, 0, w["L"], w["L"], w["L"])
+                    return w["ff"](w["h2"] if i & 1 else w["h"], [w["cos"], w["sin"]], None)[0]
+                for i in range(warmup):
+                    step(i)
+                w["stream"].synchronize()
+                start.wait()
+                for i in range(steps):
+                    w["out"] = step(i)
+                w["stream"].synchronize()
+                stop.wait()
+        threads = [threading.Thread(target=run, args=(w,)) for w in work]
+        for th in threads:
+            th.start()
+        start.wait()
+        t0 = time.perf_counter()
+        stop.wait()
+        dt = time.perf_counter() - t0
+        for th in threads:
+            th.join()
+        return dt, sum(w["L"] - w["out"].shape[1] for w in work)
+
+    # the two forms alternate twice (whichever runs second in a process has measured up to 12 % slower - allocator pools of
+    # other streams, not the form): every number is reported, the summary is each form's best
+    runs = {"one_host_thread_pair": [], "two_threads": []}
+    for _ in range(2):
+        for name, fn in (("one_host_thread_pair", one_thread), ("two_threads", two_threads)):
+            fresh()
+            dt, reduced = fn()
+            runs[name].append({"us_per_pair_of_steps": dt / steps * 1e6, "tokens_reduced_per_s": reduced * steps / dt})
+    best = {k: max(v, key=lambda r: r["tokens_reduced_per_s"]) for k, v in runs.items()}
+    return {"samples_in_flight": 2, "steps_per_sample": steps, "order": "pair, threads, pair, threads (fresh instances each time)",
+            "one_host_thread_pair": {**best["one_host_thread_pair"], "all_us": [r["us_per_pair_of_steps"] for r in runs["one_host_thread_pair"]],
+                                     "how": "framefusion_amd.FrameFusionPair (ff_ctx_merge_submit / _collect), two HIP streams, no threads"},
+            "two_threads": {**best["two_threads"], "all_us": [r["us_per_pair_of_steps"] for r in runs["two_threads"]]},
+            "us_per_pair_of_steps": best["one_host_thread_pair"]["us_per_pair_of_steps"],
+            "tokens_reduced_per_s": best["one_host_thread_pair"]["tokens_reduced_per_s"]}
 
 
 def cascade(ffa, dev, F, P, d, p_change, thr, pre, post, heads, kv_heads, num, mrope, sigma_hi=1.6, reps=6, seed=1234,

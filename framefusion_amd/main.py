@@ -222,6 +222,7 @@ class FrameFusion(nn.Module):
 
     _PLAIN = (bool, int, float, str, list, tuple, dict, type(None), torch.Tensor)
     supports_residual = True      # forward(..., residual=) exists: see call_b_with_residual()
+    accepts_last_query = True     # forward(..., self_attn_weights=LastQuery) exists: see utils.last_query_importance(defer=True)
 
     def __setattr__(self, name, value):
         # The module has no parameters, buffers or submodules; its attributes are per-prefill state

@@ -139,7 +139,9 @@ def last_query_importance(query, key, num=1, is_causal=True, scale=None, framefu
     the prune call then goes straight to its plan.  `defer=True` returns a `LastQuery` handle instead of a tensor and launches
     nothing: passed to ``FrameFusion.forward`` as ``self_attn_weights`` (what the adapters in models/ do) it makes hook +
     prune ONE host call - `FrameFusion.prune_from_qk` is the same thing by name."""
-    if defer:
+    if defer and getattr(framefusion, "accepts_last_query", framefusion is None):
+        # (an object on `.framefusion` that is not this build's FrameFusion - the reference's module, an eager stand-in - gets
+        # the tensor below instead)
         # nothing is launched here: the prune call that receives this handle enqueues importance + plan + gather in ONE
         # crossing of the C ABI (K stays where it is - the layer's KV cache - until then)
         return LastQuery(query, key, num, is_causal, scale)

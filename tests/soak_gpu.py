@@ -5,6 +5,7 @@ by-patch runs are all in play - for as many seeds as the time budget allows.
     python tests/soak_gpu.py [seconds = 240] [first seed = 0]
     python tests/soak_gpu.py importance [seconds = 120] [first seed = 0]     # K5: random head layouts vs the oracle
     python tests/soak_gpu.py residual [seconds = 120] [first seed = 0]       # call B fused with the residual add
+    python tests/soak_gpu.py pair [seconds = 120] [first seed = 0]           # two prefills interleaved through FrameFusionPair
 """
 import sys
 import time
@@ -114,7 +115,46 @@ def residual_soak(budget, first):
     print(f"residual soak: {done} prefills (up to 3 fused calls each) bit-exact, seeds {first}..{seed - 1}, {time.time() - t0:.0f} s")
 
 
+def pair_soak(budget, first):
+    """Two random prefills (different shapes, regimes, containers) interleaved through FrameFusionPair - every call of one
+    sample submitted before the other sample's call is collected - against the same two prefills through independent
+    instances: every call's rows, positions, flags and budget lists bit for bit."""
+    from framefusion_amd.pair import FrameFusionPair
+    from tests.test_gpu_pair import run_independent, run_paired, equal_logs
+    t0, done, skipped, seed = time.time(), 0, 0, first
+    while time.time() - t0 < budget:
+        rng = np.random.default_rng(70_000 + seed)
+        seed += 1
+        cs = [draw(rng), draw(rng)]
+        cs[1]["dt"] = cs[0]["dt"]
+        samples = []
+        for c in cs:
+            h, pt = video_tokens(c["F"], c["P"], c["d"], p_change=c["p_change"], sigma=0.3, sigma_hi=1.4, seed=c["seed"],
+                                 pre=c["pre"], post=c["post"], dtype=c["dt"], grid=0.125)
+            L = h.shape[1]
+            pe = positions(c["container"], L, c["dt"])
+            pe = pe.to(DEV) if isinstance(pe, torch.Tensor) else [t.to(DEV) for t in pe]
+            samples.append(dict(h=h.to(DEV), pt=pt.to(DEV), P=c["P"], pre=c["pre"], n=c["F"] * c["P"], L=L, pos=pe))
+        mk = [lambda c=c: ffa.FrameFusion(c["cost"], c["thr"], c["lb"]) for c in cs]
+        try:
+            want = [run_independent(mk[x](), samples[x], cs[x]["layers"]) for x in (0, 1)]
+        except ValueError:                       # "The cost is too small": the same raise path is unit-tested
+            skipped += 1
+            continue
+        layers = max(cs[0]["layers"], cs[1]["layers"])
+        if cs[0]["layers"] != cs[1]["layers"]:
+            want = [run_independent(mk[x](), samples[x], layers) for x in (0, 1)]
+        got = run_paired(FrameFusionPair(mk[0](), mk[1]()), samples[0], samples[1], layers)
+        equal_logs(got[0], want[0])
+        equal_logs(got[1], want[1])
+        done += 1
+    print(f"pair soak: {done} pairs of prefills bit-exact against independent instances ({skipped} skipped), seeds {first}..{seed - 1}, "
+          f"{time.time() - t0:.0f} s")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "pair":
+        return pair_soak(float(sys.argv[2]) if len(sys.argv) > 2 else 120.0, int(sys.argv[3]) if len(sys.argv) > 3 else 0)
     if len(sys.argv) > 1 and sys.argv[1] == "residual":
         return residual_soak(float(sys.argv[2]) if len(sys.argv) > 2 else 120.0, int(sys.argv[3]) if len(sys.argv) > 3 else 0)
     if len(sys.argv) > 1 and sys.argv[1] == "importance":
