@@ -204,16 +204,18 @@ def _fail(rc: int, what: str, err_bits: int = 0):
 
 
 class FrameFusion(nn.Module):
-    def __init__(self, cost=0.3, similarity_lower_bound=0.6, ratio_lower_bound=0.1, compact_outputs=False):
+    def __init__(self, cost=0.3, similarity_lower_bound=0.6, ratio_lower_bound=0.1, compact_outputs=True):
         super().__init__()
         self.cost = cost
         self.similarity_lower_bound = similarity_lower_bound
         self.ratio_lower_bound = ratio_lower_bound
         # A merge call writes into buffers of the INPUT length (the output length is only known once the plan kernel
-        # has run, and the merge kernel is already enqueued behind it) and returns views of their first L_out rows: the
-        # caller's view keeps the whole buffer alive (302 MB for a 91 MB result at 64 x 576 x 4096).  compact_outputs
-        # = True copies the views into exactly sized tensors when less than half of the buffer is used - what the
-        # reference returns (main.py:132-138) - for ~30 us per call at that shape.  INTEGRATION.md, "Output buffers".
+        # has run, and the merge kernel is already enqueued behind it).  compact_outputs = True (the default since round 5):
+        # when less than half of a buffer is used the results are copied into exactly sized tensors - what the reference
+        # returns (main.py:132-138) - and the buffers go back to the allocator; ~30 us per call at 64 x 576 x 4096, within
+        # +-0.35 % on every end-to-end prefill measured (profiles/r05_e2e_prefill.json).  False: narrow() views of the
+        # input-length buffers (a view keeps its whole buffer alive: 302 MB for a 91 MB result) - the opt-in fast path a
+        # caller takes when the next layer's call replaces the views anyway.  INTEGRATION.md, "Output buffers".
         self.compact_outputs = compact_outputs
         self._scratch = {}
         self._ptype_gen = 0       # bumped whenever patch_type is (re)assigned: keys the cached by-patch order

@@ -125,8 +125,7 @@ def pair_soak(budget, first):
     while time.time() - t0 < budget:
         rng = np.random.default_rng(70_000 + seed)
         seed += 1
-        cs = [draw(rng), draw(rng)]
-        cs[1]["dt"] = cs[0]["dt"]
+        cs = [draw(rng), draw(rng)]                   # (two unrelated samples: shapes, dtypes, regimes, containers all differ)
         samples = []
         for c in cs:
             h, pt = video_tokens(c["F"], c["P"], c["d"], p_change=c["p_change"], sigma=0.3, sigma_hi=1.4, seed=c["seed"],

@@ -691,8 +691,8 @@ def test_determinism():
 
 @pytest.mark.parametrize("container", ["ids", "rotary", "mrope"])
 def test_compact_outputs_returns_exactly_sized_tensors(container):
-    """FrameFusion(compact_outputs=True): the tensors a merge call returns own exactly their bytes (the reference's
-    `hidden_states[token_mask, :]`, main.py:132-138) instead of being views of input-length buffers; same values."""
+    """FrameFusion(compact_outputs=True), the default: the tensors a merge call returns own exactly their bytes (the reference's
+    `hidden_states[token_mask, :]`, main.py:132-138); compact_outputs=False returns views of input-length buffers; same values."""
     from framefusion_amd.synth import rotary_tables
     F, P, d = 16, 48, 1024
     h, pt = video_tokens(F, P, d, p_change=0.2, sigma_hi=1.5, seed=9, pre=5, post=5, grid=0.125)
@@ -721,7 +721,8 @@ def test_compact_outputs_returns_exactly_sized_tensors(container):
         assert c.shape == v.shape and torch.equal(c.cpu().view(torch.uint8) if c.dtype == torch.bfloat16 else c.cpu(),
                                                   v.cpu().view(torch.uint8) if v.dtype == torch.bfloat16 else v.cpu())
         assert c.is_contiguous() and c.untyped_storage().nbytes() == c.numel() * c.element_size()
-    assert out_v.untyped_storage().nbytes() == L * d * 2                        # the default: a view of an L-row buffer
+    assert out_v.untyped_storage().nbytes() == L * d * 2                        # compact_outputs=False: a view of an L-row buffer
+    assert ffa.FrameFusion().compact_outputs is True                           # exactly sized outputs are the default (round 5)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -27,7 +27,7 @@ k_of = {}
 
 
 def make(form):
-    ff = ffa.FrameFusion(0.3, c["thr"], 0.1)
+    ff = ffa.FrameFusion(0.3, c["thr"], 0.1, compact_outputs=False)
     if form == "one":
         ff._prune_one_crossing = True
 

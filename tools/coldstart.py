@@ -34,7 +34,7 @@ def main():
                                  device=str(dev))
     L = hidden.shape[1]
     cos, sin = rotary_tables(L, bench.HEAD_DIM, torch.bfloat16, device=str(dev))
-    ff = ffa.FrameFusion(bench.COST, bench.THRESHOLD, bench.RATIO_LB)
+    ff = ffa.FrameFusion(bench.COST, bench.THRESHOLD, bench.RATIO_LB, **bench.VIEWS)
     alt = hidden.clone()
     flip = [0]
 

@@ -18,7 +18,7 @@ F, P, d = (int(x) for x in (sys.argv[1:4] if len(sys.argv) > 3 else (8, 64, 256)
 h, pt = video_tokens(F, P, d, p_change=0.3, seed=1, pre=4, post=4, dtype=torch.bfloat16, device=DEV)
 L = h.shape[1]
 cos, sin = rotary_tables(L, 64, torch.bfloat16, device=DEV)
-ff = ffa.FrameFusion(0.3, 0.6, 0.1)
+ff = ffa.FrameFusion(0.3, 0.6, 0.1, compact_outputs=False)
 
 
 def call():

@@ -19,7 +19,7 @@ pe0 = rotary_tables(L, 128, torch.bfloat16, device=str(dev), mrope=c["mrope"])
 gen = torch.Generator(device=dev).manual_seed(7)
 q = torch.randn(1, c["heads"], c["num"], 128, generator=gen, device=dev).to(torch.bfloat16)
 k_full = torch.randn(1, c["kv_heads"], L, 128, generator=gen, device=dev).to(torch.bfloat16)
-ff = ffa.FrameFusion(0.3, c["thr"], 0.1)
+ff = ffa.FrameFusion(0.3, c["thr"], 0.1, compact_outputs=False)
 k_of = {}
 
 

@@ -38,7 +38,7 @@ def main():
         ptype = ptype.view(F, P).t().reshape(1, F * P).contiguous()
     L = hidden.shape[1]
     cos, sin = rotary_tables(L, 128, dtype, device="cuda:0")
-    ff = ffa.FrameFusion(0.3, 0.6, 0.1)
+    ff = ffa.FrameFusion(0.3, 0.6, 0.1, compact_outputs=False)
     ff.prepare(ptype, P, 0, L, L, L)
     out, _, _ = ff(hidden, [cos, sin], None)
     info = ff.last_call

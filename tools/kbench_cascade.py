@@ -22,7 +22,7 @@ def main():
     F, P, d = a.frames, a.patches, a.dim
     h0, pt = video_tokens(F, P, d, p_change=a.p_change, sigma=0.3, sigma_hi=1.6, seed=1234, pre=14, post=20, device=dev)
     L = h0.shape[1]
-    ff = ffa.FrameFusion(0.3, 0.6, 0.1)
+    ff = ffa.FrameFusion(0.3, 0.6, 0.1, compact_outputs=False)
     agg = {}
     for rep in range(a.reps + 2):
         ff.prepare(pt, P, 14, 14 + F * P, F * P, L)

@@ -39,7 +39,7 @@ def main():
     t_i = timeit(lambda: ffa.last_query_importance(q, k, num=a.num, is_causal=True))
     w = ffa.scaled_dot_product_attention(q, k, None, num=a.num, is_causal=True, enable_gqa=True)
     imp = ffa.last_query_importance(q, k, num=a.num, is_causal=True)
-    ff = ffa.FrameFusion(0.3, 0.6, 0.1)
+    ff = ffa.FrameFusion(0.3, 0.6, 0.1, compact_outputs=False)
     pt = torch.full((1, a.S), 0, dtype=torch.long, device=dev)
     start, n_img = 14, a.S - 34
 

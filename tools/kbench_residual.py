@@ -17,7 +17,7 @@ g = torch.Generator(device=dev).manual_seed(1)
 res = [(0.5 * torch.randn(1, L, d, generator=g, device=dev)).bfloat16() for _ in range(2)]
 att = [(h - r).contiguous() for r in res]
 cos, sin = rotary_tables(L, 128, device=dev)
-ff = ffa.FrameFusion(0.3, 0.6, 0.1)
+ff = ffa.FrameFusion(0.3, 0.6, 0.1, compact_outputs=False)
 
 
 def timeit(fn, n=40):

@@ -30,7 +30,7 @@ pre, post = (a[3], a[4]) if len(a) >= 5 else (14, 20)
 h, pt = video_tokens(F, P, d, p_change=0.2, seed=1234, pre=pre, post=post, dtype=torch.bfloat16, device=DEV)
 L = h.shape[1]
 cos, sin = rotary_tables(L, 128, torch.bfloat16, device=DEV)
-ff = ffa.FrameFusion(0.3, 0.6, 0.1)
+ff = ffa.FrameFusion(0.3, 0.6, 0.1, compact_outputs=False)
 lib = _lib.load()
 marks = {}
 raw_begin, raw_finish = lib.ff_ctx_merge_begin, lib.ff_ctx_merge_finish

@@ -17,7 +17,7 @@ h, pt = video_tokens(F, P, d, p_change=p_change, sigma=0.3, seed=1234, device=de
 h2 = h.clone()
 L = h.shape[1]
 cos, sin = rotary_tables(L, 128, device=dev)
-ff = ffa.FrameFusion(0.3, 0.6, 0.1)
+ff = ffa.FrameFusion(0.3, 0.6, 0.1, compact_outputs=False)
 acc = []
 for it in range(60):
     ff.prepare(pt, P, 0, L, L, L)
