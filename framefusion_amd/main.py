@@ -40,7 +40,6 @@ def _round_to(value: float, dtype: torch.dtype) -> float:
     return float(torch.tensor(value, dtype=dtype))
 
 
-_ONE_CROSSING_BYTES = 64 << 20      # merge calls over less than this go out as one ff_ctx_merge (see FrameFusion._merge)
 _get_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
 _PACK_PTR = struct.Struct("=Q")
 _PACK_I64 = struct.Struct("=q")
@@ -325,6 +324,14 @@ class FrameFusion(nn.Module):
         bsz, q_len, hidden_size = hidden_states.size()
         prune_now = q_len > 1 and self.finish_merging == True and self.finish_pruning == False
         merge_now = q_len > 1 and (not self.finish_merging)
+        if (prune_now or merge_now) and (hidden_size * hidden_states.element_size()) & 15:
+            # rows that are not whole 16-byte words (no model the reference supports has them; its torch path does not care):
+            # zero columns up to the next word change neither a dot product, a norm nor a fold - pad, reduce, cut them off again
+            pad = (-hidden_size) % (16 // hidden_states.element_size())
+            out, position_embeddings, attention_mask = self.forward(
+                torch.nn.functional.pad(hidden_states, (0, pad)), position_embeddings, attention_mask, self_attn_weights,
+                None if residual is None else torch.nn.functional.pad(residual, (0, pad)))
+            return out[..., :hidden_size].contiguous(), position_embeddings, attention_mask
         if residual is not None:
             if residual.shape != hidden_states.shape or residual.dtype != hidden_states.dtype or residual.device != dev:
                 raise FrameFusionHipError("residual must have the shape, dtype and device of hidden_states")
@@ -424,12 +431,6 @@ class FrameFusion(nn.Module):
         lib = _lib.load()
         st = self._merge_prepare(hidden_states, position_embeddings, attention_mask, residual)
         sc = st["sc"]
-        if st["L"] * st["d"] * hidden_states.element_size() <= _ONE_CROSSING_BYTES:
-            # a short similarity pass (< ~20 us) would be over before the outputs below exist: the host, not the kernel, would
-            # set the pace (9.7 us of idle GPU between K1 and the plan in the second call of the Qwen2-VL cascade,
-            # profiles/r04_timeline_c3.txt).  Outputs first, then ONE crossing that enqueues all three launches back to back.
-            self._merge_outputs(st)
-            return self._merge_complete(st, lib.ff_ctx_merge(sc.ctx_ptr, sc.call_ptr, sc.res_ptr))
         rc = lib.ff_ctx_merge_begin(sc.ctx_ptr, sc.call_ptr)
         if rc:
             _fail(rc, "merge")
@@ -453,7 +454,7 @@ class FrameFusion(nn.Module):
         if self.__dict__.get("_ticket") is not None:
             raise FrameFusionHipError("submit(): the previous call of this instance has not been collected")
         q_len = hidden_states.shape[1]
-        if not (q_len > 1 and not self.finish_merging):
+        if not (q_len > 1 and not self.finish_merging) or (hidden_states.shape[2] * hidden_states.element_size()) & 15:
             return {"done": self.forward(hidden_states, position_embeddings, attention_mask, self_attn_weights, residual)}
         st = self._merge_prepare(hidden_states, position_embeddings, attention_mask, residual)
         self._merge_outputs(st)
@@ -844,6 +845,9 @@ class FrameFusion(nn.Module):
         device, dtype = hidden_states.device, hidden_states.dtype
         code = _dtype_code(hidden_states)
         hidden = hidden_states.contiguous()
+        if (d * hidden.element_size()) & 15:              # (zero columns up to whole 16-byte words: the similarities do not change)
+            hidden = torch.nn.functional.pad(hidden, (0, (-d) % (16 // hidden.element_size())))
+            d = hidden.shape[2]
         ptype = token_patch_type.to(device=device, dtype=torch.int64).contiguous()
         order = torch.empty(L, dtype=torch.int32, device=device)
         sim = torch.empty(L, dtype=dtype, device=device)
@@ -890,13 +894,16 @@ class FrameFusion(nn.Module):
                                           dst.data_ptr(), keep.data_ptr(), stats.data_ptr(), ws.data_ptr(),
                                           ws_bytes, stream), "ff_plan_from_index")
         hidden = hidden_states.contiguous()
-        compact = torch.empty(L, d, dtype=dtype, device=device)
-        _lib.check(lib.ff_merge_compact(hidden.data_ptr(), compact.data_ptr(), code, L, d, L, order.data_ptr(),
+        d_pad = d + (-d) % (16 // hidden.element_size())     # (rows as whole 16-byte words: zero columns fold to zero)
+        if d_pad != d:
+            hidden = torch.nn.functional.pad(hidden, (0, d_pad - d))
+        compact = torch.empty(L, d_pad, dtype=dtype, device=device)
+        _lib.check(lib.ff_merge_compact(hidden.data_ptr(), compact.data_ptr(), code, L, d_pad, L, order.data_ptr(),
                                         member.data_ptr(), 1, dst.data_ptr(), None, None, 0, stream),
                    "ff_merge_compact")
         keep_b = keep.bool()
         kept = torch.nonzero(keep_b).reshape(-1)
-        hidden_states[0, kept] = compact[: kept.numel()]      # members keep their old rows, like the reference
+        hidden_states[0, kept] = compact[: kept.numel(), :d]      # members keep their old rows, like the reference
         return hidden_states, keep_b[None, :]
 
     @staticmethod

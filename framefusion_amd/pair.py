@@ -22,6 +22,21 @@ from . import _lib
 from .main import FrameFusion
 
 
+_STREAM_PAIRS = {}
+
+
+def concurrent_streams(device):
+    """The two sample streams of `device`, created once per process and shared by every pair (HIP maps its streams onto a
+    handful of hardware queues: a process that keeps creating streams ends up with pairs that share one - such a pair measured
+    271 us per two calls where others measured 231-246, profiles/r05_pair_probe.txt)."""
+    key = (device.type, device.index)
+    got = _STREAM_PAIRS.get(key)
+    if got is None:
+        with torch.cuda.device(device):
+            got = _STREAM_PAIRS[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+    return got
+
+
 class FrameFusionPair:
     """``pair = FrameFusionPair(ff_a, ff_b)``.
 
@@ -59,7 +74,7 @@ class FrameFusionPair:
         key = (device.type, device.index)
         st = self._streams.get(key)
         if st is None:
-            st = self._streams[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+            st = self._streams[key] = concurrent_streams(device)
         return st
 
     @property

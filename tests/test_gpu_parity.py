@@ -1094,3 +1094,26 @@ def test_prune_from_qk_equals_hook_then_prune(dtype, H, Hk, num, S, d, dh, conta
     f3 = fresh()
     with pytest.raises(ffa.FrameFusionHipError):
         f3(h[:, :-1], pos(), None, ffa.last_query_importance(q, k, num=num, is_causal=True, defer=True))
+
+
+@pytest.mark.parametrize("dtype,d", [(torch.bfloat16, 100), (torch.float16, 36), (torch.float32, 7)])
+def test_rows_that_are_not_whole_16_byte_words(dtype, d):
+    """hidden_size * itemsize % 16 != 0 (no model of the reference has such rows; its torch path does not care): the host pads
+    zero columns up to the next word - neutral for dot products, norms and folds - and cuts them off again.  Whole cascade
+    (merge calls + the prune) against the oracle, bit for bit; the static entry points too."""
+    F, P, pre, post = 9, 21, 3, 4
+    h, pt = video_tokens(F, P, d, p_change=0.4, sigma=0.3, sigma_hi=1.4, seed=d, pre=pre, post=post, dtype=dtype, grid=0.125)
+    L = h.shape[1]
+    want, _ = harness.run_cascade(orc.OracleFrameFusion(0.3, 0.6, 0.1), h.clone(), pt.clone(), P, torch.arange(L)[None], None, 3)
+    got, _ = harness.run_cascade(ffa.FrameFusion(0.3, 0.6, 0.1), dev(h), dev(pt), P, dev(torch.arange(L)[None]), None, 3)
+    assert len(got) == len(want)
+    for a, b in zip(got, want):
+        assert (a["length"], a["finish_merging"], a["finish_pruning"], a["sparsity"]) == \
+               (b["length"], b["finish_merging"], b["finish_pruning"], b["sparsity"]), a["tag"]
+        assert a["hidden"].shape[-1] == d and a["hidden"].is_contiguous() and same_bits(a["hidden"].cpu(), b["hidden"]), a["tag"]
+        assert torch.equal(a["pos"].cpu(), b["pos"])
+    sim_g, ord_g = ffa.FrameFusion.compute_similarity_and_token_index_by_patch(dev(h), dev(pt), P)
+    sim_o, ord_o = orc.pair_similarity(h, pt, P)
+    assert torch.equal(ord_g.cpu(), ord_o) and same_bits(sim_g.cpu(), sim_o)
+    a, b = h[0, :50], h[0, 50:100]
+    assert same_bits(ffa.cosine_similarity(dev(a), dev(b)).cpu(), orc.staged_cosine(a, b))
