@@ -23,7 +23,8 @@ int launch_merge_compact(const void* hidden, const void* addend, void* hidden_ou
                          const int32_t* order, const uint8_t* member, int fold, const int32_t* dst,
                          const uint8_t* keep, const ff_aux_t* aux_host, int n_aux, int32_t* order_next,
                          int32_t* inv_next, int64_t* stats, hipStream_t st, bool skip_identity, void* zero_a,
-                         size_t zero_a_bytes, const void* zero_keys, int64_t zero_n, int zero_key_dt, int* t16_end);
+                         size_t zero_a_bytes, const void* zero_keys, int64_t zero_n, int zero_key_dt, int* t16_end,
+                         const int32_t* src, int64_t l_out);
 int launch_similarity_any(const void* hidden, const void* addend, int dtype, int64_t L, int64_t d, const int64_t* ptype,
                           int32_t* order, int32_t* inv, int64_t* stats, void* sim, int* l0, int* t16_end, double thr,
                           int64_t hint_pre, int64_t hint_patches, int64_t hint_frames, hipStream_t st);
@@ -115,7 +116,7 @@ static int merge_finish(const void* hidden, const void* addend, void* hidden_out
     if (rc) return rc;
     return ff::launch_merge_compact(hidden, addend, hidden_out, dtype, L, d, L_cap, order, member, fold, dst, keep, aux_host,
                                     n_aux, order_next, inv_next, stats, (hipStream_t)stream, true, za, zab, sim, L, dtype,
-                                    ff::ws_t16_end(ws, ws_bytes));
+                                    ff::ws_t16_end(ws, ws_bytes), nullptr, -1);
 }
 
 extern "C" int ff_merge_finish(const void* hidden, const void* addend, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
@@ -192,7 +193,10 @@ extern "C" int ff_prune_step(const void* hidden, const void* addend, void* hidde
     if (((uintptr_t)hidden & 15) || ((uintptr_t)addend & 15) || ((uintptr_t)hidden_out & 15) || ((d * esz) & 15)) return FF_ERR_ALIGN;
     return ff::launch_merge_compact(hidden, addend, hidden_out, dtype, S, d, L_cap, nullptr, member, FF_FOLD_DROP, dst, keep,
                                     aux_host, n_aux, nullptr, nullptr, nullptr, st, false, za, zab, have_tables ? imp : nullptr,
-                                    S, w_dtype, ff::ws_t16_end(ws, ws_bytes));
+                                    S, w_dtype, ff::ws_t16_end(ws, ws_bytes),
+                                    // (the plan wrote src[] = the inverse of dst[]: the gather walks the OUTPUT rows; exactly k of
+                                    // the n_img positions of the range are kept, so the output length is the caller's arithmetic)
+                                    k <= n_img ? ff::ws_scratch_ints(ws, S) : nullptr, S - n_img + k);
 }
 
 // ---- call context (ABI v7): one host call per FrameFusion.forward call ------------------------------------

@@ -35,6 +35,24 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
                                  (int)blockIdx.x, (int)blockIdx.y);
 }
 
+// The prune's gather by OUTPUT rows (prune_gather_body) + the short roles of a prune launch: auxiliary rows, table clearing.
+template <int DT, bool kAdd>
+__global__ __launch_bounds__(kMergeThreads) void k_prune_gather(
+    const char* __restrict__ hidden, const char* __restrict__ addend, char* __restrict__ out, uint32_t row_bytes, int L, int64_t L_cap,
+    int l_out, const int32_t* __restrict__ src, const int32_t* __restrict__ dst, const uint8_t* __restrict__ keep, AuxPack aux,
+    int n_main, int n_aux_blocks, ZeroJob zero, int rows) {
+    const int bx = (int)blockIdx.x, by = (int)blockIdx.y;
+    if (bx >= n_main + n_aux_blocks) {
+        if (by == 0) role_clear_tables(zero, bx - n_main - n_aux_blocks);
+        return;
+    }
+    if (bx >= n_main) {
+        if (by == 0) role_aux_rows(aux, bx - n_main, L, L_cap, keep, dst);
+        return;
+    }
+    prune_gather_body<DT, kAdd>(hidden, addend, out, row_bytes, L, l_out, src, rows, bx, by);
+}
+
 // ---- square attention-mask gather (main.py:137-138, 99-100): out[r, c] = mask[src[r], src[c]] ----------------
 // Round 2 ran one workgroup per INPUT row with a dst[] lookup per input element: L^2 index reads and 2-byte scattered
 // stores (2.7 GB of traffic for a bf16 mask at 37 k tokens).  Two levels now: k_invert_dst turns dst[] (row of every
@@ -162,7 +180,8 @@ int launch_merge_compact(const void* hidden, const void* addend, void* hidden_ou
                          const int32_t* order, const uint8_t* member, int fold, const int32_t* dst,
                          const uint8_t* keep, const ff_aux_t* aux_host, int n_aux, int32_t* order_next,
                          int32_t* inv_next, int64_t* stats, hipStream_t st, bool skip_identity, void* zero_a,
-                         size_t zero_a_bytes, const void* zero_keys, int64_t zero_n, int zero_key_dt, int* t16_end) {
+                         size_t zero_a_bytes, const void* zero_keys, int64_t zero_n, int zero_key_dt, int* t16_end,
+                         const int32_t* src, int64_t l_out) {
     AuxPack pack;
     pack.n = keep ? n_aux : 0;
     for (int x = 0; x < pack.n; ++x) pack.a[x] = aux_host[x];
@@ -170,9 +189,31 @@ int launch_merge_compact(const void* hidden, const void* addend, void* hidden_ou
     const int64_t row_bytes = d * (dtype == FF_F32 ? 4 : 2);
     const int nblk = (int)((row_bytes + 1023) / 1024);
     const int ny = (nblk + kMergeWaves - 1) / kMergeWaves;
+    const int n_aux_blocks = pack.n ? (int)((L + kMergeWaves * 4 - 1) / (kMergeWaves * 4)) : 0;
+    if (fold == FF_FOLD_DROP && !order && src && l_out >= 0) {
+        // a prune: by output rows (src[] = the plan's inverse of dst[]); `rows` kept rows x 4 column tiles per workgroup.
+        // 8 / 16 / 32 rows: 62.0 / 63.0 / 71.5 us at the 72B shape, 13.0 / 11.4 / 11.2 at the Qwen2-VL shape, 30.0 / 30.5 / 29.9 at
+        // C2's threshold cascade - against 79.1 / 17.2 / 33.8 for the walk over the input slots (profiles/r05_prune_gather.txt)
+        constexpr int rows = 16;
+        const int n_main = (int)((l_out + rows - 1) / rows);
+        ZeroJob zero{(uint4*)zero_a, (int)(zero_a_bytes / 16), zero_keys, (int)zero_n, zero_key_dt, t16_end, 0};
+        if (zero_a) zero.n_blocks = zero_keys ? (int)((zero_n + kMergeThreads * 16 - 1) / (kMergeThreads * 16)) : 1;
+        const dim3 grid((unsigned)(n_main + n_aux_blocks + zero.n_blocks), (unsigned)ny);
+        if (grid.x == 0) return FF_OK;
+#define FF_PG_LAUNCH(DT, ADD)                                                                                                  \
+    hipLaunchKernelGGL((k_prune_gather<DT, ADD>), grid, dim3(kMergeThreads), 0, st, (const char*)hidden, (const char*)addend,  \
+                       (char*)hidden_out, (uint32_t)row_bytes, (int)L, L_cap, (int)l_out, src, dst, keep, pack, n_main,        \
+                       n_aux_blocks, zero, rows)
+        switch (dtype) {
+            case FF_F32: if (addend) FF_PG_LAUNCH(FF_F32, true); else FF_PG_LAUNCH(FF_F32, false); break;
+            case FF_BF16: if (addend) FF_PG_LAUNCH(FF_BF16, true); else FF_PG_LAUNCH(FF_BF16, false); break;
+            default: if (addend) FF_PG_LAUNCH(FF_F16, true); else FF_PG_LAUNCH(FF_F16, false);
+        }
+#undef FF_PG_LAUNCH
+        return (int)hipGetLastError();
+    }
     const int slots = merge_slots(dtype, addend != nullptr, L, ny);
     const int n_main = (int)((L + slots - 1) / slots);
-    const int n_aux_blocks = pack.n ? (int)((L + kMergeWaves * 4 - 1) / (kMergeWaves * 4)) : 0;
     if (!order || !stats) order_next = nullptr;
     const int n_next_blocks = order_next ? (int)((L + kMergeThreads * 16 - 1) / (kMergeThreads * 16)) : 0;
     ZeroJob zero{(uint4*)zero_a, (int)(zero_a_bytes / 16), zero_keys, (int)zero_n, zero_key_dt, t16_end, 0};
@@ -213,7 +254,7 @@ extern "C" int ff_merge_compact(const void* hidden, void* hidden_out, int dtype,
     if (L == 0) return FF_OK;
     return ff::launch_merge_compact(hidden, nullptr, hidden_out, dtype, L, d, L_cap, order, member, fold, dst, keep, aux_host, n_aux,
                                     nullptr, nullptr, nullptr,
-                                    (hipStream_t)stream, false, nullptr, 0, nullptr, 0, 0, nullptr);
+                                    (hipStream_t)stream, false, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, -1);
 }
 
 extern "C" int ff_gather_mask(const void* mask, void* out, int64_t elem_bytes, int64_t L, int64_t L_cap,

@@ -83,6 +83,36 @@ __device__ inline void zero_by_key(const ZeroJob& z, int t) {
     for (int x = 0; x < kT16Copies; ++x) tab[x * 65536] = 0;
 }
 
+// ---- the short roles that ride along with a merge / prune launch (one workgroup each, by == 0 only) --------------------------
+// The select tables of this call have been consumed by the plan kernel: clear them for the next call's producer.
+__device__ inline void role_clear_tables(const ZeroJob& zero, int zb) {
+    if (zb == 0)
+        for (int z = threadIdx.x; z < zero.a_n16; z += kMergeThreads) zero.a[z] = make_uint4(0, 0, 0, 0);
+    if (zero.keys) {
+        const int t0 = (zb * kMergeThreads + threadIdx.x) * 16;
+        for (int t = t0; t < min(t0 + 16, zero.n); ++t) {
+            if (zero.key_dt == FF_BF16) zero_by_key<FF_BF16>(zero, t);
+            else if (zero.key_dt == FF_F16) zero_by_key<FF_F16>(zero, t);
+            else zero_by_key<FF_F32>(zero, t);
+        }
+    }
+}
+// Auxiliary rows (position embeddings, patch types, position ids): plain compaction by SEQUENCE position - reads coalesced,
+// writes in increasing order.  Workgroup `ab` owns 16 positions, 16 lanes per row.
+__device__ inline void role_aux_rows(const AuxPack& aux, int ab, int L, int64_t L_cap, const uint8_t* __restrict__ keep,
+                                     const int32_t* __restrict__ dst) {
+    const int lane = lane_id();
+    const int i = ab * kMergeWaves * 4 + wave_id() * 4 + (lane >> 4);
+    const int sub = lane & 15;
+    if (i >= L || !keep[i]) return;
+    const int r = dst[i];
+    for (int x = 0; x < aux.n; ++x) {
+        const ff_aux_t& ax = aux.a[x];
+        for (int64_t ou = 0; ou < ax.outer; ++ou)
+            copy_row(aux_src_row(ax, ou, i, L), (char*)ax.dst + (ou * L_cap + r) * ax.row_bytes, ax.row_bytes, sub, 16);
+    }
+}
+
 // (bx, by): the workgroup's coordinates in the merge kernel's own 2-D grid
 template <int DT, bool kAdd>
 __device__ inline void merge_compact_body(
@@ -100,17 +130,7 @@ __device__ inline void merge_compact_body(
         // ---- the select tables of this call have been consumed by the plan kernel: clear them for the
         // next call's producer (runs even when nothing is folded)
         if (by != 0) return;
-        const int zb = bx - n_main - n_aux_blocks - n_next_blocks;
-        if (zb == 0)
-            for (int z = threadIdx.x; z < zero.a_n16; z += kMergeThreads) zero.a[z] = make_uint4(0, 0, 0, 0);
-        if (zero.keys) {
-            const int t0 = (zb * kMergeThreads + threadIdx.x) * 16;
-            for (int t = t0; t < min(t0 + 16, zero.n); ++t) {
-                if (zero.key_dt == FF_BF16) zero_by_key<FF_BF16>(zero, t);
-                else if (zero.key_dt == FF_F16) zero_by_key<FF_F16>(zero, t);
-                else zero_by_key<FF_F32>(zero, t);
-            }
-        }
+        role_clear_tables(zero, bx - n_main - n_aux_blocks - n_next_blocks);
         return;
     }
     // nothing folded (a merge call whose threshold set is empty, main.py:264-266): the reduced
@@ -156,15 +176,7 @@ __device__ inline void merge_compact_body(
         // ---- auxiliary rows (position embeddings, patch types, position ids): plain compaction by
         // SEQUENCE position - reads coalesced, writes in increasing order.  Only by == 0.
         if (by != 0) return;
-        const int i = (bx - n_main) * kMergeWaves * 4 + wave_id() * 4 + (lane >> 4);
-        const int sub = lane & 15;                       // 16 lanes per row
-        if (i >= L || !keep[i]) return;
-        const int r = dst[i];
-        for (int x = 0; x < aux.n; ++x) {
-            const ff_aux_t& ax = aux.a[x];
-            for (int64_t ou = 0; ou < ax.outer; ++ou)
-                copy_row(aux_src_row(ax, ou, i, L), (char*)ax.dst + (ou * L_cap + r) * ax.row_bytes, ax.row_bytes, sub, 16);
-        }
+        role_aux_rows(aux, bx - n_main, L, L_cap, keep, dst);
         return;
     }
     // slot groups are walked from the END of the by-patch order: the similarity pass read the rows
@@ -339,6 +351,55 @@ __device__ inline void merge_compact_body(
         if (b1.last) break;
     }
     if (open_r >= 0) flush();
+}
+
+// ---- the prune's gather (main.py:78-101: hidden_states[:, keep_indexs]) by OUTPUT rows -----------------------------------------
+// merge_compact_body with fold = DROP walks the INPUT slots and skips the loads of the dropped ones: at the prune's keep ratios
+// (29 % at the 72B shape) a batch of 4 slots holds ~1 load, a wave has 1-2 requests in flight, and the pass ran at 0.47-0.66
+// of the rate the same kernel reaches on a merge (profiles/r05_kernel_fractions.txt).  Here the plan kernel also writes
+// src[] (the position of every output row: the inverse of dst[]) and a workgroup owns `rows` consecutive OUTPUT rows x 4 column
+// tiles: every request is a row that is kept, two batches of kDepth pieces in flight per wave, rows written in order.
+template <int DT, bool kAdd>
+__device__ inline void prune_gather_body(const char* __restrict__ hidden, const char* __restrict__ addend, char* __restrict__ out,
+                                         uint32_t row_bytes, int L, int l_out, const int32_t* __restrict__ src, int rows,
+                                         const int bx, const int by) {
+    constexpr int kDepth = kAdd ? 4 : 8;
+    const int lane = lane_id();
+    const int r0 = bx * rows, r1 = min(r0 + rows, l_out);
+    const uint32_t col = (uint32_t)uniform(by * kMergeWaves + wave_id()) * 1024u;
+    if (col >= row_bytes || r0 >= r1) return;
+    const uint32_t blk_bytes = min(1024u, row_bytes - col);
+    const uint32_t voff = (uint32_t)lane * 16;
+    // rows <= 64: one coalesced load names every source row (clamped: a row index is never trusted with an address)
+    const int mine = r0 + lane < r1 ? min(max(src[r0 + lane], 0), L - 1) : 0;
+    auto in_piece = [&](const char* base, int i) { return make_rsrc(base + (int64_t)i * row_bytes + col, blk_bytes); };
+    uint4 a[kDepth], b[kDepth], a2[kAdd ? kDepth : 1], b2[kAdd ? kDepth : 1];
+    auto issue = [&](uint4* buf, uint4* buf2, int r) {
+#pragma unroll
+        for (int u = 0; u < kDepth; ++u) {
+            if (r + u < r1) {
+                const int i = __builtin_amdgcn_readlane(mine, r + u - r0);
+                buf[u] = buf_load16<2>(in_piece(hidden, i), voff);
+                if constexpr (kAdd) buf2[u] = buf_load16<2>(in_piece(addend, i), voff);
+            }
+        }
+    };
+    auto store = [&](const uint4* buf, const uint4* buf2, int r) {
+#pragma unroll
+        for (int u = 0; u < kDepth; ++u) {
+            if (r + u < r1) {
+                uint4 v = buf[u];
+                if constexpr (kAdd) v = add16<DT>(v, buf2[u]);
+                buf_store16<2>(make_rsrc(out + (int64_t)(r + u) * row_bytes + col, blk_bytes), voff, v);
+            }
+        }
+    };
+    for (int r = r0; r < r1; r += 2 * kDepth) {
+        issue(a, a2, r);
+        issue(b, b2, r + kDepth);
+        store(a, a2, r);
+        store(b, b2, r + kDepth);
+    }
 }
 
 }  // namespace ff

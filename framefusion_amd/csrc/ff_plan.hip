@@ -572,6 +572,7 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan(
         for (int e = 0; e < 4; ++e) {
             const int kp = (kb >> (8 * e)) & 1u;
             d[e] = kp ? p : -1;
+            if (kp && pp.src_out && i0 + e < L) pp.src_out[p] = i0 + e;
             p += kp;
         }
         if (i0 + 4 <= L) {
@@ -817,6 +818,7 @@ static int launch_plan(const void* values, PlanParams pp, bool have_tables, int6
 PlanParams merge_plan_params(int dtype, double thr, double sub, double ratio_lb, long long force_k) {
     PlanParams pp;
     pp.mode = 0; pp.lo = 0; pp.hi = -1; pp.k_given = force_k; pp.sub = sub; pp.ratio_lb = ratio_lb; pp.n_slices = 0;
+    pp.src_out = nullptr;
     // the k-th similarity of a video sits in the binade of typical thresholds: [0.5, 1)
     const double guess_value = force_k >= 0 ? 0.75 : thr;
     pp.p0_guess = (int)(dtype == FF_F32 ? host_thr_key<FF_F32>(guess_value) >> 24
@@ -848,6 +850,7 @@ PlanParams prune_plan_params(int dtype, int64_t start, int64_t n_img, int64_t k)
     PlanParams pp;
     pp.mode = 1; pp.lo = (int)start; pp.hi = (int)(start + n_img); pp.k_given = k; pp.sub = 0; pp.ratio_lb = 0;
     pp.thr_key = 0xffffffffu; pp.n_slices = 0;
+    pp.src_out = nullptr;
     // importances are probabilities of ~1/S: guess the binade of 1/n_img
     const double guess_value = n_img > 0 ? 1.0 / (double)n_img : 1.0;
     pp.p0_guess = (int)(dtype == FF_F32 ? host_thr_key<FF_F32>(guess_value) >> 24
@@ -855,10 +858,12 @@ PlanParams prune_plan_params(int dtype, int64_t start, int64_t n_img, int64_t k)
     return pp;
 }
 
+// Also writes src[] = the inverse of dst[] (position of every output row) into ws_scratch_ints(ws, S): the prune's gather walks it
 int launch_plan_prune(const void* imp, int dtype, int64_t S, int64_t start, int64_t n_img, int64_t k,
                       uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats, void* ws, size_t ws_bytes,
                       bool have_tables, hipStream_t st) {
-    const PlanParams pp = prune_plan_params(dtype, start, n_img, k);
+    PlanParams pp = prune_plan_params(dtype, start, n_img, k);
+    pp.src_out = ws_scratch_ints(ws, S);
     switch (dtype) {
         case FF_F32: return launch_plan<FF_F32>(imp, pp, have_tables, S, S, nullptr, member, keep, dst, stats, ws, ws_bytes, nullptr, 0, st);
         case FF_BF16: return launch_plan<FF_BF16>(imp, pp, have_tables, S, S, nullptr, member, keep, dst, stats, ws, ws_bytes, nullptr, 0, st);

@@ -15,6 +15,8 @@ struct PlanParams {
     uint32_t thr_key;
     int p0_guess;        // expected top byte of the k-th key (speculative prefetch of its level-1 rows)
     int n_slices;
+    int32_t* src_out;    // optional (prune): src_out[dst[i]] = i for every kept position - the inverse of dst[], what the
+                         // prune's gather walks by OUTPUT rows (ff_merge_body.h, prune_gather_body)
 };
 
 // Copy of the result block into device-visible pinned host memory: one lane per word (a single
@@ -330,6 +332,7 @@ __device__ inline void plan_fast_body(
     if (i0 < L) {
         dst[i0] = kp ? before + ex : -1;
         keep[i0] = (uint8_t)kp;
+        if (pp.src_out && kp) pp.src_out[before + ex] = i0;
     }
     if (bid == nblk - 1) {
         if (tid == 0) {

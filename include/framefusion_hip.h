@@ -152,7 +152,8 @@ int ff_plan_from_index(const int64_t* merge_index, int64_t n_merge, const int32_
  * importance [S] dtype T; keeps every position outside [start, start+n_img) and the k largest
  * inside it (ties -> lowest index).  Outputs as ff_plan_merge with order = identity; member[i] = 1
  * marks a DROPPED position (nothing is folded: ff_merge_compact is then called with order = NULL
- * and fold = 0). */
+ * and fold = 0).  The [S] int32 scratch inside `ws` also receives src[] = the inverse of dst[] (the
+ * position of every output row), which the gather of ff_prune_step walks by output rows. */
 int ff_plan_prune(const void* importance, int dtype, int64_t S, int64_t start, int64_t n_img,
                   int64_t k, uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
                   void* ws, size_t ws_bytes, ff_stream_t stream);
