@@ -146,6 +146,9 @@ PROTOTYPES = {
     "ff_ctx_merge_begin": (_i32, [_vp, _vp]),
     "ff_ctx_merge_finish": (_i32, [_vp, _vp, _vp]),
     "ff_ctx_merge": (_i32, [_vp, _vp, _vp]),
+    "ff_ctx_merge_plan": (_i32, [_vp, _vp]),
+    "ff_ctx_merge_wait": (_i32, [_vp, _vp, _vp]),
+    "ff_ctx_merge_apply": (_i32, [_vp, _vp, _vp]),
     "ff_ctx_merge_submit": (_i32, [_vp, _vp]),
     "ff_ctx_merge_collect": (_i32, [_vp, _vp, _vp]),
     "ff_ctx_prune": (_i32, [_vp, _vp]),

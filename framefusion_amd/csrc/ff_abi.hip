@@ -92,15 +92,17 @@ static int merge_finish(const void* hidden, const void* addend, void* hidden_out
                         const int32_t* order, const int32_t* inv, const void* sim, uint8_t* member, int32_t* dst,
                         uint8_t* keep, int64_t* stats, int64_t* stats_host_mapped, int64_t seq, const ff_aux_t* aux_host,
                         int n_aux, int32_t* order_next, int32_t* inv_next, void* ws, size_t ws_bytes,
-                        ff_stream_t stream) {
-    if (!hidden || !hidden_out || !order || !inv || !sim || !member || !dst || !keep || !stats || !ws) return FF_ERR_ARG;
+                        ff_stream_t stream, int phase = 3, int64_t min_cap = -1) {
+    // phase: 1 = the plan only (no output field is looked at), 2 = the merge kernel only (behind a plan whose result the caller
+    // has seen: L_cap >= min_cap = its l_out is enough), 3 = both (L_cap >= L: the output length is not known yet)
+    if (!hidden || (!hidden_out && (phase & 2)) || !order || !inv || !sim || !member || !dst || !keep || !stats || !ws) return FF_ERR_ARG;
     if ((order_next == nullptr) != (inv_next == nullptr)) return FF_ERR_ARG;
     if (ws_bytes < ff_workspace_bytes(L, 1)) return FF_ERR_WORKSPACE;
-    if (L_cap < L) return FF_ERR_ARG;
+    if ((phase & 2) && L_cap < (phase == 3 ? L : min_cap)) return FF_ERR_ARG;
     if (dtype != FF_F32 && dtype != FF_BF16 && dtype != FF_F16) return FF_ERR_ARG;
     if (n_aux < 0 || n_aux > FF_MAX_AUX || (n_aux > 0 && !aux_host)) return FF_ERR_ARG;
     const int64_t esz = dtype == FF_F32 ? 4 : 2;
-    if (((uintptr_t)hidden & 15) || ((uintptr_t)addend & 15) || ((uintptr_t)hidden_out & 15) || ((d * esz) & 15)) return FF_ERR_ALIGN;
+    if (((uintptr_t)hidden & 15) || ((uintptr_t)addend & 15) || ((phase & 2) && ((uintptr_t)hidden_out & 15)) || ((d * esz) & 15)) return FF_ERR_ALIGN;
     if (order_next && ((uintptr_t)member & 15)) return FF_ERR_ALIGN;
     if (L == 0) return FF_OK;
     if (((uintptr_t)member & 7) || ((uintptr_t)dst & 15) || ((uintptr_t)keep & 15) || ((uintptr_t)order & 15) ||
@@ -111,9 +113,11 @@ static int merge_finish(const void* hidden, const void* addend, void* hidden_out
     void *za, *zb;
     size_t zab, zbb;
     ff::table_regions(ws, ws_bytes, L, &za, &zab, &zb, &zbb);
-    int rc = ff::launch_plan_merge(sim, dtype, order, inv, L, threshold, sub, ratio_lb, member, dst, keep, stats, ws, ws_bytes,
+    int rc = FF_OK;
+    if (phase & 1)
+        rc = ff::launch_plan_merge(sim, dtype, order, inv, L, threshold, sub, ratio_lb, member, dst, keep, stats, ws, ws_bytes,
                                    true, stats_host_mapped, seq, (hipStream_t)stream, force_k);
-    if (rc) return rc;
+    if (rc || !(phase & 2)) return rc;
     return ff::launch_merge_compact(hidden, addend, hidden_out, dtype, L, d, L_cap, order, member, fold, dst, keep, aux_host,
                                     n_aux, order_next, inv_next, stats, (hipStream_t)stream, true, za, zab, sim, L, dtype,
                                     ff::ws_t16_end(ws, ws_bytes), nullptr, -1);
@@ -320,19 +324,20 @@ static int ctx_wait(ff_ctx_t* c, hipStream_t st, int64_t* waited_ns) {
     return rc;
 }
 
-static int ctx_finish_enqueue(ff_ctx_t* c, const ff_merge_call_t* a) {
+static int ctx_finish_enqueue(ff_ctx_t* c, const ff_merge_call_t* a, int phase = 3, int64_t min_cap = -1) {
     if (a->fold != FF_FOLD_SEQUENTIAL && a->fold != FF_FOLD_MEAN) return FF_ERR_ARG;
     int rc = merge_finish(a->hidden, a->addend, a->hidden_out, (int)a->dtype, a->L, a->d, a->L_cap, a->threshold, a->sub,
                           a->ratio_lb, a->force_k < 0 ? -1 : (long long)a->force_k, (int)a->fold, c->order, c->inv, c->sim,
                           c->member, c->dst, c->keep, c->stats, c->stats_host, c->seq, a->aux, (int)a->n_aux, c->order_next,
-                          c->inv_next, c->ws, c->ws_bytes, a->stream);
+                          c->inv_next, c->ws, c->ws_bytes, a->stream, phase, min_cap);
     if (rc) return rc;
-    c->dirty = 0;
+    if (phase & 2) c->dirty = 0;           // (the merge kernel is what clears the select tables)
     return rc;
 }
 
 // everything of a finish that follows the argument checks; `enqueued`: plan + K4 of the first attempt are already on the stream
-static int ctx_finish(ff_ctx_t* c, const ff_merge_call_t* a, ff_merge_result_t* r, bool enqueued) {
+static int ctx_after_result(ff_ctx_t* c, const ff_merge_call_t* a, const ff_merge_result_t* r);
+static int ctx_finish(ff_ctx_t* c, const ff_merge_call_t* a, ff_merge_result_t* r, bool enqueued, int phase = 3) {
     int rc;
     c->in_flight = 0;
     hipStream_t st = (hipStream_t)a->stream;
@@ -340,7 +345,7 @@ static int ctx_finish(ff_ctx_t* c, const ff_merge_call_t* a, ff_merge_result_t* 
     r->wait_ns = 0;
     for (int attempt = 0;; ++attempt) {
         if (!(enqueued && attempt == 0)) {
-            rc = ctx_finish_enqueue(c, a);
+            rc = ctx_finish_enqueue(c, a, phase);
             if (rc) { c->dirty = 1; c->order_len = 0; return rc; }
         }
         int64_t waited = 0;
@@ -372,6 +377,16 @@ static int ctx_finish(ff_ctx_t* c, const ff_merge_call_t* a, ff_merge_result_t* 
         r->l_out = h[FF_STAT_LOUT];
         break;
     }
+    if (phase == 1) {                      // the merge kernel is still to come (ff_ctx_merge_apply)
+        c->in_flight = 3;
+        return FF_OK;
+    }
+    return ctx_after_result(c, a, r);
+}
+
+// what follows the merge kernel's enqueue once the result is known: mask gather, order swap
+static int ctx_after_result(ff_ctx_t* c, const ff_merge_call_t* a, const ff_merge_result_t* r) {
+    int rc;
     // the attention mask follows once the call is known to be valid and to fold something: nothing for an attempt whose layout
     // hint was wrong, nothing when the sequence stays as it is (the caller keeps its own mask)
     if (a->mask && r->l_out != a->L) {
@@ -397,7 +412,7 @@ static int ctx_finish_check(ff_ctx_t* c, const ff_merge_call_t* a, ff_merge_resu
     if (!a || !r) return FF_ERR_ARG;
     int rc = ctx_check(c, a->L);
     if (rc) return rc;
-    if (!c->in_flight) return FF_ERR_STATE;
+    if (c->in_flight != 1) return FF_ERR_STATE;
     if (a->mask && !a->mask_out) return FF_ERR_ARG;
     return FF_OK;
 }
@@ -425,6 +440,43 @@ extern "C" int ff_ctx_merge_collect(ff_ctx_t* c, const ff_merge_call_t* a, ff_me
     int rc = ctx_finish_check(c, a, r);
     if (rc) return rc;
     return ctx_finish(c, a, r, true);
+}
+
+// ---- the merge call for exactly sized outputs: the host sees l_out BEFORE the merge kernel is enqueued --------------------------
+// begin (K1) -> ff_ctx_merge_plan (plan kernel enqueued, nothing waited for) -> ff_ctx_merge_wait (result block; a wrong layout
+// hint is repeated through K0 here) -> the host sizes its outputs to l_out -> ff_ctx_merge_apply (merge kernel, mask gather,
+// order swap).  Costs the GPU the host's reaction time between plan and merge kernel (~10-20 us) and saves the input-length
+// output buffers (or the copy out of them).
+extern "C" int ff_ctx_merge_plan(ff_ctx_t* c, const ff_merge_call_t* a) {
+    if (!a) return FF_ERR_ARG;
+    int rc = ctx_check(c, a->L);
+    if (rc) return rc;
+    if (c->in_flight != 1) return FF_ERR_STATE;
+    rc = ctx_finish_enqueue(c, a, 1);
+    if (rc) { c->in_flight = 0; c->dirty = 1; c->order_len = 0; return rc; }
+    c->in_flight = 2;
+    return FF_OK;
+}
+
+extern "C" int ff_ctx_merge_wait(ff_ctx_t* c, const ff_merge_call_t* a, ff_merge_result_t* r) {
+    if (!a || !r) return FF_ERR_ARG;
+    int rc = ctx_check(c, a->L);
+    if (rc) return rc;
+    if (c->in_flight != 2) return FF_ERR_STATE;
+    return ctx_finish(c, a, r, true, 1);            // (leaves in_flight = 3 on success)
+}
+
+extern "C" int ff_ctx_merge_apply(ff_ctx_t* c, const ff_merge_call_t* a, const ff_merge_result_t* r) {
+    if (!a || !r) return FF_ERR_ARG;
+    int rc = ctx_check(c, a->L);
+    if (rc) return rc;
+    if (c->in_flight != 3) return FF_ERR_STATE;
+    if (a->mask && !a->mask_out) return FF_ERR_ARG;
+    if (r->l_out != c->stats_host[FF_STAT_LOUT] || r->l_out < 0 || r->l_out > a->L) return FF_ERR_ARG;      // not this call's result
+    c->in_flight = 0;
+    rc = ctx_finish_enqueue(c, a, 2, r->l_out);
+    if (rc) { c->dirty = 1; c->order_len = 0; return rc; }
+    return ctx_after_result(c, a, r);
 }
 
 extern "C" int ff_ctx_merge(ff_ctx_t* c, const ff_merge_call_t* a, ff_merge_result_t* r) {

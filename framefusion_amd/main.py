@@ -208,13 +208,13 @@ class FrameFusion(nn.Module):
         self.cost = cost
         self.similarity_lower_bound = similarity_lower_bound
         self.ratio_lower_bound = ratio_lower_bound
-        # A merge call writes into buffers of the INPUT length (the output length is only known once the plan kernel
-        # has run, and the merge kernel is already enqueued behind it).  compact_outputs = True (the default since round 5):
-        # when less than half of a buffer is used the results are copied into exactly sized tensors - what the reference
-        # returns (main.py:132-138) - and the buffers go back to the allocator; ~30 us per call at 64 x 576 x 4096, within
-        # +-0.35 % on every end-to-end prefill measured (profiles/r05_e2e_prefill.json).  False: narrow() views of the
-        # input-length buffers (a view keeps its whole buffer alive: 302 MB for a 91 MB result) - the opt-in fast path a
-        # caller takes when the next layer's call replaces the views anyway.  INTEGRATION.md, "Output buffers".
+        # compact_outputs = True (the default since round 5): exactly sized outputs, what the reference returns
+        # (main.py:132-138).  The host waits for the plan's result block, sizes the outputs to l_out and only then enqueues
+        # the merge kernel (ff_ctx_merge_plan / _wait / _apply): the GPU idles for the host's reaction time between the two
+        # kernels (~10-20 us), nothing is over-allocated, nothing is copied.  False: the merge kernel is enqueued blind, right
+        # behind the plan, into buffers of the INPUT length, and narrow() views of them are returned (a view keeps its whole
+        # buffer alive: 302 MB for a 91 MB result at 64 x 576 x 4096) - the opt-in fast path: no idle gap.  End to end the two
+        # differ by less than +-0.35 % (profiles/r05_e2e_prefill.json).  INTEGRATION.md, "Output buffers".
         self.compact_outputs = compact_outputs
         self._scratch = {}
         self._ptype_gen = 0       # bumped whenever patch_type is (re)assigned: keys the cached by-patch order
@@ -434,6 +434,14 @@ class FrameFusion(nn.Module):
         rc = lib.ff_ctx_merge_begin(sc.ctx_ptr, sc.call_ptr)
         if rc:
             _fail(rc, "merge")
+        if self.compact_outputs:
+            # exactly sized outputs (the default): the plan goes out behind K1, the host waits for l_out, sizes the outputs to it
+            # and only then enqueues the merge kernel - no input-length buffers, no copy; the GPU idles for the host's reaction
+            # time between the two kernels instead
+            rc = lib.ff_ctx_merge_plan(sc.ctx_ptr, sc.call_ptr)
+            if rc:
+                _fail(rc, "merge")
+            return self._merge_exact_tail(st)
         self._merge_outputs(st)
         # The one device->host hand-off of the call: the plan kernel stores the result block into pinned
         # host memory (sequence word last) BEFORE the merge kernel runs, so the host learns L_out while the
@@ -457,9 +465,14 @@ class FrameFusion(nn.Module):
         if not (q_len > 1 and not self.finish_merging) or (hidden_states.shape[2] * hidden_states.element_size()) & 15:
             return {"done": self.forward(hidden_states, position_embeddings, attention_mask, self_attn_weights, residual)}
         st = self._merge_prepare(hidden_states, position_embeddings, attention_mask, residual)
-        self._merge_outputs(st)
         sc = st["sc"]
-        rc = _lib.load().ff_ctx_merge_submit(sc.ctx_ptr, sc.call_ptr)
+        lib = _lib.load()
+        if self.compact_outputs:                 # exactly sized outputs: K1 + plan now, outputs and merge kernel at collect()
+            rc = lib.ff_ctx_merge_begin(sc.ctx_ptr, sc.call_ptr) or lib.ff_ctx_merge_plan(sc.ctx_ptr, sc.call_ptr)
+            st["exact"] = True
+        else:
+            self._merge_outputs(st)
+            rc = lib.ff_ctx_merge_submit(sc.ctx_ptr, sc.call_ptr)
         if rc:
             _fail(rc, "merge")
         self._ticket = st
@@ -473,8 +486,29 @@ class FrameFusion(nn.Module):
         self._ticket = None
         sc = ticket["sc"]
         with torch.cuda.device(ticket["device"]):
+            if ticket.get("exact"):
+                return self._merge_exact_tail(ticket)
             rc = _lib.load().ff_ctx_merge_collect(sc.ctx_ptr, sc.call_ptr, sc.res_ptr)
             return self._merge_complete(ticket, rc)
+
+    def _merge_exact_tail(self, st):
+        """wait for the result block -> outputs of exactly l_out rows -> merge kernel (ff_ctx_merge_wait / _apply)."""
+        lib = _lib.load()
+        sc = st["sc"]
+        rc = lib.ff_ctx_merge_wait(sc.ctx_ptr, sc.call_ptr, sc.res_ptr)
+        if rc:
+            return self._merge_complete(st, rc)                      # (raises)
+        L, L_out = st["L"], int(sc.res.l_out)
+        if L_out == L:
+            # nothing folds: the launch only clears the select tables; no output is written (any valid pointer will do)
+            _PACK_PTR.pack_into(sc.call, 16, st["hidden"].data_ptr())
+            _PACK_I64.pack_into(sc.call, _lib.MERGE_CALL_AUX_OFFSET - 8, 0)
+            _lib.MASK_TRIPLE.pack_into(sc.call, _lib.MERGE_CALL_MASK_OFFSET, 0, 0, 0)
+            st.update(mask_cap=None, L_cap=L)
+        else:
+            self._merge_outputs(st, L_out)
+        rc = lib.ff_ctx_merge_apply(sc.ctx_ptr, sc.call_ptr, sc.res_ptr)
+        return self._merge_complete(st, rc)
 
     def _merge_prepare(self, hidden_states, position_embeddings, attention_mask, residual=None):
         """Validation + the input half of the call block (everything ff_ctx_merge_begin reads), on PyTorch's current stream."""
@@ -519,11 +553,15 @@ class FrameFusion(nn.Module):
                     hidden_states=hidden_states, position_embeddings=position_embeddings, attention_mask=attention_mask,
                     mask_in=mask_in, residual=residual)
 
-    def _merge_outputs(self, st):
-        """The output half of the call block (read by ff_ctx_merge_finish only): allocated while the similarity pass runs."""
+    def _merge_outputs(self, st, L_cap=None):
+        """The output half of the call block (read by ff_ctx_merge_finish / _apply only).  L_cap = None: buffers of the INPUT
+        length, allocated while the similarity pass runs (the output length is not known yet); else exactly L_cap = l_out rows."""
         sc, L, d, dtype, device, ptype = st["sc"], st["L"], st["d"], st["dtype"], st["device"], st["ptype"]
         call = sc.call
-        L_cap = L
+        exact = L_cap is not None
+        if not exact:
+            L_cap = L
+        _PACK_I64.pack_into(call, 56, L_cap)                           # ff_merge_call_t.L_cap
         out = torch.empty((1, L_cap, d), dtype=dtype, device=device)
         ptype_out = torch.empty((1, L_cap), dtype=torch.int64, device=device)
         srcs, outs, rebuild = self._aux_for_positions(st["position_embeddings"], L, L_cap)
@@ -535,7 +573,7 @@ class FrameFusion(nn.Module):
         # ABI's other form - mask + an [L_cap, L_cap] buffer in the call block, gathered by ff_ctx_merge_finish itself - is
         # what a host without a cheap allocator uses; `_mask_through_call` routes through it for the tests)
         mask_cap, mask_in = None, st["mask_in"]
-        if mask_in is not None and self.__dict__.get("_mask_through_call"):
+        if mask_in is not None and (exact or self.__dict__.get("_mask_through_call")):
             mask_cap = torch.empty(1, 1, L_cap, L_cap, dtype=mask_in.dtype, device=mask_in.device)
             _lib.MASK_TRIPLE.pack_into(call, _lib.MERGE_CALL_MASK_OFFSET, mask_in.data_ptr(), mask_cap.data_ptr(), mask_in.element_size())
         else:

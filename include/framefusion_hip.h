@@ -387,7 +387,8 @@ typedef struct ff_ctx {
     int64_t seq;           /* number of the last merge call (echoed by the device)                      */
     int64_t order_len;     /* length of the sequence `order`/`inv` describe; 0 = none                   */
     int64_t dirty;         /* a call died half-way: workspace + stats are reset by the next call        */
-    int64_t in_flight;     /* 1 between ff_ctx_merge_begin and ff_ctx_merge_finish                      */
+    int64_t in_flight;     /* 0: no call; 1: begun (K1 enqueued); 2: planned (ff_ctx_merge_plan); 3: result
+                              known, merge kernel still to come (ff_ctx_merge_wait)                      */
     int64_t swaps;         /* number of order <-> order_next exchanges so far (owner mirrors its views) */
     int64_t last_L;        /* input length of the merge call that finished last and whose keep set is still in
                               the scratch (0: none) - what ff_ctx_gather_mask may be asked for (ABI v9)         */
@@ -454,6 +455,20 @@ int ff_ctx_merge(ff_ctx_t* ctx, const ff_merge_call_t* call, ff_merge_result_t* 
  * Results are those of ff_ctx_merge, bit for bit. */
 int ff_ctx_merge_submit(ff_ctx_t* ctx, const ff_merge_call_t* call);
 int ff_ctx_merge_collect(ff_ctx_t* ctx, const ff_merge_call_t* call, ff_merge_result_t* result);
+
+/* The merge call for EXACTLY SIZED outputs (ABI v9): the host learns l_out before the merge kernel is enqueued and sizes
+ * hidden_out / aux[].dst / mask_out to it (L_cap = l_out) - no input-length buffers, no copy out of them.
+ *   ff_ctx_merge_begin  K1 (as above)
+ *   ff_ctx_merge_plan   the plan kernel, enqueued behind it; no output field of `call` is looked at; nothing is waited for
+ *   ff_ctx_merge_wait   waits for the result block (a wrong layout hint is repeated through K0 here): result->l_out
+ *   ff_ctx_merge_apply  the merge kernel with the call's (now set) output fields, L_cap >= l_out; mask gather; order swap.
+ *                       When l_out == L nothing is written: any non-NULL hidden_out will do, n_aux = 0 (the launch still
+ *                       clears the select tables).
+ * Between plan and merge kernel the GPU idles for the host's reaction time (~10-20 us); ff_ctx_merge_finish / _submit avoid that
+ * by enqueueing the merge kernel blind, into buffers of L rows.  What FrameFusion.forward does by default (compact_outputs). */
+int ff_ctx_merge_plan(ff_ctx_t* ctx, const ff_merge_call_t* call);
+int ff_ctx_merge_wait(ff_ctx_t* ctx, const ff_merge_call_t* call, ff_merge_result_t* result);
+int ff_ctx_merge_apply(ff_ctx_t* ctx, const ff_merge_call_t* call, const ff_merge_result_t* result);
 
 /* The attention mask of the merge call that just finished on this context, gathered with its keep set (main.py:137-138):
  * out[r, c] = mask[src[r], src[c]] for the l_out kept positions, row stride L_cap (>= l_out) elements.  FF_ERR_STATE unless

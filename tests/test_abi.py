@@ -151,6 +151,12 @@ def test_context_calls_validate_before_any_hip_call():
     assert lib.ff_ctx_merge_begin(a(ctx), a(call)) == -4           # workspace smaller than ff_workspace_bytes(cap)
     ctx.ws_bytes = lib.ff_workspace_bytes(1024, 1)
     assert lib.ff_ctx_merge_finish(a(ctx), a(call), a(res)) == _lib.ERR_STATE     # finish without begin
+    # the exact-output flow is a state machine too: plan needs a begun call, wait a planned one, apply a known result
+    assert lib.ff_ctx_merge_plan(a(ctx), a(call)) == _lib.ERR_STATE
+    assert lib.ff_ctx_merge_wait(a(ctx), a(call), a(res)) == _lib.ERR_STATE
+    assert lib.ff_ctx_merge_apply(a(ctx), a(call), a(res)) == _lib.ERR_STATE
+    assert lib.ff_ctx_merge_collect(a(ctx), a(call), a(res)) == _lib.ERR_STATE
+    assert lib.ff_ctx_merge_plan(a(ctx), None) == -1 and lib.ff_ctx_merge_wait(a(ctx), a(call), None) == -1
     pc = _lib.FFPruneCall()
     pc.S = 4096
     assert lib.ff_ctx_prune(a(ctx), a(pc)) == -1
