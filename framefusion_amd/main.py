@@ -495,13 +495,25 @@ class FrameFusion(nn.Module):
         """wait for the result block -> outputs of exactly l_out rows -> merge kernel (ff_ctx_merge_wait / _apply)."""
         lib = _lib.load()
         sc = st["sc"]
+        # While K1 runs: outputs for the length the top-k branch would give (L - int(sub * ftn), main.py:122 - host arithmetic
+        # when the number of non-text tokens is known: from prepare()'s layout scalars, or from the previous call of the
+        # prefill).  If the plan decides that way the merge kernel goes out the moment the result is seen; if not (threshold
+        # branch) the guess costs one allocation that was made under the similarity pass.
+        guess = st.get("L_guess")
+        if guess is not None and 0 < guess < st["L"]:
+            self._merge_outputs(st, guess)
+        else:
+            guess = None
         rc = lib.ff_ctx_merge_wait(sc.ctx_ptr, sc.call_ptr, sc.res_ptr)
         if rc:
             return self._merge_complete(st, rc)                      # (raises)
         L, L_out = st["L"], int(sc.res.l_out)
-        if L_out == L:
+        if L_out == guess:
+            pass                                                     # (the call block already describes the right outputs)
+        elif L_out == L:
             # nothing folds: the launch only clears the select tables; no output is written (any valid pointer will do)
             _PACK_PTR.pack_into(sc.call, 16, st["hidden"].data_ptr())
+            _PACK_I64.pack_into(sc.call, 56, L)                        # ff_merge_call_t.L_cap
             _PACK_I64.pack_into(sc.call, _lib.MERGE_CALL_AUX_OFFSET - 8, 0)
             _lib.MASK_TRIPLE.pack_into(sc.call, _lib.MERGE_CALL_MASK_OFFSET, 0, 0, 0)
             st.update(mask_cap=None, L_cap=L)
@@ -549,7 +561,14 @@ class FrameFusion(nn.Module):
                                        order_valid, self._threshold_for(dtype), sub, self.ratio_lower_bound, -1,
                                        _lib.FOLD_SEQUENTIAL, hint_pre, hint_frames, stream or 0, 0)
         sc.order_gen = None                  # until the call has come back
-        return dict(sc=sc, stream=stream, L=L, d=d, dtype=dtype, device=device, hidden=hidden, addend=addend, ptype=ptype,
+        # the number of non-text tokens, where the host can know it without asking the device (see _merge_exact_tail)
+        ftn = None
+        if hint_frames:
+            ftn = hint_frames * P
+        elif order_valid and self.last_call is not None and self.last_call.get("kind") == "merge" and self.last_call["L_out"] == L:
+            ftn = self.last_call["ftn"] - (self.last_call["L_in"] - L)
+        L_guess = None if ftn is None or ftn <= 0 else L - min(int(sub * ftn), ftn)
+        return dict(sc=sc, stream=stream, L=L, d=d, dtype=dtype, device=device, hidden=hidden, addend=addend, ptype=ptype, L_guess=L_guess,
                     hidden_states=hidden_states, position_embeddings=position_embeddings, attention_mask=attention_mask,
                     mask_in=mask_in, residual=residual)
 

@@ -107,9 +107,16 @@ static int full_mode(int F, int P, int d, int pre, int L, const std::vector<uint
     call2.aux[1] = ff_aux_t{dtab_out[0], dtab_out2[0], dh * 2, planes, (int64_t)L * dh * 2};
     call2.aux[2] = ff_aux_t{dtab_out[1], dtab_out2[1], dh * 2, planes, (int64_t)L * dh * 2};
     const int64_t swaps_before = ctx.swaps;
-    FF(ff_ctx_merge(&ctx, &call2, &res[1]));
-    CK(hipStreamSynchronize(st));
+    // ... through the exact-output flow (ABI v9): plan behind K1, wait for l_out, size the outputs to it (L_cap = l_out: the aux
+    // planes come out l_out rows apart), then the merge kernel
+    FF(ff_ctx_merge_begin(&ctx, &call2));
+    FF(ff_ctx_merge_plan(&ctx, &call2));
+    if (ff_ctx_merge_apply(&ctx, &call2, &res[1]) != FF_ERR_STATE) { fprintf(stderr, "apply before wait was not refused\n"); return 6; }
+    FF(ff_ctx_merge_wait(&ctx, &call2, &res[1]));
     const int64_t l2 = res[1].l_out;
+    call2.L_cap = l2;
+    FF(ff_ctx_merge_apply(&ctx, &call2, &res[1]));
+    CK(hipStreamSynchronize(st));
     std::vector<uint16_t> o1((size_t)l1 * d), o2((size_t)l2 * d), t2((size_t)planes * l2 * dh);
     std::vector<int64_t> p2(l2);
     std::vector<uint8_t> keep2(l1);
@@ -126,7 +133,7 @@ static int full_mode(int F, int P, int d, int pre, int L, const std::vector<uint
         printf("HIDDEN2_FNV %016llx\nPTYPE2_FNV %016llx\n", (unsigned long long)fnv_words16(o2), (unsigned long long)fnv_words64(p2));
         for (int w = 0; w < 2; ++w) {
             for (int p = 0; p < planes; ++p)
-                CK(hipMemcpy(t2.data() + (size_t)p * l2 * dh, (char*)dtab_out2[w] + (size_t)p * l1 * dh * 2, (size_t)l2 * dh * 2, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(t2.data() + (size_t)p * l2 * dh, (char*)dtab_out2[w] + (size_t)p * l2 * dh * 2, (size_t)l2 * dh * 2, hipMemcpyDeviceToHost));
             printf("TABLE%d_FNV %016llx\n", w, (unsigned long long)fnv_words16(t2));
         }
     }
