@@ -190,7 +190,8 @@ def main():
     per_rank = dp.gather_records(dist, (rank, dev.index, L, L_out, elapsed / args.steps * 1e3, dp.sample_seed(args.seed, rank),
                                         info["count"], su.get("min", 0.0), su.get("median", 0.0), su.get("p90", 0.0), su.get("max", 0.0)), dev)
     who = dp.gather_identities(dist, dev)          # hostname / pid / PCI address of every rank's GPU: N ranks = N distinct devices?
-    distinct = len({(w.get("hostname"), w.get("pci_bus_id")) for w in who})
+    # (a platform that reports no PCI address falls back on the UUID, then on the device index the rank bound itself to)
+    distinct = len({(w.get("hostname"), w.get("pci_bus_id") or w.get("uuid") or f"index {int(r[1])}") for w, r in zip(who, per_rank)})
     backend_used = dist.get_backend() if dist is not None else None
     if world > 1 and not args.oversubscribe and (distinct != world or backend_used != "nccl"):
         # an N-GPU line must be N devices talking RCCL: anything else is a functional check and has to say so (--oversubscribe)

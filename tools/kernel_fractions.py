@@ -11,7 +11,7 @@ PEAK, ELT, DH = 8.0e12, 2, 128
 tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 print(f"# tools/kernel_fractions.py {tag}: compulsory bytes per kernel / duration (rocprofv3 timelines of the same tag) / 8 TB/s.")
 print("# K1 similarity: Nv rows read.  K4 of a folding merge: (L_in + L_out) rows + cos/sin in + out + 8-byte ints (SURVEY 8d).  K4 of an")
-print("# identity merge: nothing (early exit).  K4 of a prune: 2 x L_out x (row + cos/sin rows) - dropped rows are never read.  K5: H_kv x S x dh.")
+print("# identity merge: nothing (early exit).  The prune's gather: 2 x L_out x (row + cos/sin rows) - dropped rows are never read.  K5: H_kv x S x dh.")
 print("# plan kernels move < 1 MB: latency, no fraction.\n")
 worst = 0.0
 for cfg in ("c2", "7b", "c3", "c5", "c5topk", "c2thr"):
@@ -38,10 +38,10 @@ for cfg in ("c2", "7b", "c3", "c5", "c5topk", "c2thr"):
                    ("k_merge_compact", 0 if a == b else (a + b) * row + (a + b) * pe_row + 8 * (a + b))]
             nv -= a - b
         else:
-            per = [("k_lq", 0), ("k_lq", c["kv_heads"] * a * DH * ELT), ("k_plan", 0), ("k_merge_compact", 2 * b * (row + pe_row))]
+            per = [("k_lq", 0), ("k_lq", c["kv_heads"] * a * DH * ELT), ("k_plan", 0), ("k_prune_gather", 2 * b * (row + pe_row))]
         for want, nbytes in per:
             name, us = kern[q]
-            assert name.startswith(want), (cfg, q, name, want)
+            assert name.startswith(want) or (want == "k_prune_gather" and name.startswith("k_merge_compact")), (cfg, q, name, want)
             q += 1
             if want == "k_lq" and nbytes == 0:            # scores + finish: one line for the pair
                 name2, us2 = kern[q]
