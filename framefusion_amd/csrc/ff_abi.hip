@@ -418,16 +418,6 @@ static int ctx_finish_check(ff_ctx_t* c, const ff_merge_call_t* a, ff_merge_resu
 }
 
 extern "C" int ff_ctx_merge_finish(ff_ctx_t* c, const ff_merge_call_t* a, ff_merge_result_t* r) {
-    if (c && a && r && c->in_flight == 2) {
-        // the plan is already on the stream (ff_ctx_merge_plan right behind begin: a short similarity pass would otherwise be
-        // over before the host has its outputs, and the plan would wait for the host): only the merge kernel is missing
-        int rc = ctx_check(c, a->L);
-        if (rc) return rc;
-        if (a->mask && !a->mask_out) return FF_ERR_ARG;
-        rc = ctx_finish_enqueue(c, a, 2, a->L);
-        if (rc) { c->in_flight = 0; c->dirty = 1; c->order_len = 0; return rc; }
-        return ctx_finish(c, a, r, true);
-    }
     int rc = ctx_finish_check(c, a, r);
     if (rc) return rc;
     return ctx_finish(c, a, r, false);

@@ -40,7 +40,6 @@ def _round_to(value: float, dtype: torch.dtype) -> float:
     return float(torch.tensor(value, dtype=dtype))
 
 
-_PLAN_FIRST_BYTES = 1 << 62        # view outputs: merge calls over less than this enqueue their plan before they allocate (FrameFusion._merge)
 _get_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
 _PACK_PTR = struct.Struct("=Q")
 _PACK_I64 = struct.Struct("=q")
@@ -443,12 +442,6 @@ class FrameFusion(nn.Module):
             if rc:
                 _fail(rc, "merge")
             return self._merge_exact_tail(st)
-        if st["L"] * st["d"] * hidden_states.element_size() <= _PLAN_FIRST_BYTES:
-            # a short similarity pass is over before the outputs below exist: the plan (which needs none of them) goes out
-            # behind it now, ff_ctx_merge_finish then adds the merge kernel only
-            rc = lib.ff_ctx_merge_plan(sc.ctx_ptr, sc.call_ptr)
-            if rc:
-                _fail(rc, "merge")
         self._merge_outputs(st)
         # The one device->host hand-off of the call: the plan kernel stores the result block into pinned
         # host memory (sequence word last) BEFORE the merge kernel runs, so the host learns L_out while the

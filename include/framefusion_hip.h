@@ -438,9 +438,6 @@ typedef struct ff_merge_result {
  * every ~50 us and a failed or drained stream ends the wait with FF_ERR_DEVICE / the hipError_t.
  * A FF_ERR_BIT_LAYOUT result is handled inside finish: workspace reset, the whole call repeated
  * with hint_frames = 0, result->unhinted = 1.
- * finish also accepts a call whose plan is already enqueued (ff_ctx_merge_plan right behind begin, which looks at no output
- * field): it then adds the merge kernel only - for short sequences, where the similarity pass is over before the host has
- * allocated its outputs and the plan would otherwise wait for the host.
  * ff_ctx_merge = begin + finish (outputs allocated up front).
  * Because finish waits on host memory it cannot be captured into a hipGraph (neither can anything that must learn
  * L_out before it continues); the capturable form of the same three launches is ff_merge_step / ff_merge_begin +

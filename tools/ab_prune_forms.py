@@ -3,7 +3,6 @@
   hook      last_query_importance(q, k, framefusion=ff) in the attention hook, then forward(..., importance)     (rounds 3-4)
   early     forward(..., LastQuery handle): importance launched at the top of _prune, plan + gather at its end  (shipped)
   one       forward(..., LastQuery handle) with ff._prune_one_crossing: ff_ctx_prune_from_qk at the end of _prune
-  late      "early" with main._PLAN_FIRST_BYTES = 0: every merge call allocates its (view) outputs before its plan is enqueued
 Whole prefill cascades of a trace_config configuration back to back.   python tools/ab_prune_forms.py [c3|c5|c2thr] [rounds]"""
 import os, sys, time
 import torch
@@ -33,7 +32,6 @@ def make(form):
         ff._prune_one_crossing = True
 
     def prefill():
-        ffa.main._PLAN_FIRST_BYTES = 0 if form == "late" else (1 << 62)
         ff.prepare(pt, P, c["pre"], c["pre"] + F * P - 1, F * P, L)
         h, pe = h0, [t for t in pe0]
         n = 0
@@ -50,7 +48,7 @@ def make(form):
     return prefill
 
 
-forms = {f: make(f) for f in ("hook", "early", "one", "late")}
+forms = {f: make(f) for f in ("hook", "early", "one")}
 outs = {f: fn() for f, fn in forms.items()}
 assert all(torch.equal(outs["hook"], o) for o in outs.values()), "the three forms disagree"
 for fn in forms.values():
