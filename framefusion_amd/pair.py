@@ -25,15 +25,32 @@ from .main import FrameFusion
 _STREAM_PAIRS = {}
 
 
+def _new_hip_stream(device):
+    """A stream created through the HIP runtime itself (hipStreamCreateWithFlags, non-blocking), wrapped for PyTorch.  Streams
+    from torch's pool were all created when the pool was: which hardware queue each sits on is fixed, and two of them can share
+    one - their kernels then run in submission order (1 pool pair in 5 did, profiles/r05_pair_probe.txt: 270 us per two calls
+    where independent streams give 231-242).  A stream created NOW gets the least used queue: 4 pairs of 4 ran at 233-239 us."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so.7")                       # (the runtime torch has loaded: same handle)
+    s = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = hip.hipStreamCreateWithFlags(ctypes.byref(s), ctypes.c_uint(1))      # hipStreamNonBlocking
+    if rc != 0 or not s.value:
+        raise OSError(f"hipStreamCreateWithFlags failed ({rc})")
+    return torch.cuda.ExternalStream(s.value, device=device)
+
+
 def concurrent_streams(device):
-    """The two sample streams of `device`, created once per process and shared by every pair (HIP maps its streams onto a
-    handful of hardware queues: a process that keeps creating streams ends up with pairs that share one - such a pair measured
-    271 us per two calls where others measured 231-246, profiles/r05_pair_probe.txt)."""
+    """The two sample streams of `device`, created once per process (never destroyed) and shared by every pair."""
     key = (device.type, device.index)
     got = _STREAM_PAIRS.get(key)
     if got is None:
-        with torch.cuda.device(device):
-            got = _STREAM_PAIRS[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+        try:
+            got = (_new_hip_stream(device), _new_hip_stream(device))
+        except (OSError, AttributeError):                       # no direct access to the runtime: torch's pool will do
+            with torch.cuda.device(device):
+                got = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+        _STREAM_PAIRS[key] = got
     return got
 
 

@@ -1,14 +1,15 @@
 #!/usr/bin/env python
-"""How much does the one-thread pair depend on WHICH two HIP streams it runs on? (development probe: the pair on the process's
-cached pair streams, on six fresh stream pairs, and the two-thread form in between; profiles/r05_pair_probe.txt)"""
-import os, sys, threading, time
+"""How much does the one-thread pair depend on WHICH two HIP streams it runs on? (development probe: the pair on streams from
+torch's pool, on streams created through the HIP runtime directly (torch.cuda.ExternalStream), on a normal + a high-priority
+stream; the two-thread form in between; profiles/r05_pair_probe.txt)"""
+import ctypes, os, sys, threading, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench
 import framefusion_amd as ffa
 from framefusion_amd.synth import video_tokens, rotary_tables
 
 dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
 F, P, d = 64, 576, 4096
 work = []
 for t in range(2):
@@ -17,6 +18,14 @@ for t in range(2):
     cos, sin = rotary_tables(L, 128, torch.bfloat16, device=str(dev))
     work.append(dict(h=h, h2=h.clone(), pt=pt, cos=cos, sin=sin, L=L, stream=torch.cuda.Stream(device=dev), out=None))
 steps, warmup = 100, 20
+hip = ctypes.CDLL("libamdhip64.so.7")
+
+
+def hip_stream(flags=1):                      # hipStreamNonBlocking
+    s = ctypes.c_void_p()
+    rc = hip.hipStreamCreateWithFlags(ctypes.byref(s), ctypes.c_uint(flags))
+    assert rc == 0, rc
+    return torch.cuda.ExternalStream(s.value, device=dev)
 
 
 def fresh():
@@ -40,11 +49,11 @@ def run_pair(pair):
     return (time.perf_counter() - t0) / steps * 1e6
 
 
-def new_pair(own_streams=False):
+def new_pair(streams=None):
     fresh()
     pair = ffa.FrameFusionPair(work[0]["ff"], work[1]["ff"], None, sync_with_current=False)
-    if own_streams:        # two fresh torch streams, unprobed (what the pair did before it probed for concurrency)
-        pair._streams[(dev.type, dev.index)] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+    if streams is not None:
+        pair._streams[(dev.type, dev.index)] = streams
     return pair
 
 
@@ -82,14 +91,20 @@ def show(tag, us, pair=None):
     extra = ""
     if pair is not None:
         extra = "  streams " + " ".join(hex(s.cuda_stream) for s in pair.streams)
-    print(f"{tag:42s} {us:7.1f} us per two calls   reserved {torch.cuda.memory_reserved() / 2**30:.2f} GiB{extra}", flush=True)
+    print(f"{tag:52s} {us:7.1f} us per two calls{extra}", flush=True)
 
 
-p0 = new_pair(); show("pair (the process's pair streams)", run_pair(p0), p0)
-for n in range(6):
-    p = new_pair(own_streams=True)
-    show(f"pair on fresh streams #{n}", run_pair(p), p)
+p0 = new_pair(); show("pair (the process's pair streams: torch pool)", run_pair(p0), p0)
+for n in range(4):
+    p = new_pair((torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)))
+    show(f"torch pool streams #{n}", run_pair(p), p)
+for n in range(4):
+    p = new_pair((hip_stream(), hip_stream()))
+    show(f"hipStreamCreateWithFlags(nonblocking) x 2 #{n}", run_pair(p), p)
+for n in range(3):
+    p = new_pair((torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev, priority=-1)))
+    show(f"normal + high priority #{n}", run_pair(p), p)
+p = new_pair((torch.cuda.current_stream(dev), hip_stream()))
+show("PyTorch's current stream + one new stream", run_pair(p), p)
 show("two threads", run_threads())
 p0 = new_pair(); show("pair (the process's pair streams) after threads", run_pair(p0), p0)
-show("two threads again", run_threads())
-p0 = new_pair(); show("pair (the process's pair streams) again", run_pair(p0), p0)
