@@ -84,6 +84,28 @@ def launch_ranks(n_ranks: int, script: str, argv: Sequence[str]) -> None:
     os.execvpe(cmd[0], cmd, env)
 
 
+class _StdoutToStderr:
+    """While RCCL sets itself up: file descriptor 1 points at stderr, and C stdio is flushed before it is put back.  RCCL
+    prints a five-line banner ("RCCL version : ...") with printf on rank 0 when its first communicator is created; stdout of
+    a bench run is ONE JSON line, and a buffered banner would otherwise surface behind it when the process exits."""
+
+    def __enter__(self):
+        import ctypes
+        sys.stdout.flush()
+        self._libc = ctypes.CDLL(None)
+        self._libc.fflush(None)
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        self._libc.fflush(None)
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def _timeout_s() -> float:
     return float(os.environ.get("FF_DP_INIT_TIMEOUT", "120"))
 
@@ -208,9 +230,10 @@ def init(backend: str = "nccl", device: Optional[torch.device] = None, force: bo
     err: Optional[BaseException] = None
     joined = False
     try:
-        _join(dist, backend, device, world, rank, force)
-        joined = True
-        _probe(dist, backend, device, world)
+        with _StdoutToStderr():                  # (RCCL's banner, gloo's connection notes: not on the report's stdout)
+            _join(dist, backend, device, world, rank, force)
+            joined = True
+            _probe(dist, backend, device, world)
     except Exception as e:                                      # noqa: BLE001
         err = e
     everyone = _agree(dist, err is None, world, rank) if joined else False

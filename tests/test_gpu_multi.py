@@ -27,8 +27,8 @@ def run_bench(*argv, env_extra=None, expect_rc=0):
         assert res.returncode == expect_rc, (res.returncode, res.stderr[-2000:])
         return res.stderr
     assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
-    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, res.stdout
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), res.stdout       # ONE line on stdout, nothing else (RCCL's banner included)
     return json.loads(lines[0])
 
 
