@@ -107,7 +107,7 @@ class _StdoutToStderr:
 
 
 def _timeout_s() -> float:
-    return float(os.environ.get("FF_DP_INIT_TIMEOUT", "120"))
+    return float(os.environ.get("FF_DP_INIT_TIMEOUT", "300"))
 
 
 def _join(dist, backend: str, device, world: int, rank: int, force: bool):
@@ -209,7 +209,7 @@ def init(backend: str = "nccl", device: Optional[torch.device] = None, force: bo
     or None.
 
     IPC-mode fallback: HSA_ENABLE_IPC_MODE_LEGACY is read once, when the HSA runtime starts, so a process cannot change
-    its mind.  If joining or the first collective fails - raises, or does not complete within FF_DP_INIT_TIMEOUT (120) s -
+    its mind.  If joining or the first collective fails - raises, or does not complete within FF_DP_INIT_TIMEOUT (300) s -
     on ANY rank (the ranks exchange their verdicts through the rendezvous store), EVERY rank re-executes itself - same
     pid, so an outer torch.distributed.run keeps supervising it - with the variable flipped ("0" <-> unset) and
     FF_DP_ATTEMPT=1; a second failure is final and leaves no process group behind.  `ipc_mode()` / `attempt()` say what ran."""

@@ -172,7 +172,7 @@ def test_nccl_init_plumbing_without_a_gpu(monkeypatch):
     dev = torch.device("cuda", 1)
     assert dp.init("nccl", dev) is dist
     import datetime
-    tmo = {"timeout": datetime.timedelta(seconds=120)}                       # (hangs become errors: FF_DP_INIT_TIMEOUT)
+    tmo = {"timeout": datetime.timedelta(seconds=300)}                       # (hangs become errors: FF_DP_INIT_TIMEOUT)
     assert calls == [("nccl", {**tmo, "device_id": dev})]                    # world / rank come from the launcher's env
     assert os.environ["MASTER_ADDR"] == "127.0.0.1"
     # unset + the HSA runtime not started yet in this process: the documented value is filled in (it still takes effect);
