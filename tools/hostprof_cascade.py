@@ -33,7 +33,7 @@ def prefill():
         if ff.finish_merging and not ff.finish_pruning:
             if n_in not in k_of:
                 k_of[n_in] = k_full[:, :, :n_in].contiguous()
-            w = ffa.last_query_importance(q, k_of[n_in], num=c["num"], is_causal=True, framefusion=ff)
+            w = ffa.last_query_importance(q, k_of[n_in], num=c["num"], is_causal=True, framefusion=ff, defer=True)
         h, pe, _ = ff(h, pe, None, w)
         n += 1
     return n
