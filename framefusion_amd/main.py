@@ -147,6 +147,10 @@ class _Scratch:
         for s, o in pairs:
             if n >= room:
                 raise FrameFusionHipError("too many auxiliary tensors")
+            if type(s) is _Strided:       # (its strides were looked at a moment ago, by _token_dense, in this very call)
+                s, known = s.t, s.outer_bytes
+            else:
+                known = None
             if s.ndim == 2:         # [B, L] ids
                 row, outer = s.element_size(), s.shape[0]
                 outer_bytes = 0
@@ -154,18 +158,30 @@ class _Scratch:
                 last = s.shape[-1]
                 row = last * s.element_size()
                 outer = s.numel() // (L * last)
-                # (recomputed from the strides, never taken from an attribute a caller's tensor may carry from an earlier life)
-                outer_bytes = 0 if s.is_contiguous() else _outer_stride(s) * s.element_size()
+                # (from the strides of THIS call, never from an attribute a caller's tensor may carry from an earlier life)
+                outer_bytes = known if known is not None else (0 if s.is_contiguous() else _outer_stride(s) * s.element_size())
             pack(block, offset + size * n, s.data_ptr(), o.data_ptr(), row, outer, outer_bytes)
             n += 1
         return n
 
 
-def _token_dense(t: torch.Tensor) -> torch.Tensor:
-    """`t` itself when the merge kernel can read it in place (contiguous, or rows dense and the leading dims one uniform
-    stride apart: `_outer_stride`), else a contiguous copy."""
-    if t.is_contiguous() or _outer_stride(t) is not None:
+class _Strided:
+    """A [..., L, dh] tensor the merge kernel reads in place although it is not contiguous, with the byte stride between its outer
+    slices - what `_token_dense` found out, handed to `put_aux` so that the strides are looked at once per call."""
+    __slots__ = ("t", "outer_bytes")
+
+    def __init__(self, t, outer_bytes):
+        self.t, self.outer_bytes = t, outer_bytes
+
+
+def _token_dense(t: torch.Tensor):
+    """`t` itself when it is contiguous; `_Strided(t, stride)` when the merge kernel can still read it in place (rows dense and
+    the leading dims one uniform stride apart: `_outer_stride`); else a contiguous copy."""
+    if t.is_contiguous():
         return t
+    st = _outer_stride(t)
+    if st is not None:
+        return _Strided(t, st * t.element_size())
     return t.contiguous()
 
 
@@ -174,24 +190,26 @@ def _outer_stride(t: torch.Tensor):
     (stride 1 / dh on the last two axes) when those leading dims are ONE uniform stride apart - None otherwise.  True for
     contiguous tensors and for the [3, 1, L_out, dh] views a merge call returns for M-RoPE tables (three planes, L_cap rows
     apart), which therefore go into the next call without a copy."""
-    if t.ndim < 3 or t.stride(-1) != 1 or t.stride(-2) != t.shape[-1]:
+    shape, strides = t.shape, t.stride()
+    nd = len(shape)
+    if nd < 3 or strides[-1] != 1 or strides[-2] != shape[-1]:
         return None
     stride = None
     expect = None                       # stride the next-outer non-trivial dim must have
-    for k in range(t.ndim - 3, -1, -1):
-        if t.shape[k] == 1:
+    for k in range(nd - 3, -1, -1):
+        if shape[k] == 1:
             continue
         if stride is None:
-            stride = t.stride(k)
-            expect = stride * t.shape[k]
-        elif t.stride(k) != expect:
+            stride = strides[k]
+            expect = stride * shape[k]
+        elif strides[k] != expect:
             return None
         else:
-            expect *= t.shape[k]
+            expect *= shape[k]
     if stride is None:
-        return t.shape[-2] * t.shape[-1]
+        return shape[-2] * shape[-1]
     # a broadcast (stride 0) or overlapping leading dim has no plane to read in place: the caller copies
-    return stride if stride >= t.shape[-2] * t.shape[-1] else None
+    return stride if stride >= shape[-2] * shape[-1] else None
 
 
 def _fail(rc: int, what: str, err_bits: int = 0):
@@ -389,7 +407,7 @@ class FrameFusion(nn.Module):
                 if t.ndim not in (3, 4) or t.shape[-2] != L:
                     raise FrameFusionHipError(f"position embedding of shape {tuple(t.shape)} does not have "
                                               f"{L} tokens on its second-to-last axis")
-            a, b = _token_dense(a), _token_dense(b)
+            src_a, src_b = _token_dense(a), _token_dense(b)       # (tensors, or _Strided wrappers of a and b themselves)
             out_shape = shape[:-2] + (L_cap, shape[-1])
             if b.shape == shape and b.dtype == a.dtype:
                 both = torch.empty((2,) + out_shape, dtype=a.dtype, device=a.device)     # cos and sin: one allocation
@@ -403,7 +421,7 @@ class FrameFusion(nn.Module):
                 for x in (0, 1):
                     position_embeddings[x] = outs[x].narrow(ax, 0, L_out)
                 return position_embeddings
-            return [a, b], outs, rebuild
+            return [src_a, src_b], outs, rebuild
         if type(position_embeddings) == torch.Tensor:
             if position_embeddings.ndim != 2:
                 raise NotImplementedError("Only support 2D position embeddings")

@@ -245,7 +245,8 @@ def test_outer_stride_of_token_dense_views():
     assert _outer_stride(full) == 40 and _token_dense(full) is full
     view = full.narrow(2, 0, 6)                                  # what a merge call returns for an M-RoPE table
     assert not view.is_contiguous() and _outer_stride(view) == 40
-    assert _token_dense(view) is view and not hasattr(view, "_ff_outer_bytes")      # (no cached stride on caller tensors)
+    wrapped = _token_dense(view)            # read in place: the tensor itself + its outer stride in bytes, found in THIS call
+    assert wrapped.t is view and wrapped.outer_bytes == 40 * 4 and not hasattr(view, "_ff_outer_bytes")
     flat = torch.zeros(1, 10, 4).narrow(1, 0, 6)                 # [1, L_out, dh] of a [1, L_cap, dh] buffer: contiguous as it is
     assert flat.is_contiguous() and _outer_stride(flat) == 24
     two = torch.zeros(2, 3, 10, 4)                               # two leading dims, one uniform stride: collapsible
