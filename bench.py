@@ -67,6 +67,9 @@ def parse():
                          "run through the backend (RCCL) on a 1-GPU box")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip cpu_baseline and eager_gpu_baseline")
     ap.add_argument("--no-extra", action="store_true", help="skip extra.configs (C3 / C5 / 7B shape)")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not collect roofline.traffic live (two rocprofv3 --pmc passes of a short child run, ~25 s): take it from "
+                         "the committed profiles/rNN_pmc_* summaries instead (withheld when they are of another build)")
     ap.add_argument("--e2e", nargs="?", const="7b", default=None, choices=sorted(E2E_SHAPES) + ["all"],
                     help="also run BASELINE.json configs[1] (7b) / configs[4] (72b) end to end: a random-weight Qwen2 LLM of that "
                          "LLaVA-Video model's shape, 64 frames prefilled dense / with this build / with the torch port of the reference "
@@ -213,7 +216,15 @@ def main():
         achieved = alg[dominant] / (dense_us * 1e-6) / 1e9
         ms_per_step = t_max / args.steps * 1e3
         headline = (F, P, d) == (FRAMES, PATCHES, DIM)
-        traffic, traffic_source = profiled_traffic(dominant) if headline else (None, None)
+        traffic, traffic_source = (None, None)
+        if headline:
+            if world == 1 and not args.no_pmc:
+                traffic, traffic_source = live_traffic(dominant)
+            if traffic is None:
+                live_note = traffic_source
+                traffic, traffic_source = profiled_traffic(dominant)
+                if live_note and traffic_source is not None:
+                    traffic_source["live_attempt"] = live_note
         result = {
             "metric": BASELINE_METRIC,
             "value": tok_all / t_max,
@@ -427,6 +438,51 @@ def stage_times(ff, _lib, hidden, hidden_alt, ptype, cos, sin, P, L, d, info, de
     torch.cuda.synchronize()
     both_us = sum(a.elapsed_time(b) for a, b in pairs) / reps * 1e3
     return kernel_us, dominant, both_us - kernel_us[names[q_dom - 1]]
+
+
+def live_traffic(kernel):
+    """(bytes, source): HBM bytes per launch of `kernel` measured NOW, by two child runs of this script under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes: the TCC has four counter slots, FETCH_SIZE
+    takes three and WRITE_SIZE two - MI355X_MICROARCH.md "rocprofv3 PMC slots"), mean over the kernel's launches, corrected as
+    that guide prescribes: 2 x FETCH_SIZE (gfx950 tallies 64 B per 128-B request of a 16 B / lane streaming read) + WRITE_SIZE, both
+    reported in KiB.  (None, why) when rocprofv3 is not there, a pass fails or takes longer than two minutes."""
+    import csv, glob, shutil, signal, subprocess, tempfile
+    pat = {"merge_compact": "k_merge_compact<", "similarity": "k_pair_similarity<"}[kernel]
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, {"live": False, "why": "rocprofv3 not on PATH"}
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--no-extra", "--no-pmc"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    means, launches = {}, {}
+    work = tempfile.mkdtemp(prefix="ff_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(work, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc", "--"] + child
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = proc.wait(timeout=120)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)
+                proc.wait()
+                return None, {"live": False, "why": f"the {counter} pass did not finish within 120 s"}
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if rc != 0 or not files:
+                return None, {"live": False, "why": f"the {counter} pass failed (exit {rc}, {len(files)} counter files)"}
+            vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(files[0]))
+                    if pat in r["Kernel_Name"] and r["Counter_Name"] == counter]
+            if not vals:
+                return None, {"live": False, "why": f"no {counter} rows for {pat}"}
+            means[counter], launches[counter] = sum(vals) / len(vals), len(vals)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    total = 2.0 * means["FETCH_SIZE"] * 1024.0 + means["WRITE_SIZE"] * 1024.0
+    return total, {"live": True, "how": "two child runs of this script under rocprofv3 --kernel-trace --pmc <counter> (separate passes), mean "
+                                       "over the kernel's launches; bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB, gfx950 correction)",
+                   "child": " ".join(child[1:]), "fetch_kib_mean": means["FETCH_SIZE"], "write_kib_mean": means["WRITE_SIZE"],
+                   "launches": launches}
 
 
 def profiled_traffic(kernel):

@@ -135,8 +135,14 @@ def test_single_gpu_line_has_the_contract_fields():
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0.3 < rf["frac"] < 1.0 and rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"])
     # the traffic figure names where it comes from, and is withheld when the PMC passes are of another build
     ts = rf["traffic_source"]
-    assert ts is not None and ("stale" in ts or "error" in ts or ts["profiled_source_hash"] == ts["running_source_hash"])
-    assert (rf["traffic"] is None) == ("stale" in ts or "error" in ts)
+    # measured live (two rocprofv3 --pmc child passes) where rocprofv3 is installed; else from the committed summaries, withheld
+    # when those are of another build
+    assert ts is not None
+    if ts.get("live"):
+        assert rf["traffic"] > 0 and ts["launches"]["FETCH_SIZE"] > 20 and ts["launches"]["WRITE_SIZE"] > 20
+    else:
+        assert "stale" in ts or "error" in ts or ts["profiled_source_hash"] == ts["running_source_hash"]
+        assert (rf["traffic"] is None) == ("stale" in ts or "error" in ts)
     if rf["traffic"] is not None:
         assert 0.8 < rf["traffic"] / rf["algorithmic_bytes"] < 1.3
     cb = out["cpu_baseline"]

@@ -6,7 +6,7 @@
 tag=$1; out=${2:-gpurun_out/${tag}_profiles}
 mkdir -p "$out"; root=$(pwd)
 cd /tmp && export TMPDIR=/tmp && cd "$root"
-B="python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-extra"
+B="python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-extra --no-pmc"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/prof/pmc_fetch" -o pmc -- $B > /dev/null 2> "$out/fetch.err"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/prof/pmc_write" -o pmc -- $B > /dev/null 2> "$out/write.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof/trace" -o trace -- $B > /dev/null 2> "$out/trace.err"

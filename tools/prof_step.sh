@@ -6,7 +6,7 @@ mkdir -p "$out"
 root=$(pwd)
 cd /tmp && export TMPDIR=/tmp && cd "$root"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof" -o trace -- \
-    python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-extra "$@" > "$out/prof_bench.json" 2> "$out/prof.err"
+    python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-extra --no-pmc "$@" > "$out/prof_bench.json" 2> "$out/prof.err"
 trace=$(find "$out/prof" -name '*kernel_trace.csv' | head -1)
 stats=$(find "$out/prof" -name '*kernel_stats.csv' | head -1)
 python tools/timeline.py "$trace" > "$out/timeline.txt"
