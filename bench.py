@@ -13,7 +13,7 @@ merge + compaction - and one 256-byte result block, on one video sample resident
 each rank reduces its own independent sample (seed + rank): weak scaling, no data-path collective; rank
 0's workload description is broadcast and the per-rank records are all_gathered.  Rank 0 prints ONE JSON
 line.  `roofline` prices the dominant kernel (live hipEvent timing on the launch stream, algorithmic bytes
-from DESIGN.md); `cpu_baseline` times the CPU oracle (oracle/ff_oracle.py, a torch-CPU port of the reference
+from DESIGN.md, `traffic` from two rocprofv3 --pmc passes of a short child run); `cpu_baseline` times the CPU oracle (oracle/ff_oracle.py, a torch-CPU port of the reference
 path) on the same input; `eager_gpu_baseline` runs the same torch port on the MI355X (what the reference costs
 through PyTorch-ROCm eager: the denominator of the >= 5x target); `extra.configs` times BASELINE.json's
 other single-GPU configurations (C3, C5) and the real LLaVA-Video-7B shape.

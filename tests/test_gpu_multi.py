@@ -57,7 +57,7 @@ def test_one_rank_group_over_rccl():
     (dp.init(..., device_id=...) with HSA_ENABLE_IPC_MODE_LEGACY=0), and rank 0's config broadcast, the all_gather of the
     per-rank records and the all_reduce of time / units all execute inside RCCL on the MI355X before the line is printed.
     (Two ranks on one device are refused by RCCL itself: "Duplicate GPU detected".)"""
-    out = run_bench("--steps", "10", "--warmup", "3", "--force-dist", "--no-cpu-baseline", "--no-extra")
+    out = run_bench("--steps", "10", "--warmup", "3", "--force-dist", "--no-cpu-baseline", "--no-extra", "--no-pmc")
     assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and out["collective_backend"] == "nccl"
     assert [r["rank"] for r in out["per_rank"]] == [0] and out["per_rank"][0]["tokens_in"] == 64 * 576
     assert 0 < out["per_rank"][0]["tokens_out"] < 64 * 576 and out["value"] > 0
@@ -106,7 +106,7 @@ def test_eight_ranks_sharing_one_gpu_over_gloo():
 def test_two_samples_per_gpu_go_through_the_pair():
     """`--samples 2` on one GPU: the rank owns two samples per step and keeps both in flight (FrameFusionPair); the line says so
     and its value counts both."""
-    out = run_bench("--samples", "2", "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-extra")
+    out = run_bench("--samples", "2", "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-extra", "--no-pmc")
     cfg = out["config"]
     assert cfg["samples_per_gpu_per_step"] == 2 and cfg["samples_per_step"] == 2 and "FrameFusionPair" in cfg["workload"]
     one = cfg["tokens_in"] - cfg["tokens_out"]
