@@ -451,6 +451,8 @@ def live_traffic(kernel):
     exe = shutil.which("rocprofv3")
     if exe is None:
         return None, {"live": False, "why": "rocprofv3 not on PATH"}
+    if "rocprof" in os.environ.get("LD_PRELOAD", "") or os.environ.get("ROCP_TOOL_LIBRARIES") or os.environ.get("ROCPROFILER_REGISTER_FORCE_LOAD"):
+        return None, {"live": False, "why": "this run is itself being profiled: no nested rocprofv3"}
     child = [sys.executable, os.path.abspath(__file__), "--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--no-extra", "--no-pmc"]
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
