@@ -1,4 +1,4 @@
-"""GPU: FrameFusionPair / ff_ctx_merge_pair - two samples in flight from one host thread give, bit for bit, what two
+"""GPU: FrameFusionPair (FrameFusion.submit / collect, ff_ctx_merge_submit / _collect) - two samples in flight from one host thread give, bit for bit, what two
 independent instances give (the reference's form: one instance per sample, script/demo/llava_video_compare.py:217-223)."""
 import pytest
 import torch
