@@ -432,13 +432,17 @@ extern "C" int ff_ctx_merge_submit(ff_ctx_t* c, const ff_merge_call_t* a) {
     if (rc) return rc;
     if (a->mask && !a->mask_out) rc = FF_ERR_ARG;
     if (!rc) rc = ctx_finish_enqueue(c, a);
-    if (rc) { c->in_flight = 0; c->dirty = 1; c->order_len = 0; }
-    return rc;
+    if (rc) { c->in_flight = 0; c->dirty = 1; c->order_len = 0; return rc; }
+    c->in_flight = 4;                    // submitted: only ff_ctx_merge_collect may follow
+    return FF_OK;
 }
 
 extern "C" int ff_ctx_merge_collect(ff_ctx_t* c, const ff_merge_call_t* a, ff_merge_result_t* r) {
-    int rc = ctx_finish_check(c, a, r);
+    if (!a || !r) return FF_ERR_ARG;
+    int rc = ctx_check(c, a->L);
     if (rc) return rc;
+    if (c->in_flight != 4) return FF_ERR_STATE;
+    if (a->mask && !a->mask_out) return FF_ERR_ARG;
     return ctx_finish(c, a, r, true);
 }
 

@@ -388,7 +388,8 @@ typedef struct ff_ctx {
     int64_t order_len;     /* length of the sequence `order`/`inv` describe; 0 = none                   */
     int64_t dirty;         /* a call died half-way: workspace + stats are reset by the next call        */
     int64_t in_flight;     /* 0: no call; 1: begun (K1 enqueued); 2: planned (ff_ctx_merge_plan); 3: result
-                              known, merge kernel still to come (ff_ctx_merge_wait)                      */
+                              known, merge kernel still to come (ff_ctx_merge_wait); 4: submitted
+                              (ff_ctx_merge_submit: everything enqueued, ff_ctx_merge_collect pending)   */
     int64_t swaps;         /* number of order <-> order_next exchanges so far (owner mirrors its views) */
     int64_t last_L;        /* input length of the merge call that finished last and whose keep set is still in
                               the scratch (0: none) - what ff_ctx_gather_mask may be asked for (ABI v9)         */

@@ -92,7 +92,12 @@ static int full_mode(int F, int P, int d, int pre, int L, const std::vector<uint
     call.aux[0] = ff_aux_t{dpt, dpt_out, 8, 1};
     call.aux[1] = ff_aux_t{dtab[0], dtab_out[0], dh * 2, planes};
     call.aux[2] = ff_aux_t{dtab[1], dtab_out[1], dh * 2, planes};
-    FF(ff_ctx_merge(&ctx, &call, &res[0]));
+    // the first call as submit + collect (ABI v9: everything enqueued, the wait split off - what a host that keeps two samples in
+    // flight calls; here with one sample: a collect before any submit and a second submit in between must be refused)
+    if (ff_ctx_merge_collect(&ctx, &call, &res[0]) != FF_ERR_STATE) { fprintf(stderr, "collect without submit was not refused\n"); return 6; }
+    FF(ff_ctx_merge_submit(&ctx, &call));
+    if (ff_ctx_merge_plan(&ctx, &call) != FF_ERR_STATE) { fprintf(stderr, "plan on a submitted call was not refused\n"); return 6; }
+    FF(ff_ctx_merge_collect(&ctx, &call, &res[0]));
     const int64_t l1 = res[0].l_out;
     std::vector<uint8_t> keep1(L);
     CK(hipStreamSynchronize(st));
