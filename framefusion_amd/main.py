@@ -488,6 +488,10 @@ class FrameFusion(nn.Module):
         if self.compact_outputs:                 # exactly sized outputs: K1 + plan now, outputs and merge kernel at collect()
             rc = lib.ff_ctx_merge_begin(sc.ctx_ptr, sc.call_ptr) or lib.ff_ctx_merge_plan(sc.ctx_ptr, sc.call_ptr)
             st["exact"] = True
+            guess = st.get("L_guess")
+            if not rc and guess is not None and 0 < guess < st["L"]:     # the top-k branch's outputs, allocated under K1
+                self._merge_outputs(st, guess)
+                st["guessed"] = True
         else:
             self._merge_outputs(st)
             rc = lib.ff_ctx_merge_submit(sc.ctx_ptr, sc.call_ptr)
@@ -519,7 +523,8 @@ class FrameFusion(nn.Module):
         # branch) the guess costs one allocation that was made under the similarity pass.
         guess = st.get("L_guess")
         if guess is not None and 0 < guess < st["L"]:
-            self._merge_outputs(st, guess)
+            if not st.get("guessed"):                                # (submit() has done it already)
+                self._merge_outputs(st, guess)
         else:
             guess = None
         rc = lib.ff_ctx_merge_wait(sc.ctx_ptr, sc.call_ptr, sc.res_ptr)
