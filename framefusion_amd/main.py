@@ -265,6 +265,7 @@ class FrameFusion(nn.Module):
         state["_host_ints"] = {}
         state["last_call"] = None
         state["_ticket"] = None
+        state["_bad_hints"] = set(self.__dict__.get("_bad_hints", ()))
         return state
 
     def __deepcopy__(self, memo):
@@ -324,6 +325,8 @@ class FrameFusion(nn.Module):
                 return None
         P, pre, n = whole(patch_num), whole(start), whole(length)
         if P is None or pre is None or n is None or P < 1 or pre < 0 or n < P or n % P:
+            return None
+        if (P, pre, n // P) in self.__dict__.get("_bad_hints", ()):      # (found wrong on the device in an earlier prefill)
             return None
         return pre, n // P
 
@@ -631,7 +634,12 @@ class FrameFusion(nn.Module):
         nv, ftn, count, branch, k, L_out, err, unhinted, wait_ns = _lib.MERGE_RESULT.unpack_from(sc.res)
         if unhinted:
             # patch_type is not the frame-major layout the prepare() scalars suggested (e.g. text between
-            # the frames): the library repeated the call through K0; stop hinting for this prefill
+            # the frames): the library repeated the call through K0; stop hinting for this prefill - and for
+            # every later prefill whose scalars describe the same (wrong) layout: a packer that puts separators between its
+            # frames does so for every prompt, and each wrong hint costs a whole wasted call
+            bad = self.__dict__.get("_layout_hint")
+            if bad is not None:
+                self.__dict__.setdefault("_bad_hints", set()).add((int(self.patch_num),) + tuple(bad))
             self._layout_hint = None
         if rc:
             _fail(rc, "merge", err)
@@ -652,7 +660,7 @@ class FrameFusion(nn.Module):
             # the device and wrote nothing - the reduced sequence is the input itself, and the order
             # in the scratch still describes the (unchanged) patch_type
             self.last_call = dict(kind="merge", L_in=L, L_out=L, nv=nv, ftn=ftn, count=count, branch=branch,
-                                  k=k, scratch=sc, dtype=dtype, order=sc.order, wait_ns=wait_ns)
+                                  k=k, scratch=sc, dtype=dtype, order=sc.order, wait_ns=wait_ns, unhinted=bool(unhinted))
             sc.order_gen = self._ptype_gen
             if residual is not None:          # nothing folded, but the caller is owed the sum
                 return residual + hidden_states, position_embeddings, attention_mask
@@ -661,7 +669,7 @@ class FrameFusion(nn.Module):
         # order maintenance: the merge kernel also wrote the by-patch order of the compacted sequence
         # (now the context's current one), so the next merge call of this prefill skips K0
         self.last_call = dict(kind="merge", L_in=L, L_out=L_out, nv=nv, ftn=ftn, count=count, branch=branch,
-                              k=k, scratch=sc, dtype=dtype, order=sc.order_next, wait_ns=wait_ns)
+                              k=k, scratch=sc, dtype=dtype, order=sc.order_next, wait_ns=wait_ns, unhinted=bool(unhinted))
         mask_cap, L_cap = st["mask_cap"], st["L_cap"]
         if mask_cap is not None:
             attention_mask = mask_cap[:, :, :L_out, :L_out]

@@ -786,14 +786,21 @@ def test_layout_hint_mismatch_falls_back_to_k0():
         assert f.last_call["nv"] == int(stats[_lib.STAT_NV]) and f.last_call["ftn"] == int(stats[_lib.STAT_FTN]), name
         sc = f.last_call["scratch"]
         assert int(sc.stats[_lib.STAT_ERROR]) == 0, name           # published and cleared
-        # the instance keeps working: a second prefill with a correct row is hinted again
+        assert f.last_call["unhinted"], name                       # (the library repeated the call through K0)
+        # the instance keeps working - and has learnt: scalars that described a wrong layout once are not hinted again (a packer
+        # that puts separators between its frames does so for every prompt; each wrong hint costs a whole wasted call, a
+        # missing one only K0's closed form), other scalars are
         f.prepare(dev(pt), P, 4, 4 + F * P - 1, F * P, L)
-        assert f._layout_hint == (4, F)
+        assert f._layout_hint is None
         hg2, pg2, _ = f(dev(h), dev(torch.arange(L)[None]), None)
+        assert not f.last_call["unhinted"]
         o2 = orc.OracleFrameFusion(0.3, 0.6, 0.1)
         o2.prepare(pt.clone(), P, 4, 4 + F * P - 1, F * P, L)
         ho2, po2, _ = o2.forward(h, torch.arange(L)[None], None)
         assert torch.equal(pg2.cpu(), po2) and same_bits(hg2.cpu(), ho2), name
+        h3, pt3 = video_tokens(F + 1, P, d, p_change=0.4, sigma=0.3, seed=8, pre=4, post=6, grid=0.125)
+        f.prepare(dev(pt3), P, 4, 4 + (F + 1) * P - 1, (F + 1) * P, h3.shape[1])
+        assert f._layout_hint == (4, F + 1), name
 
 
 def test_layout_hint_from_the_scalars_the_packers_pass():
