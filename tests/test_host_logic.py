@@ -265,3 +265,19 @@ def test_outer_stride_of_token_dense_views():
     assert dense is not exp and dense.is_contiguous() and torch.equal(dense, exp)
     lap = torch.zeros(100).as_strided((3, 1, 10, 4), (20, 40, 4, 1))          # overlapping planes: copied as well
     assert _outer_stride(lap) is None and _token_dense(lap).is_contiguous()
+
+
+def test_bench_charges_every_call_kind_its_compulsory_bytes():
+    """bench.call_bytes: what extra.configs[*].hbm_frac divides by.  A prune moves only the rows it keeps (rounds 1-4 charged it
+    S + L_out rows, which put the 72B prune gather above the 8 TB/s peak); an identity merge writes nothing."""
+    import bench
+    d, elt, dh = 8192, 2, 128
+    row, pe = d * elt, 2 * dh * elt
+    S, L_out = 35072, 10205
+    prune = bench.call_bytes("prune", S, L_out, S, d, elt, dh, kv_heads=8)
+    assert prune == 8 * S * dh * elt + 2 * L_out * (row + pe) + 5 * S
+    assert prune < bench.merge_bytes(S, L_out, d, elt, dh)                       # the old charge
+    assert prune / 63.3e-6 < 8.0e12                                              # the measured 63.3 us stay below the peak
+    assert bench.call_bytes("merge", 6404, 6404, 6377, 3584, elt, dh, pe_outer=3) == 6377 * 3584 * elt       # identity: K1's read only
+    L, Lo = 36864, 11060
+    assert bench.call_bytes("merge", L, Lo, L, 4096, elt, dh) == bench.merge_bytes(L, Lo, 4096, elt, dh) == 417513888
