@@ -457,8 +457,10 @@ int ff_ctx_merge(ff_ctx_t* ctx, const ff_merge_call_t* call, ff_merge_result_t* 
 int ff_ctx_merge_submit(ff_ctx_t* ctx, const ff_merge_call_t* call);
 int ff_ctx_merge_collect(ff_ctx_t* ctx, const ff_merge_call_t* call, ff_merge_result_t* result);
 
-/* The merge call for EXACTLY SIZED outputs (ABI v9): the host learns l_out before the merge kernel is enqueued and sizes
- * hidden_out / aux[].dst / mask_out to it (L_cap = l_out) - no input-length buffers, no copy out of them.
+/* The merge call for EXACTLY SIZED outputs (ABI v9) - what the reference returns: hidden_states[token_mask, :], the position
+ * embeddings and the attention mask gathered with the same mask (framefusion/main.py:132-138, 161-178).  The host learns l_out
+ * before the merge kernel is enqueued and sizes hidden_out / aux[].dst / mask_out to it (L_cap = l_out) - no input-length
+ * buffers, no copy out of them.
  *   ff_ctx_merge_begin  K1 (as above)
  *   ff_ctx_merge_plan   the plan kernel, enqueued behind it; no output field of `call` is looked at; nothing is waited for
  *   ff_ctx_merge_wait   waits for the result block (a wrong layout hint is repeated through K0 here): result->l_out
@@ -466,7 +468,9 @@ int ff_ctx_merge_collect(ff_ctx_t* ctx, const ff_merge_call_t* call, ff_merge_re
  *                       When l_out == L nothing is written: any non-NULL hidden_out will do, n_aux = 0 (the launch still
  *                       clears the select tables).
  * Between plan and merge kernel the GPU idles for the host's reaction time (~10-20 us); ff_ctx_merge_finish / _submit avoid that
- * by enqueueing the merge kernel blind, into buffers of L rows.  What FrameFusion.forward does by default (compact_outputs). */
+ * by enqueueing the merge kernel blind, into buffers of L rows.  What FrameFusion.forward does by default (compact_outputs),
+ * with the outputs of the top-k branch's length (L - int(sub * ftn), main.py:122: host arithmetic) allocated under K1, so that
+ * the gap shrinks to the crossing itself when the plan decides that way. */
 int ff_ctx_merge_plan(ff_ctx_t* ctx, const ff_merge_call_t* call);
 int ff_ctx_merge_wait(ff_ctx_t* ctx, const ff_merge_call_t* call, ff_merge_result_t* result);
 int ff_ctx_merge_apply(ff_ctx_t* ctx, const ff_merge_call_t* call, const ff_merge_result_t* result);
