@@ -5,7 +5,9 @@
 //   host F P d input.bin full     two merge calls through the call context (ff_ctx_merge): the first with an
 //                                 `addend` (the residual add formed in the passes), M-RoPE style [3, L, 128] cos / sin
 //                                 aux tensors and the frame-major layout hint; the second on the compacted output with
-//                                 the maintained order (order_valid = 1)
+//                                 the maintained order (order_valid = 1), driven as plan / wait / apply with exactly sized
+//                                 outputs; then the first call once more on TWO contexts and two streams at once
+//                                 (submit, submit, collect, collect)
 //   hipcc --offload-arch=gfx950 -O2 -I include tests/abi_host/host.cpp -L framefusion_amd -lframefusion_hip
 //         -Wl,-rpath,$PWD/framefusion_amd -o tests/abi_host/host
 #include <hip/hip_runtime.h>
@@ -144,6 +146,45 @@ static int full_mode(int F, int P, int d, int pre, int L, const std::vector<uint
     }
     printf("KEEP1 "); for (int i = 0; i < L; ++i) putchar(keep1[i] ? '1' : '0'); putchar('\n');
     printf("KEEP2 "); for (int i = 0; i < l1; ++i) putchar(keep2[i] ? '1' : '0'); putchar('\n');
+    // Two samples in flight from this one host thread (ABI v9): the first call again, on context A and on a second context B
+    // with its own scratch and its own stream - submit(A), submit(B), collect(A), collect(B).  Same input, so both must give
+    // the first call's output again.
+    {
+        void *border, *border_next, *binv, *binv_next, *bsim, *bmember, *bdst, *bkeep, *bstats, *bws, *bout, *bpt_out, *btab_out[2];
+        int64_t* bstats_host;
+        CK(hipMalloc(&border, L * 4)); CK(hipMalloc(&border_next, L * 4)); CK(hipMalloc(&binv, L * 4)); CK(hipMalloc(&binv_next, L * 4));
+        CK(hipMalloc(&bsim, L * 4)); CK(hipMalloc(&bmember, L)); CK(hipMalloc(&bdst, L * 4)); CK(hipMalloc(&bkeep, L));
+        CK(hipMalloc(&bstats, FF_STAT_WORDS * 8)); CK(hipMalloc(&bws, wsb)); CK(hipMalloc(&bout, hb)); CK(hipMalloc(&bpt_out, L * 8));
+        for (int w = 0; w < 2; ++w) CK(hipMalloc(&btab_out[w], tb));
+        CK(hipHostMalloc((void**)&bstats_host, FF_STAT_WORDS * 8, hipHostMallocDefault));
+        memset(bstats_host, 0, FF_STAT_WORDS * 8);
+        CK(hipMemset(bstats, 0, FF_STAT_WORDS * 8)); CK(hipMemset(bws, 0, wsb));
+        hipStream_t st_b; CK(hipStreamCreateWithFlags(&st_b, hipStreamNonBlocking));
+        ff_ctx_t ctx_b; memset(&ctx_b, 0, sizeof ctx_b);
+        ctx_b.cap = L; ctx_b.order = (int32_t*)border; ctx_b.order_next = (int32_t*)border_next; ctx_b.inv = (int32_t*)binv;
+        ctx_b.inv_next = (int32_t*)binv_next; ctx_b.sim = bsim; ctx_b.member = (uint8_t*)bmember; ctx_b.dst = (int32_t*)bdst;
+        ctx_b.keep = (uint8_t*)bkeep; ctx_b.stats = (int64_t*)bstats; ctx_b.stats_host = bstats_host; ctx_b.ws = bws; ctx_b.ws_bytes = wsb;
+        ff_merge_call_t call_b = call;
+        call_b.hidden_out = bout; call_b.stream = st_b;
+        call_b.aux[0] = ff_aux_t{dpt, bpt_out, 8, 1};
+        call_b.aux[1] = ff_aux_t{dtab[0], btab_out[0], dh * 2, planes};
+        call_b.aux[2] = ff_aux_t{dtab[1], btab_out[1], dh * 2, planes};
+        ff_merge_result_t ra, rb;
+        FF(ff_ctx_reset(&ctx, st));
+        FF(ff_ctx_merge_submit(&ctx, &call));
+        FF(ff_ctx_merge_submit(&ctx_b, &call_b));
+        FF(ff_ctx_merge_collect(&ctx, &call, &ra));
+        FF(ff_ctx_merge_collect(&ctx_b, &call_b, &rb));
+        CK(hipStreamSynchronize(st)); CK(hipStreamSynchronize(st_b));
+        std::vector<uint16_t> oa((size_t)l1 * d), ob((size_t)l1 * d);
+        int ok = ra.l_out == l1 && rb.l_out == l1;
+        if (ok) {
+            CK(hipMemcpy(oa.data(), dout, oa.size() * 2, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(ob.data(), bout, ob.size() * 2, hipMemcpyDeviceToHost));
+            ok = fnv_words16(oa) == fnv_words16(o1) && fnv_words16(ob) == fnv_words16(o1);
+        }
+        printf("PAIR_OK %d\n", ok);
+    }
     FILE* f = fopen(path, "wb");
     if (!f) return 5;
     fwrite(h.data(), 2, h.size(), f);

@@ -104,6 +104,7 @@ def test_cpp_host_full_size_context_calls(tmp_path, F, P, d):
     pre, post = 5, 7
     L = pre + F * P + post
     assert out["L"] == L and len(calls) == 2 and calls[0]["UNHINTED"] == 0 and out["ORDER_REUSED"] == 1
+    assert out["PAIR_OK"] == "1"            # two contexts in flight from the one host thread gave the first call's output twice
     h = torch.from_numpy(np.fromfile(blob, dtype=np.int16).reshape(1, L, d).copy()).view(torch.bfloat16)
     pt = torch.full((1, L), -1, dtype=torch.int64)
     pt[0, pre:pre + F * P] = torch.arange(F * P) % P
