@@ -99,11 +99,15 @@ def test_pair_matches_two_independent_instances(dtype, container, shape_a, shape
     sb = sample(*shape_b[:4], seed=12, pre=shape_b[4], post=shape_b[5], dtype=dtype, container=container)
     want_a = run_independent(ffa.FrameFusion(0.3, 0.6, 0.1), sa, 4)
     want_b = run_independent(ffa.FrameFusion(0.3, 0.6, 0.1), sb, 4)
-    pair = FrameFusionPair(ffa.FrameFusion(0.3, 0.6, 0.1), ffa.FrameFusion(0.3, 0.6, 0.1))
-    for _ in range(2):                          # a second prefill through the same instances (scratch reuse, order maintenance)
-        got_a, got_b = run_paired(pair, sa, sb, 4)
-        equal_logs(got_a, want_a)
-        equal_logs(got_b, want_b)
+    # both output forms: exactly sized (default: K1 + plan at submit, merge kernel at collect) and views of input-length buffers
+    # (everything enqueued at submit: ff_ctx_merge_submit / _collect)
+    for views in (False, True):
+        kw = dict(compact_outputs=False) if views else {}
+        pair = FrameFusionPair(ffa.FrameFusion(0.3, 0.6, 0.1, **kw), ffa.FrameFusion(0.3, 0.6, 0.1, **kw))
+        for _ in range(2):                      # a second prefill through the same instances (scratch reuse, order maintenance)
+            got_a, got_b = run_paired(pair, sa, sb, 4)
+            equal_logs(got_a, want_a)
+            equal_logs(got_b, want_b)
     torch.cuda.synchronize()
 
 
