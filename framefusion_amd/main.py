@@ -342,6 +342,8 @@ class FrameFusion(nn.Module):
             # tensors (several replicas on several GPUs in one process, as in the reference's demo)
             with torch.cuda.device(dev):
                 return self.forward(hidden_states, position_embeddings, attention_mask, self_attn_weights, residual)
+        if self.__dict__.get("_ticket") is not None:
+            raise FrameFusionHipError("forward(): a submitted call of this instance has not been collected")
         bsz, q_len, hidden_size = hidden_states.size()
         prune_now = q_len > 1 and self.finish_merging == True and self.finish_pruning == False
         merge_now = q_len > 1 and (not self.finish_merging)

@@ -173,6 +173,8 @@ def test_pair_refuses_misuse_and_survives_a_bad_sample():
     with pytest.raises(ffa.FrameFusionHipError):
         pair.a.submit(sa["h"], list(sa["pos"]), None)                     # ... and so has its instance
     with pytest.raises(ffa.FrameFusionHipError):
+        pair.a(sa["h"], list(sa["pos"]), None)                            # (a plain call in between is refused as well)
+    with pytest.raises(ffa.FrameFusionHipError):
         pair.collect(1)                                                   # nothing in flight for sample 1
     bad = sa["h"][:, :-1]                                                 # patch_type does not cover this sequence
     with pytest.raises(ffa.FrameFusionHipError):
