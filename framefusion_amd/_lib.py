@@ -26,10 +26,11 @@ DTYPE_CODE = {torch.float32: FF_F32, torch.bfloat16: FF_BF16, torch.float16: FF_
 STAT_T_ORDER, STAT_T_PLAN = 16, 24
 FOLD_DROP, FOLD_SEQUENTIAL, FOLD_MEAN = 0, 1, 2
 STAT_ERROR = 11
-ERR_BIT_BARRIER, ERR_BIT_LAYOUT = 1, 2
+ERR_BIT_BARRIER, ERR_BIT_LAYOUT, ERR_BIT_RESIDENT = 1, 2, 4
+STAT_APPLIED = 12
 STAT_WORDS = 32
 MAX_AUX = 4
-ABI_VERSION = 9
+ABI_VERSION = 10
 ERR_DEVICE, ERR_STATE = -5, -6
 
 
@@ -45,7 +46,8 @@ class FFCtx(C.Structure):
                 ("keep", C.c_void_p), ("stats", C.c_void_p), ("stats_host", C.c_void_p), ("ws", C.c_void_p),
                 ("ws_bytes", C.c_size_t),
                 ("seq", C.c_int64), ("order_len", C.c_int64), ("dirty", C.c_int64), ("in_flight", C.c_int64),
-                ("swaps", C.c_int64), ("last_L", C.c_int64), ("last_l_out", C.c_int64)]
+                ("swaps", C.c_int64), ("last_L", C.c_int64), ("last_l_out", C.c_int64),
+                ("cur_nv", C.c_int64), ("cur_ftn", C.c_int64), ("res_active", C.c_int64), ("res_off", C.c_int64)]
 
 
 class FFMergeCall(C.Structure):
@@ -70,10 +72,11 @@ MASK_TRIPLE = struct.Struct("=2Qq")
 
 class FFMergeResult(C.Structure):
     _fields_ = [("nv", C.c_int64), ("ftn", C.c_int64), ("count", C.c_int64), ("branch", C.c_int64), ("k", C.c_int64),
-                ("l_out", C.c_int64), ("error", C.c_int64), ("unhinted", C.c_int64), ("wait_ns", C.c_int64)]
+                ("l_out", C.c_int64), ("error", C.c_int64), ("unhinted", C.c_int64), ("wait_ns", C.c_int64),
+                ("applied", C.c_int64)]
 
 
-MERGE_RESULT = struct.Struct("=9q")
+MERGE_RESULT = struct.Struct("=10q")
 
 
 class FFPruneCall(C.Structure):
@@ -151,6 +154,7 @@ PROTOTYPES = {
     "ff_ctx_merge_apply": (_i32, [_vp, _vp, _vp]),
     "ff_ctx_merge_submit": (_i32, [_vp, _vp]),
     "ff_ctx_merge_collect": (_i32, [_vp, _vp, _vp]),
+    "ff_ctx_merge_one_launch": (_i32, [_vp, _vp]),
     "ff_ctx_prune": (_i32, [_vp, _vp]),
     "ff_ctx_prune_from_qk": (_i32, [_vp, _vp, _vp]),
     "ff_ctx_gather_mask": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp]),

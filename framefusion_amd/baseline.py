@@ -150,7 +150,7 @@ class FixedSparsityMerging:
         _PACK_I64.pack_into(call, _lib.MERGE_CALL_AUX_OFFSET - 8, n_aux)
         _lib.MASK_TRIPLE.pack_into(call, _lib.MERGE_CALL_MASK_OFFSET, 0, 0, 0)
         rc = lib.ff_ctx_merge_finish(sc.ctx_ptr, sc.call_ptr, sc.res_ptr)
-        nv, _ftn, _count, _branch, k_used, L_out, err, _unhinted, _wait = _lib.MERGE_RESULT.unpack_from(sc.res)
+        nv, _ftn, _count, _branch, k_used, L_out, err, _unhinted, _wait, _applied = _lib.MERGE_RESULT.unpack_from(sc.res)
         if rc:
             _fail(rc, "merge", err)
         sc.sync_views()

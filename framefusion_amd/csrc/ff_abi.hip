@@ -2,6 +2,7 @@
 // K0 -> K1 -> K2+K3 -> K4 from a single host call (one FrameFusion.forward merge call,
 // framefusion/main.py:104-138).
 #include "ff_common.h"
+#include "ff_resident.h"
 #include "ff_source_hash.h"
 
 namespace ff {
@@ -169,6 +170,7 @@ extern "C" int ff_prune_step(const void* hidden, const void* addend, void* hidde
     if (dtype != FF_F32 && dtype != FF_BF16 && dtype != FF_F16) return FF_ERR_ARG;
     if (w_dtype != FF_F32 && w_dtype != FF_BF16 && w_dtype != FF_F16) return FF_ERR_ARG;
     if (S >= (1ll << 29)) return FF_ERR_UNSUPPORTED;
+    if (L_cap < S - n_img + (k <= n_img ? k : n_img)) return FF_ERR_ARG;       // (the gather writes that many rows)
     if (ws_bytes < ff_workspace_bytes(S, 1)) return FF_ERR_WORKSPACE;
     if (((uintptr_t)attn_w & 15) || ((uintptr_t)importance & 15) || ((uintptr_t)member & 7) || ((uintptr_t)dst & 15) ||
         ((uintptr_t)keep & 15) || ((uintptr_t)ws & 15))
@@ -235,6 +237,7 @@ static int ctx_clean(ff_ctx_t* c, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     c->dirty = 0;
     c->order_len = 0;          // stats[NV] / stats[FTN] went with the reset: K0 (or the hinted K1) rebuilds them
+    c->cur_nv = c->cur_ftn = 0;
     c->last_L = 0;
     return FF_OK;
 }
@@ -242,7 +245,9 @@ static int ctx_clean(ff_ctx_t* c, hipStream_t st) {
 extern "C" int ff_ctx_reset(ff_ctx_t* c, ff_stream_t stream) {
     if (!c) return FF_ERR_ARG;
     c->order_len = 0;
+    c->cur_nv = c->cur_ftn = 0;
     c->in_flight = 0;
+    c->res_active = 0;
     c->last_L = 0;
     return ctx_clean(c, (hipStream_t)stream);
 }
@@ -282,6 +287,10 @@ extern "C" int ff_ctx_merge_begin(ff_ctx_t* c, const ff_merge_call_t* a) {
     int rc = ctx_check(c, a->L);
     if (rc) return rc;
     if (a->L == 0) return FF_ERR_ARG;
+    // a planned / waited-for / submitted call must be finished (or the context reset) first: its result block would never be
+    // matched and its order swap lost.  A call that was only begun may be begun again (the workspace is reset: ctx_begin).
+    if (c->in_flight >= 2) return FF_ERR_STATE;
+    if (c->res_off > 0) c->res_off -= 1;
     return ctx_begin(c, a, true);
 }
 
@@ -335,7 +344,7 @@ static int ctx_finish_enqueue(ff_ctx_t* c, const ff_merge_call_t* a, int phase =
     return rc;
 }
 
-// everything of a finish that follows the argument checks; `enqueued`: plan + K4 of the first attempt are already on the stream
+// everything of a finish that follows the argument checks; `enqueued`: the kernels of the first attempt are already on the stream
 static int ctx_after_result(ff_ctx_t* c, const ff_merge_call_t* a, const ff_merge_result_t* r);
 static int ctx_finish(ff_ctx_t* c, const ff_merge_call_t* a, ff_merge_result_t* r, bool enqueued, int phase = 3) {
     int rc;
@@ -343,6 +352,9 @@ static int ctx_finish(ff_ctx_t* c, const ff_merge_call_t* a, ff_merge_result_t* 
     hipStream_t st = (hipStream_t)a->stream;
     r->unhinted = 0;
     r->wait_ns = 0;
+    r->applied = 0;
+    bool resident = c->res_active != 0;            // the first attempt is the one-launch kernel
+    c->res_active = 0;
     for (int attempt = 0;; ++attempt) {
         if (!(enqueued && attempt == 0)) {
             rc = ctx_finish_enqueue(c, a, phase);
@@ -355,14 +367,21 @@ static int ctx_finish(ff_ctx_t* c, const ff_merge_call_t* a, ff_merge_result_t* 
         const int64_t* h = c->stats_host;
         const int64_t err = h[FF_STAT_ERROR];
         r->error = err;
-        if ((err & FF_ERR_BIT_LAYOUT) && !(err & ~(int64_t)FF_ERR_BIT_LAYOUT) && attempt == 0) {
-            // patch_type is not the frame-major layout the hint described: everything this call enqueued is
-            // void - reset the workspace and repeat it through K0
+        const bool layout = (err & FF_ERR_BIT_LAYOUT) && !(err & ~(int64_t)(FF_ERR_BIT_LAYOUT | FF_ERR_BIT_RESIDENT));
+        const bool gave_up = resident && (err & FF_ERR_BIT_RESIDENT) && !(err & ~(int64_t)FF_ERR_BIT_RESIDENT);
+        if ((layout || gave_up) && attempt == 0) {
+            // layout: patch_type is not the frame-major layout the hint described - everything this call enqueued is void, repeat it
+            // through K0.  gave_up: the one-launch kernel left at its barrier (or found another sequence than the host described);
+            // its tables and barrier words are in no defined state.  Either way: reset the workspace, repeat through the three
+            // launches - blind into the caller's buffers when they hold L rows, else the plan only (ff_ctx_merge_apply follows)
+            if (gave_up) c->res_off = 32;
             c->dirty = 1;
-            rc = ctx_begin(c, a, false);
+            rc = ctx_begin(c, a, !layout);
             c->in_flight = 0;
             if (rc) { c->dirty = 1; c->order_len = 0; return rc; }
-            r->unhinted = 1;
+            if (layout) r->unhinted = 1;
+            if (resident) phase = (phase != 1 && a->hidden_out && a->L_cap >= a->L) ? 3 : 1;
+            resident = false;
             continue;
         }
         if (err) {
@@ -375,12 +394,17 @@ static int ctx_finish(ff_ctx_t* c, const ff_merge_call_t* a, ff_merge_result_t* 
         r->branch = h[FF_STAT_BRANCH];
         r->k = h[FF_STAT_K];
         r->l_out = h[FF_STAT_LOUT];
+        if (resident) {
+            if (h[FF_STAT_APPLIED]) c->dirty = 0;       // (it has cleared the select tables itself)
+            else phase = 1;                              // the plan only: the merge kernel is still to come
+        }
         break;
     }
     if (phase == 1) {                      // the merge kernel is still to come (ff_ctx_merge_apply)
         c->in_flight = 3;
         return FF_OK;
     }
+    r->applied = 1;
     return ctx_after_result(c, a, r);
 }
 
@@ -400,8 +424,12 @@ static int ctx_after_result(ff_ctx_t* c, const ff_merge_call_t* a, const ff_merg
         t = c->inv; c->inv = c->inv_next; c->inv_next = t;
         c->swaps += 1;
         c->order_len = r->l_out;
+        c->cur_nv = r->nv - (a->L - r->l_out);          // (what the merge kernel leaves in stats[NV] / stats[FTN])
+        c->cur_ftn = r->ftn - (a->L - r->l_out);
     } else {
         c->order_len = a->L;       // nothing folded: the order describes the unchanged sequence
+        c->cur_nv = r->nv;
+        c->cur_ftn = r->ftn;
     }
     c->last_L = a->L;              // (what ff_ctx_gather_mask may be asked for)
     c->last_l_out = r->l_out;
@@ -423,17 +451,76 @@ extern "C" int ff_ctx_merge_finish(ff_ctx_t* c, const ff_merge_call_t* a, ff_mer
     return ctx_finish(c, a, r, false);
 }
 
-// A merge call in two halves that do NOT wait in between: submit = begin + plan + K4 enqueued (outputs allocated up front),
+// Is this call one for the one-launch kernel (ff_resident.hip)?  The host must know the by-patch order's length: from the layout
+// hint, or from the previous call of the prefill.
+static bool ctx_resident(const ff_ctx_t* c, const ff_merge_call_t* a, int64_t* nv, int64_t* ftn, bool* hinted) {
+    if (c->res_off > 0 || a->L < 1 || a->d < 1) return false;
+    const bool ov = a->order_valid && c->order_len == a->L && c->cur_nv > 0 && !c->dirty;
+    const bool hint = !ov && a->hint_frames > 0 && a->hint_pre >= 0 && a->patch_num >= 1 &&
+                      a->hint_pre + a->hint_frames * a->patch_num <= a->L;
+    if (!ov && !hint) return false;
+    *nv = ov ? c->cur_nv : a->hint_frames * a->patch_num;
+    *ftn = ov ? c->cur_ftn : *nv;
+    *hinted = hint;
+    if (a->fold != FF_FOLD_SEQUENTIAL || a->n_aux < 0 || a->n_aux > FF_MAX_AUX) return false;
+    if (((uintptr_t)a->hidden & 15) || ((uintptr_t)a->hidden_out & 15) || !a->hidden || !a->patch_type) return false;
+    return ff::merge_resident_fits((int)a->dtype, a->L, a->d, *nv, a->addend != nullptr, (int)a->fold);
+}
+
+extern "C" int ff_ctx_merge_one_launch(const ff_ctx_t* c, const ff_merge_call_t* a) {
+    if (!a || ctx_check(c, a->L) || c->in_flight >= 2) return 0;
+    int64_t nv, ftn;
+    bool hinted;
+    ff_ctx_t probe = *c;
+    if (probe.res_off > 0) probe.res_off -= 1;          // (what ff_ctx_merge_submit will see)
+    return ctx_resident(&probe, a, &nv, &ftn, &hinted) ? 1 : 0;
+}
+
+// A merge call in two halves that do NOT wait in between: submit = everything enqueued (outputs allocated up front),
 // collect = the wait for the result block + the context's bookkeeping.  A host thread that submits sample B (on another
 // stream) before it collects sample A keeps two samples in flight: A's plan bubble and kernel ramps sit under B's streaming
 // pass (what two replicas on two threads achieve in the reference's demo, llava_video_compare.py:217-223).
+// When the call fits on the chip (ctx_resident) "everything" is ONE kernel.
 extern "C" int ff_ctx_merge_submit(ff_ctx_t* c, const ff_merge_call_t* a) {
-    int rc = ff_ctx_merge_begin(c, a);
+    if (!a) return FF_ERR_ARG;
+    int rc = ctx_check(c, a->L);
     if (rc) return rc;
-    if (a->mask && !a->mask_out) rc = FF_ERR_ARG;
-    if (!rc) rc = ctx_finish_enqueue(c, a);
-    if (rc) { c->in_flight = 0; c->dirty = 1; c->order_len = 0; return rc; }
-    c->in_flight = 4;                    // submitted: only ff_ctx_merge_collect may follow
+    if (c->in_flight >= 2) return FF_ERR_STATE;
+    int64_t nv = 0, ftn = 0;
+    bool hinted = false;
+    if (c->res_off > 0) c->res_off -= 1;
+    if (!ctx_resident(c, a, &nv, &ftn, &hinted)) {
+        c->res_off += c->res_off > 0 ? 1 : 0;            // (ff_ctx_merge_begin counts the call)
+        rc = ff_ctx_merge_begin(c, a);
+        if (rc) return rc;
+        if (a->mask && !a->mask_out) rc = FF_ERR_ARG;
+        if (!rc) rc = ctx_finish_enqueue(c, a);
+        if (rc) { c->in_flight = 0; c->dirty = 1; c->order_len = 0; return rc; }
+        c->in_flight = 4;                    // submitted: only ff_ctx_merge_collect may follow
+        return FF_OK;
+    }
+    if (a->mask && !a->mask_out && a->hidden_out) return FF_ERR_ARG;
+    for (int x = 0; x < (a->hidden_out ? (int)a->n_aux : 0); ++x)
+        if (!a->aux[x].src || !a->aux[x].dst || a->aux[x].row_bytes < 1 || a->aux[x].outer < 1 || a->aux[x].src_outer_bytes < 0) return FF_ERR_ARG;
+    hipStream_t st = (hipStream_t)a->stream;
+    rc = ctx_clean(c, st);
+    if (rc) return rc;
+    const int order_valid = hinted ? 0 : 1;
+    c->last_L = 0;
+    c->seq += 1;
+    c->dirty = 1;                // until the kernel is known to have cleared the select tables (collect) / the merge kernel is enqueued (apply)
+    ff::ResLaunch p;
+    p.hidden = a->hidden; p.hidden_out = a->hidden_out; p.dtype = (int)a->dtype; p.L = a->L; p.d = a->d; p.L_cap = a->L_cap;
+    p.nv = nv; p.ftn = ftn; p.ptype = a->patch_type; p.order = c->order; p.inv = c->inv;
+    p.hint_pre = a->hint_pre; p.hint_patches = a->patch_num; p.hint_frames = order_valid ? 0 : a->hint_frames;
+    p.sim = c->sim; p.member = c->member; p.keep = c->keep; p.dst = c->dst; p.order_next = c->order_next; p.inv_next = c->inv_next;
+    p.stats = c->stats; p.host_mapped = c->stats_host; p.seq = c->seq; p.aux = a->aux; p.n_aux = (int)a->n_aux;
+    p.thr = a->threshold; p.sub = a->sub; p.ratio_lb = a->ratio_lb; p.force_k = a->force_k < 0 ? -1 : (long long)a->force_k;
+    p.ws = c->ws; p.ws_bytes = c->ws_bytes;
+    rc = ff::launch_merge_resident(p, st);
+    if (rc) { c->order_len = 0; return rc; }
+    c->in_flight = 4;
+    c->res_active = 1;
     return FF_OK;
 }
 

@@ -689,7 +689,8 @@ static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1
 // workgroup totals][2 x G x 256 ints: fp32 level rows][L ints: inverse order of the stand-alone entry
 // points][K0's per-slice rows, ff_order.hip] ... free ... [G slices of level-1 tables, down from the
 // end];  G = ceil(L / 4096).
-constexpr int kWsFixedInts = kL0Ints + 16 + 2 * 512;          // (room for 512 workgroup totals)
+constexpr int kWsResBarInts = 1024;                            // barrier words of the one-launch merge kernel (ff_resident.hip)
+constexpr int kWsFixedInts = kL0Ints + 16 + 2 * 512 + kWsResBarInts;          // (room for 512 workgroup totals)
 size_t plan_ws_front_bytes(int64_t L) {
     const size_t G = (size_t)((L + kSelSlice - 1) / kSelSlice) + 1;
     const size_t b = ((size_t)kWsFixedInts + 2 * G * 256 + (size_t)L + 16) * sizeof(int) + 256;
@@ -703,6 +704,8 @@ int* ws_l0(void* ws) { return (int*)ws; }
 int* ws_t16_end(void* ws, size_t ws_bytes) { return (int*)((char*)ws + (ws_bytes & ~(size_t)15)); }
 uint32_t* ws_tag(void* ws) { return (uint32_t*)((int*)ws + kL0Ints); }
 unsigned long long* ws_agg(void* ws) { return (unsigned long long*)((int*)ws + kL0Ints + 16); }
+struct ResBar;
+ResBar* ws_resbar(void* ws) { return (ResBar*)((int*)ws + kL0Ints + 16 + 2 * 512); }
 static int* ws_levels(void* ws) { return (int*)ws + kWsFixedInts; }
 int32_t* ws_scratch_ints(void* ws, int64_t L);
 static int32_t* ws_inv(void* ws, int64_t L) {

@@ -454,6 +454,8 @@ class FrameFusion(nn.Module):
         lib = _lib.load()
         st = self._merge_prepare(hidden_states, position_embeddings, attention_mask, residual)
         sc = st["sc"]
+        if self.one_launch and lib.ff_ctx_merge_one_launch(sc.ctx_ptr, sc.call_ptr):
+            return self._merge_one_launch(st)
         rc = lib.ff_ctx_merge_begin(sc.ctx_ptr, sc.call_ptr)
         if rc:
             _fail(rc, "merge")
@@ -471,6 +473,49 @@ class FrameFusion(nn.Module):
         # second streaming pass is still in flight and returns without waiting for it.
         rc = lib.ff_ctx_merge_finish(sc.ctx_ptr, sc.call_ptr, sc.res_ptr)
         return self._merge_complete(st, rc)
+
+    # The one-launch kernel (csrc/ff_resident.hip): the activation fits into the chip's registers + LDS (the LLaVA-Video-7B and
+    # Qwen2-VL-7B prefills do) and is read ONCE.  False: always the three launches (A/B measurements, tests).
+    one_launch = True
+
+    def _merge_one_launch(self, st):
+        """Outputs first, then ONE crossing that enqueues ONE kernel (ff_ctx_merge_submit), then the wait (ff_ctx_merge_collect).
+        Exactly sized outputs (the default) are allocated for the length the top-k branch gives (main.py:122, host arithmetic); if
+        the plan decides otherwise - or no length can be guessed - the launch stops behind its plan (`applied` = 0) and the merge
+        kernel follows alone, into outputs of the length the result block names (ff_ctx_merge_apply)."""
+        lib = _lib.load()
+        sc, L = st["sc"], st["L"]
+        st["one_launch"] = True
+        if self.compact_outputs:
+            guess = st.get("L_guess")
+            if guess is not None and 0 < guess < L:
+                self._merge_outputs(st, guess)
+            else:
+                self._no_outputs(st)
+        else:
+            self._merge_outputs(st)
+        rc = lib.ff_ctx_merge_submit(sc.ctx_ptr, sc.call_ptr)
+        if rc:
+            _fail(rc, "merge")
+        rc = lib.ff_ctx_merge_collect(sc.ctx_ptr, sc.call_ptr, sc.res_ptr)
+        if rc or sc.res.applied:
+            return self._merge_complete(st, rc)
+        L_out = int(sc.res.l_out)
+        if L_out == L:
+            self._no_outputs(st, hidden=st["hidden"])       # nothing folds: the launch only clears the select tables
+        elif st.get("L_cap") != L and st.get("L_cap") != L_out:
+            self._merge_outputs(st, L_out)
+        rc = lib.ff_ctx_merge_apply(sc.ctx_ptr, sc.call_ptr, sc.res_ptr)
+        return self._merge_complete(st, rc)
+
+    def _no_outputs(self, st, hidden=None):
+        """The output half of the call block, empty: a plan-only submit (hidden = None) / an apply that writes nothing."""
+        call, L = st["sc"].call, st["L"]
+        _PACK_PTR.pack_into(call, 16, hidden.data_ptr() if hidden is not None else 0)
+        _PACK_I64.pack_into(call, 56, L if hidden is not None else 0)             # ff_merge_call_t.L_cap
+        _PACK_I64.pack_into(call, _lib.MERGE_CALL_AUX_OFFSET - 8, 0)
+        _lib.MASK_TRIPLE.pack_into(call, _lib.MERGE_CALL_MASK_OFFSET, 0, 0, 0)
+        st.update(mask_cap=None, L_cap=L if hidden is not None else 0)
 
     # ---- the same call in two halves (FrameFusionPair): everything enqueued by submit, the wait in collect ------------------------
     def submit(self, hidden_states, position_embeddings, attention_mask, self_attn_weights=None, residual=None):
@@ -499,6 +544,9 @@ class FrameFusion(nn.Module):
                 st["guessed"] = True
         else:
             self._merge_outputs(st)
+            # (two samples in flight: never the one-launch kernel - it needs every CU until its grid barrier, two of them
+            # side by side wait for each other until one gives up)
+            sc.ctx.res_off = max(int(sc.ctx.res_off), 2)
             rc = lib.ff_ctx_merge_submit(sc.ctx_ptr, sc.call_ptr)
         if rc:
             _fail(rc, "merge")
@@ -540,11 +588,7 @@ class FrameFusion(nn.Module):
             pass                                                     # (the call block already describes the right outputs)
         elif L_out == L:
             # nothing folds: the launch only clears the select tables; no output is written (any valid pointer will do)
-            _PACK_PTR.pack_into(sc.call, 16, st["hidden"].data_ptr())
-            _PACK_I64.pack_into(sc.call, 56, L)                        # ff_merge_call_t.L_cap
-            _PACK_I64.pack_into(sc.call, _lib.MERGE_CALL_AUX_OFFSET - 8, 0)
-            _lib.MASK_TRIPLE.pack_into(sc.call, _lib.MERGE_CALL_MASK_OFFSET, 0, 0, 0)
-            st.update(mask_cap=None, L_cap=L)
+            self._no_outputs(st, hidden=st["hidden"])
         else:
             self._merge_outputs(st, L_out)
         rc = lib.ff_ctx_merge_apply(sc.ctx_ptr, sc.call_ptr, sc.res_ptr)
@@ -576,6 +620,11 @@ class FrameFusion(nn.Module):
         sub = self._compute_pruning_ratio(self.sparsity_list, self.cost)           # main.py:109
         mask_in = self._mask_for(attention_mask, L) if attention_mask is not None else None     # (shape errors before anything runs)
         sc, stream = self._scratch_for(device, L)
+        if sc.ctx.in_flight:
+            # an earlier call of this instance died between two crossings (an exception in the host code above the library):
+            # forget it - the context's reset also restores the workspace protocol
+            _lib.check(_lib.load().ff_ctx_reset(sc.ctx_ptr, stream or 0), "ff_ctx_reset")
+            sc.order_gen = None
         order_valid = 1 if sc.order_gen == self._ptype_gen else 0
         # first call of a prefill: hand the frame-major layout the prepare() scalars describe to the
         # similarity kernel, which derives and verifies the by-patch order itself (no K0 launch)
@@ -616,11 +665,12 @@ class FrameFusion(nn.Module):
         n_aux = 1 + sc.put_aux(call, _lib.MERGE_CALL_AUX_OFFSET + _lib.AUX_ENTRY.size, zip(srcs, outs), L, room=_lib.MAX_AUX - 1)
         _PACK_PTR.pack_into(call, 16, out.data_ptr())
         _PACK_I64.pack_into(call, _lib.MERGE_CALL_AUX_OFFSET - 8, n_aux)
-        # (the attention mask is gathered behind the call, into a buffer of the OUTPUT length: see _merge_complete.  The C
-        # ABI's other form - mask + an [L_cap, L_cap] buffer in the call block, gathered by ff_ctx_merge_finish itself - is
-        # what a host without a cheap allocator uses; `_mask_through_call` routes through it for the tests)
+        # (the attention mask is gathered behind the call, into a buffer of the OUTPUT length - never a speculative one: see
+        # _merge_complete.  The C ABI's other form - mask + an [L_cap, L_cap] buffer in the call block, gathered by
+        # ff_ctx_merge_finish itself - is what a host without a cheap allocator uses; `_mask_through_call` routes through it
+        # for the tests)
         mask_cap, mask_in = None, st["mask_in"]
-        if mask_in is not None and (exact or self.__dict__.get("_mask_through_call")):
+        if mask_in is not None and self.__dict__.get("_mask_through_call"):
             mask_cap = torch.empty(1, 1, L_cap, L_cap, dtype=mask_in.dtype, device=mask_in.device)
             _lib.MASK_TRIPLE.pack_into(call, _lib.MERGE_CALL_MASK_OFFSET, mask_in.data_ptr(), mask_cap.data_ptr(), mask_in.element_size())
         else:
@@ -633,7 +683,7 @@ class FrameFusion(nn.Module):
         sc, L, dtype, stream = st["sc"], st["L"], st["dtype"], st["stream"]
         hidden_states, position_embeddings, attention_mask, residual = (st["hidden_states"], st["position_embeddings"],
                                                                         st["attention_mask"], st["residual"])
-        nv, ftn, count, branch, k, L_out, err, unhinted, wait_ns = _lib.MERGE_RESULT.unpack_from(sc.res)
+        nv, ftn, count, branch, k, L_out, err, unhinted, wait_ns, _applied = _lib.MERGE_RESULT.unpack_from(sc.res)
         if unhinted:
             # patch_type is not the frame-major layout the prepare() scalars suggested (e.g. text between
             # the frames): the library repeated the call through K0; stop hinting for this prefill - and for
@@ -662,7 +712,8 @@ class FrameFusion(nn.Module):
             # the device and wrote nothing - the reduced sequence is the input itself, and the order
             # in the scratch still describes the (unchanged) patch_type
             self.last_call = dict(kind="merge", L_in=L, L_out=L, nv=nv, ftn=ftn, count=count, branch=branch,
-                                  k=k, scratch=sc, dtype=dtype, order=sc.order, wait_ns=wait_ns, unhinted=bool(unhinted))
+                                  k=k, scratch=sc, dtype=dtype, order=sc.order, wait_ns=wait_ns, unhinted=bool(unhinted),
+                                  one_launch=bool(st.get("one_launch")), applied=bool(_applied))
             sc.order_gen = self._ptype_gen
             if residual is not None:          # nothing folded, but the caller is owed the sum
                 return residual + hidden_states, position_embeddings, attention_mask
@@ -671,8 +722,9 @@ class FrameFusion(nn.Module):
         # order maintenance: the merge kernel also wrote the by-patch order of the compacted sequence
         # (now the context's current one), so the next merge call of this prefill skips K0
         self.last_call = dict(kind="merge", L_in=L, L_out=L_out, nv=nv, ftn=ftn, count=count, branch=branch,
-                              k=k, scratch=sc, dtype=dtype, order=sc.order_next, wait_ns=wait_ns, unhinted=bool(unhinted))
-        mask_cap, L_cap = st["mask_cap"], st["L_cap"]
+                              k=k, scratch=sc, dtype=dtype, order=sc.order_next, wait_ns=wait_ns, unhinted=bool(unhinted),
+                              one_launch=bool(st.get("one_launch")), applied=bool(_applied))
+        mask_cap = st["mask_cap"]
         if mask_cap is not None:
             attention_mask = mask_cap[:, :, :L_out, :L_out]
         elif attention_mask is not None:                                            # main.py:137-138
@@ -685,12 +737,6 @@ class FrameFusion(nn.Module):
                 _fail(rc, "merge (attention mask)")
             attention_mask = mask_out
         hidden_out, ptype_new, pos_new = st["out"].narrow(1, 0, L_out), st["ptype_out"].narrow(1, 0, L_out), st["rebuild"](L_out)
-        if self.compact_outputs and 2 * L_out < L_cap:
-            hidden_out, ptype_new = hidden_out.clone(), ptype_new.clone()
-            if type(pos_new) == list:
-                pos_new[0], pos_new[1] = pos_new[0].clone(), pos_new[1].clone()
-            else:
-                pos_new = pos_new.clone()
         self.patch_type = ptype_new                                                 # main.py:132
         sc.order_gen = self._ptype_gen
         return hidden_out, pos_new, attention_mask

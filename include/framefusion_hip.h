@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FF_ABI_VERSION 9
+#define FF_ABI_VERSION 10
 
 enum { FF_F32 = 0, FF_BF16 = 1, FF_F16 = 2 };
 
@@ -59,6 +59,8 @@ enum {
     FF_STAT_TIES_TAKEN = 9,/* debug: entries equal to the k-th value that were selected           */
     FF_STAT_SEQ = 10,      /* sequence number, copied from the call (host polling)                */
     FF_STAT_ERROR = 11,    /* bit mask of device-side checks that failed, FF_ERR_BIT_*; cleared once published */
+    FF_STAT_APPLIED = 12,  /* one-launch merge call: 1 = the outputs are written (or nothing folds), 0 = the plan only -
+                              member / keep / dst are in place, the merge kernel is still to come (L_cap < l_out or no outputs) */
     FF_STAT_T_ORDER = 16,  /* 2 words: shader-clock cycles of K0's second launch (diagnostics)    */
     FF_STAT_T_PLAN = 24,   /* 7 words: steady-counter stamps of the plan kernel's phases (diagnostics) */
     FF_STAT_WORDS = 32
@@ -66,8 +68,10 @@ enum {
 
 enum {
     FF_ERR_BIT_BARRIER = 1,  /* a workgroup of the plan kernel never saw a predecessor's total (bounded look-back) */
-    FF_ERR_BIT_LAYOUT = 2    /* the frame-major layout hint of ff_merge_begin does not describe
+    FF_ERR_BIT_LAYOUT = 2,   /* the frame-major layout hint of ff_merge_begin does not describe
                                 patch_type: the call's outputs are meaningless, repeat it unhinted  */
+    FF_ERR_BIT_RESIDENT = 4  /* the one-launch merge kernel gave up (its grid barrier timed out behind another barrier kernel, or the
+                                sequence is not what the host believed): the library repeats the call through the three launches */
 };
 
 typedef void* ff_stream_t; /* hipStream_t */
@@ -394,6 +398,10 @@ typedef struct ff_ctx {
     int64_t last_L;        /* input length of the merge call that finished last and whose keep set is still in
                               the scratch (0: none) - what ff_ctx_gather_mask may be asked for (ABI v9)         */
     int64_t last_l_out;    /* ... and its output length                                                         */
+    int64_t cur_nv;        /* visual / non-text tokens of the sequence `order` describes (0: not known to the host) -     */
+    int64_t cur_ftn;       /* what makes a later merge call of the prefill eligible for the one-launch kernel (ABI v10)  */
+    int64_t res_active;    /* the call in flight went out as the one-launch kernel                                      */
+    int64_t res_off;       /* > 0: merge calls left for which the one-launch kernel is not tried (it gave up recently)  */
 } ff_ctx_t;
 
 /* Inputs of one merge call (main.py:104-138).  The same structure goes to begin and finish; the
@@ -429,6 +437,9 @@ typedef struct ff_merge_result {
     int64_t unhinted;    /* 1: the layout hint did not describe patch_type; the call was repeated
                             through K0 inside ff_ctx_merge_finish (stop hinting for this sample)        */
     int64_t wait_ns;     /* time ff_ctx_merge_finish spent polling for the result block (diagnostics)   */
+    int64_t applied;     /* 1: the merge kernel of the call is enqueued (or ran); 0: the plan only - the context is in
+                            the state ff_ctx_merge_wait leaves it in and ff_ctx_merge_apply must follow (ABI v10:
+                            ff_ctx_merge_collect behind a one-launch call whose output buffers were absent or too short) */
 } ff_merge_result_t;
 
 /* begin: (reset if dirty) + K0 unless order_valid/hinted + K1.  Enqueues only.
@@ -456,6 +467,19 @@ int ff_ctx_merge(ff_ctx_t* ctx, const ff_merge_call_t* call, ff_merge_result_t* 
  * Results are those of ff_ctx_merge, bit for bit. */
 int ff_ctx_merge_submit(ff_ctx_t* ctx, const ff_merge_call_t* call);
 int ff_ctx_merge_collect(ff_ctx_t* ctx, const ff_merge_call_t* call, ff_merge_result_t* result);
+
+/* The one-launch merge kernel (ABI v10, csrc/ff_resident.hip): when the whole activation fits into the chip's registers + LDS
+ * (bf16, rows of at most 8 KiB, at most 56 visual tokens per CU: the LLaVA-Video-7B and Qwen2-VL-7B prefills the reference ships
+ * for - 90-96 MB - do) and the by-patch order is known to the host (layout hint, or the order a previous call of the prefill left),
+ * ff_ctx_merge_submit enqueues ONE kernel that reads every row ONCE - similarities, one grid barrier, the plan, the fold from the
+ * resident rows - instead of K1, plan and merge kernel.  Same results, bit for bit.  Such a call may be submitted with
+ * hidden_out = NULL ("plan only") or with buffers of fewer than l_out rows (outputs sized for the top-k branch's length,
+ * main.py:122, while the plan took the threshold branch): ff_ctx_merge_collect then reports result->applied = 0 and
+ * ff_ctx_merge_apply - with outputs of l_out rows - finishes the call with the merge kernel alone.
+ * Returns 1 if ff_ctx_merge_submit(ctx, call) would take that path now (only the input half of `call` is looked at), else 0.
+ * Two such kernels never run side by side on a device without one of them timing out (each needs every CU until its barrier):
+ * a host that keeps two samples in flight on two streams sets ctx->res_off to a large number on both contexts. */
+int ff_ctx_merge_one_launch(const ff_ctx_t* ctx, const ff_merge_call_t* call);
 
 /* The merge call for EXACTLY SIZED outputs (ABI v9) - what the reference returns: hidden_states[token_mask, :], the position
  * embeddings and the attention mask gathered with the same mask (framefusion/main.py:132-138, 161-178).  The host learns l_out

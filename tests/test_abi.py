@@ -47,7 +47,7 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(_lib.LIB_PATH)
     for name in declared_functions():
         assert hasattr(lib, name), name
-    assert _lib.load().ff_abi_version() == _lib.ABI_VERSION == 9
+    assert _lib.load().ff_abi_version() == _lib.ABI_VERSION == 10
 
 
 def test_stat_enum_matches_binding():
