@@ -454,11 +454,12 @@ extern "C" int ff_ctx_merge_finish(ff_ctx_t* c, const ff_merge_call_t* a, ff_mer
 // Is this call one for the one-launch kernel (ff_resident.hip)?  The host must know the by-patch order's length: from the layout
 // hint, or from the previous call of the prefill.
 static bool ctx_resident(const ff_ctx_t* c, const ff_merge_call_t* a, int64_t* nv, int64_t* ftn, bool* hinted) {
-    if (c->res_off > 0 || a->L < 1 || a->d < 1) return false;
+    if (c->res_off > 0 || a->L < 1 || a->d < 1 || (c->cap & 3)) return false;      // (whole 16-byte words behind order / inv / sim)
     const bool ov = a->order_valid && c->order_len == a->L && c->cur_nv > 0 && !c->dirty;
     const bool hint = !ov && a->hint_frames > 0 && a->hint_pre >= 0 && a->patch_num >= 1 &&
                       a->hint_pre + a->hint_frames * a->patch_num <= a->L;
     if (!ov && !hint) return false;
+    if (hint && a->patch_num < 32) return false;           // (the kernel's closed form of a position's slot: 32 positions, two frames)
     *nv = ov ? c->cur_nv : a->hint_frames * a->patch_num;
     *ftn = ov ? c->cur_ftn : *nv;
     *hinted = hint;

@@ -8,16 +8,16 @@
 //   A  load + similarities: the rows are requested kResRL ahead of the arithmetic (the first kResRL by LDS-DMA into LDS, the rest
 //      into VGPRs, 4 per row per wave) and STAY there.  |x|^2 and the T-rounded pair dots are summed per lane as the rows arrive
 //      (recipe of ff_similarity.hip), per wave on the DPP network, across the waves through LDS; the segment's similarities are
-//      published write-through and folded into the select tables (as K1's epilogue does).
+//      published write-through.
 //   -- ONE XCD-hierarchical grid barrier (static groups blockIdx & 7; bounded; abort flag) --
-//   B  plan, by every workgroup for itself (nothing else crosses workgroups): decision, k-th key and ties from the tables
-//      (ff_plan_fast.h's arithmetic) with the similarities 32 per thread in registers; member bits by slot; the member bitmap
-//      by POSITION (closed form of the frame-major layout, or inv[]); two prefix scans.  Workgroup 0 publishes the result block.
+//   B  plan, by every workgroup for itself (nothing else crosses workgroups; the select tables of the three-launch path are not
+//      touched): all similarities 32 per thread in registers, two 256-bin histograms in LDS (top byte, then low byte of the
+//      k-th key's bin), decision and ties with ff_plan_fast.h's arithmetic; member bits by slot; the member bitmap by POSITION
+//      (closed form of the frame-major layout, or inv[]); two prefix scans.  Workgroup 0 publishes the result block.
 //   C  fold + compaction FROM THE RESIDENT ROWS: a wave walks its rows in order, a non-member opens an output row, a member folds
 //      into it (rounding after every add, main.py:304-317); a run that continues into the next workgroup's segment is finished
 //      by its anchor's workgroup, which fetches those rows (L2 / Infinity Cache) - the only rows read twice.  Then the short
-//      roles: non-visual rows, auxiliary rows (position tables, patch types), member / keep / dst, next order + inverse, table
-//      clearing (behind a second, non-blocking count of the workgroups that have finished READING the tables).
+//      roles: non-visual rows, auxiliary rows (position tables, patch types), member / keep / dst, next order + inverse.
 //
 // When the output buffers are too short for the result (L_cap < l_out: exactly sized outputs allocated for the top-k branch's
 // length while the plan took the threshold branch) or absent, the launch stops after B with member / keep / dst in place:
@@ -27,6 +27,7 @@
 // launches at the 7B layout.  Lesson of the probe: all loads first, arithmetic behind them, starts the arithmetic 9-12 us late -
 // a CU holds far fewer requests than 8 waves x 55 KiB, so the load INSTRUCTIONS queue; hence the software pipeline.
 #include <atomic>
+#include <type_traits>
 
 #include "ff_common.h"
 #include "ff_merge_body.h"
@@ -43,7 +44,6 @@ constexpr int kResRows = kResRV + kResRL;        // <= 62: a wave names its rows
 constexpr int kResKeys = 32;                     // similarities per thread in the plan
 constexpr int kResMaxNv = kResThreads * kResKeys;        // 16 384
 constexpr int kResMaxL = 2 * kResMaxNv;                  // 32 768 (two position words per thread)
-constexpr int kResSlices = kResMaxNv / kSelSlice;        // 4 level-1 slices
 static_assert(kResRows <= 62 && kResRV % 2 == 0 && kResRL % 2 == 0, "rows are handled in pairs, named by lane");
 
 // barrier state, 128-byte lines, zero between launches (the last arriver of every stage resets its word)
@@ -52,7 +52,6 @@ struct ResBar {
     unsigned top[32];
     unsigned gen[8][32];
     unsigned abort_tag[32];
-    unsigned readers[32];
 };
 static_assert(sizeof(ResBar) <= 4096, "ff_plan.hip reserves 4 KB of the workspace front");
 
@@ -69,9 +68,6 @@ struct ResArgs {
     int32_t* inv;
     int hint_pre, hint_patches, hint_frames;
     void* sim;
-    int* l0;
-    int* t16_end;
-    float thr;
     PlanParams pp;
     uint8_t* member;
     uint8_t* keep;
@@ -163,36 +159,17 @@ __device__ inline bool res_barrier(ResBar* gb, int bid, int nwg, unsigned tag) {
     return ok;
 }
 
-// table[idx] += 1 for every lane with `valid` (idx relative to `table`, may be negative: the level-1 slices lie DOWN from the
-// end of the workspace); equal indices folded into one atomic for the first kIters distinct values (ff_common.h, wave_agg_add)
-template <int kIters>
-__device__ inline void wave_agg_add_rel(int* table, int idx, bool valid) {
-    unsigned long long rem = __ballot(valid);
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int it = 0; it < kIters; ++it) {
-        if (rem == 0ull) break;
-        const int first = __ffsll((long long)rem) - 1;
-        const int v = __builtin_amdgcn_readlane(idx, first);
-        const unsigned long long m = __ballot(valid && idx == v) & rem;
-        if (lane == first) atomicAdd(table + v, (int)__popcll(m));
-        rem &= ~m;
-    }
-    if ((rem >> lane) & 1ull) atomicAdd(table + idx, 1);
-}
-
 constexpr size_t kResPartBytes = (size_t)(kResRows + 2) * kResWaves * 8;          // float2 [rows + 2][waves]
 struct ResLds {
     // offsets into the dynamic LDS block (all multiples of 16)
     static constexpr size_t part = 0;
     static constexpr size_t simk = part + ((kResPartBytes + 15) & ~(size_t)15);      // u32 [64]: raw bits of my similarities
     static constexpr size_t sflag = simk + 64 * 4;                                  // int [64]: slot continues its predecessor's chain
-    static constexpr size_t dpart = sflag + 64 * 4;                                 // int [2][256]
-    static constexpr size_t drows = dpart + 2 * 256 * 4;                            // int [kResSlices][256]
-    static constexpr size_t scratch = drows + kResSlices * 256 * 4;                 // int [32]
+    static constexpr size_t dpart = sflag + 64 * 4;                                 // int [256 + 8 * 256 + 8]: the plan's histograms
+    static constexpr size_t scratch = dpart + (256 + 8 * 256 + 8) * 4;              // int [32]
     static constexpr size_t bcast = scratch + 32 * 4;                               // int [16]
-    static constexpr size_t slotmask = bcast + 16 * 4;                              // u32 [512]
-    static constexpr size_t slotpre = slotmask + 512 * 4;                           // int [512]  members before the word
+    static constexpr size_t slotmask = bcast + 16 * 4;                              // u32 [512 + 8]: word w at w + (w >> 6)
+    static constexpr size_t slotpre = slotmask + 528 * 4;                           // int [512]  members before the word
     static constexpr size_t posmask = slotpre + 512 * 4;                            // u32 [1024]
     static constexpr size_t pospre = posmask + 1024 * 4;                            // int [1024]
     static constexpr size_t sres = pospre + 1024 * 4;                               // int64 [32]
@@ -207,12 +184,16 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
     constexpr int E = 8, RV = kResRV, RL = kResRL;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2* part = (float2*)(smem + ResLds::part);
-    uint32_t* simk = (uint32_t*)(smem + ResLds::simk);
     int* sflag = (int*)(smem + ResLds::sflag);
-    int (*dpart)[256] = (int (*)[256])(smem + ResLds::dpart);
+    int* hist0 = (int*)(smem + ResLds::dpart);                  // [256] level 0 | [8][256] level 1 | [8] counters
+    int* hist1 = hist0 + 256;
+    int* hcnt = hist1 + 8 * 256;
     int* scratch = (int*)(smem + ResLds::scratch);
     int* bcast = (int*)(smem + ResLds::bcast);
-    uint32_t* slotmask = (uint32_t*)(smem + ResLds::slotmask);
+    uint32_t* slotmask_ = (uint32_t*)(smem + ResLds::slotmask);
+    // (one pad word per 64: threads 32 positions apart read words F apart - all 64 lanes one bank at F = 64 without it)
+    auto slotword = [&](int w) -> uint32_t& { return slotmask_[w + (w >> 6)]; };
+    auto slotbit = [&](int t) -> uint32_t { return (slotword(t >> 5) >> (t & 31)) & 1u; };
     int* slotpre = (int*)(smem + ResLds::slotpre);
     uint32_t* posmask = (uint32_t*)(smem + ResLds::posmask);
     int* pospre = (int*)(smem + ResLds::pospre);
@@ -223,6 +204,10 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
     const int bid = blockIdx.x, G = gridDim.x;
     const int nt = a.nt, L = a.L;
     const unsigned tag = (unsigned)a.seq;
+    // phase stamps of workgroup 0 (100 MHz wall clock, relative to its start): stats[FF_STAT_T_PLAN ..], diagnostics
+    const long long stamp0 = wall_clock64();
+    long long stamp[7] = {0, 0, 0, 0, 0, 0, 0};
+    long long sub[8] = {0, 0, 0, 0, 0, 0, 0, 0};               // finer stamps (stats[FF_STAT_T_ORDER ..])
     const int F = a.hint_frames, P = a.hint_patches, pre = a.hint_pre;
     int nv, ftn;
     if constexpr (kHint) { nv = P * F; ftn = nv; }
@@ -292,8 +277,13 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
         uint32_t prev_off;
         if constexpr (kHint) prev_off = (uint32_t)pos_hint(s0 > 0 ? s0 - 1 : 0) * rb;
         else prev_off = (uint32_t)__builtin_amdgcn_readlane(ordw, 0) * rb;
+#ifdef FF_RES_NO_UNCOUNTED
+        const uint4 prev_c = buf_load16s(hres, vcol, prev_off);
+        u32x4 prevv; prevv.x = prev_c.x; prevv.y = prev_c.y; prevv.z = prev_c.z; prevv.w = prev_c.w;
+#else
         u32x4 prevv;
         buf_load16_uncounted(prevv, hraw, vcol, prev_off);
+#endif
         // every wave issues exactly 1 + RL + RV requests (rows past n: an out-of-range offset, answered with zeros without
         // traffic), so that the hand-counted waits below hold for every segment length
 #pragma unroll
@@ -332,7 +322,11 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
             if (i + 1 < RV) { if (RL + i + 1 < n) v[i + 1] = buf_load16s(hres, vcol, row_off(RL + i + 1)); else v[i + 1] = buf_load16s(hres, kDead, 0u); }
             if (i == 0) {
                 // (the row before my first slot was requested first: it is there when rows 0 and 1 are)
+#ifdef FF_RES_WAIT_ALL
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(prevv) :: "memory");
+#else
                 asm volatile("s_waitcnt vmcnt(%1)" : "+v"(prevv) : "n"(RL) : "memory");
+#endif
                 const uint4 prev = make_uint4(prevv.x, prevv.y, prevv.z, prevv.w);
                 if constexpr (DT == FF_BF16) A::unpack(prev, lastf);
                 else lastw = prev;
@@ -340,7 +334,9 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
                 wave_sum4_dpp63(q0, z0, z1, z2);
                 if (lane == 63) part[wv] = make_float2(q0, 0.f);
             } else {
+#ifndef FF_RES_WAIT_ALL
                 asm volatile("s_waitcnt vmcnt(%0)" :: "n"(RL) : "memory");
+#endif
             }
             if (i < n) two(*lrow(i), *lrow(i + 1), i);
         }
@@ -380,7 +376,8 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
         }
     }
     __syncthreads();
-    // ---- similarities of my slots (wave 0: lane <-> slot), published write-through, folded into the select tables
+    stamp[0] = wall_clock64() - stamp0;                       // rows in, norms and dots done
+    // ---- similarities of my slots (wave 0: lane <-> slot), published write-through
     if (wv == 0) {
         const bool mine = lane < n;
         float sv = -2.0f;                                   // IGNORE_TOKEN (main.py:225-238)
@@ -394,18 +391,11 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
             const float na = A::rnd(sqrtf(qa)), nb = A::rnd(sqrtf(qb));
             sv = A::rnd(A::rnd(d) / A::rnd(na * nb));
         }
-        uint32_t bits;
-        if constexpr (DT == FF_BF16) bits = __float_as_uint(sv) >> 16;
-        else { _Float16 h = (_Float16)sv; bits = (uint32_t)__builtin_bit_cast(uint16_t, h); }
-        simk[lane] = mine ? bits : 0u;
+        const uint32_t bits = __float_as_uint(sv) >> 16;
         if (mine) __hip_atomic_store((uint16_t*)a.sim + (s0 + lane), (uint16_t)bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t key = order_key<DT>(bits);
-        int* tab = a.l0 + (bid & (kL0Copies - 1)) * kL0Stride;
-        const int n_ge = __popcll(__ballot(mine && sv >= a.thr));
-        if (lane == 0 && n_ge) atomicAdd(&tab[256], n_ge);
-        wave_agg_add_rel<4>(tab, (int)(key >> 8), mine);
-        const int g = (s0 + lane) / kSelSlice;
-        wave_agg_add_rel<8>(a.t16_end, (int)t16_bin(key) - (g + 1) * (int)kT16SliceInts, mine);
+    } else {
+        // (the plan's histograms start from zero)
+        for (int z = tid - kWave; z < 256 + 8 * 256 + 8; z += kResThreads - kWave) hist0[z] = 0;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -420,64 +410,94 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
 
     // ======================================================================================================================
     // B. plan (every workgroup for itself)
+    stamp[1] = wall_clock64() - stamp0;                       // barrier passed
     const PlanParams& pp = a.pp;
-    const int c = tid & 255, q = tid >> 8;
-    const int n_slices = (nv + kSelSlice - 1) / kSelSlice;
-    // ---- round 1: tables, my 32 similarities, the error word
-    int l0v[kL0Copies / 2];
-#pragma unroll
-    for (int x = 0; x < kL0Copies / 2; ++x) l0v[x] = a.l0[(q + x * 2) * kL0Stride + c];
-    const int l0cnt_raw = a.l0[(tid & (kL0Copies - 1)) * kL0Stride + 256];
-    int specv[kResSlices / 2];
-    {
-        const uint32_t bin = t16_bin(((uint32_t)pp.p0_guess << 8) | (uint32_t)c);
-#pragma unroll
-        for (int j = 0; j < kResSlices / 2; ++j) specv[j] = q + j * 2 < n_slices ? t16_slice(a.t16_end, q + j * 2)[bin] : 0;
-    }
-    const long long err_bits = (long long)__hip_atomic_load((unsigned long long*)(a.stats + FF_STAT_ERROR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    {
-        int colsum = 0;
-#pragma unroll
-        for (int x = 0; x < kL0Copies / 2; ++x) colsum += l0v[x];
-        dpart[q][c] = colsum;
-        if (tid < kL0Copies) scratch[tid] = l0cnt_raw;
-    }
-    // my 32 similarities (requested once the level-0 words have left their registers)
-    // (a 16-byte buffer access that crosses the end of the range is out of range as a WHOLE: the last, partial group of 8 is
-    // read element by element)
-    const __amdgpu_buffer_rsrc_t sres_rsrc = make_rsrc(a.sim, (uint32_t)nv * 2u);
+    // ---- my 32 similarities (bit e <-> slot 32 * tid + e) as order-preserving keys, two per word
+    // (a 16-byte buffer access that crosses the end of the range is out of range as a WHOLE, so the range is rounded up to
+    // whole words: the context's `sim` holds 4 bytes per token of capacity; what lies past nv is masked by `valid`)
+    const int t_base = tid * kResKeys;
+    const __amdgpu_buffer_rsrc_t sres_rsrc = make_rsrc(a.sim, ((uint32_t)nv * 2u + 15u) & ~15u);
     uint4 kx[kResKeys / 8];
 #pragma unroll
+    for (int x = 0; x < kResKeys / 8; ++x) kx[x] = buf_load16s(sres_rsrc, (uint32_t)(t_base + x * 8) * 2u, 0u);
+    const long long err_bits = (long long)__hip_atomic_load((unsigned long long*)(a.stats + FF_STAT_ERROR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t valid = nv - t_base >= 32 ? 0xffffffffu : (nv - t_base <= 0 ? 0u : (1u << (nv - t_base)) - 1u);
+    // raw bits -> keys, both halves of a word at once: negative values are inverted, the others get the sign bit; NaN -> 0xffff
+    auto keys2 = [&](uint32_t w) -> uint32_t {
+        const uint32_t neg = (w >> 15) & 0x00010001u;
+        uint32_t k2 = w ^ (((neg << 16) - neg) | 0x80008000u);
+        const uint32_t mag = w & 0x7fff7fffu;
+        if ((mag & 0xffffu) > 0x7f80u) k2 |= 0x0000ffffu;
+        if ((mag >> 16) > 0x7f80u) k2 |= 0xffff0000u;
+        return k2;
+    };
+    uint32_t kk[kResKeys / 2];
+#pragma unroll
     for (int x = 0; x < kResKeys / 8; ++x) {
-        const int t0 = tid * kResKeys + x * 8;
-        if (t0 + 8 <= nv || t0 >= nv) {
-            kx[x] = buf_load16s(sres_rsrc, (uint32_t)t0 * 2u, 0u);
+        kk[4 * x] = keys2(kx[x].x); kk[4 * x + 1] = keys2(kx[x].y); kk[4 * x + 2] = keys2(kx[x].z); kk[4 * x + 3] = keys2(kx[x].w);
+    }
+    auto key_of = [&](int e) -> uint32_t { return (e & 1) ? kk[e >> 1] >> 16 : kk[e >> 1] & 0xffffu; };
+    // threshold set (main.py:113): key >= thr_key and not NaN, as ONE unsigned compare
+    uint32_t thm = 0;
+    {
+        const uint32_t span = 0xffffu - pp.thr_key;
+#pragma unroll
+        for (int e = 0; e < kResKeys; ++e) thm |= (uint32_t)((key_of(e) - pp.thr_key) < span) << e;
+        thm &= valid;
+    }
+    sub[3] = wall_clock64() - stamp0;                         // keys there, threshold set
+    // ---- level 0, speculated: the k-th similarity of a video sits in the binade of typical thresholds (pp.p0_guess, as the
+    // three-launch plan guesses): count my keys whose top byte is ABOVE / EQUAL to the guess - both halves of a word at once -
+    // and let the totals say whether the guess holds.  (A 256-bin histogram of top bytes in LDS costs microseconds here: a
+    // video's similarities share two or three top bytes and same-address LDS atomics serialise.)
+    {
+        const uint32_t g = (uint32_t)pp.p0_guess;
+        int c_ge = 0, c_eq = 0;
+        if (valid == 0xffffffffu) {
+            const uint32_t G1 = g * 0x00010001u, G8 = g * 0x01000100u;
+#pragma unroll
+            for (int x = 0; x < kResKeys / 2; ++x) {
+                const uint32_t tb = kk[x] & 0xff00ff00u;
+                const uint32_t z = tb ^ G8;                                              // a half is zero <=> its top byte == g
+                c_eq += __popc((z - 0x00010001u) & ~z & 0x80008000u);
+                c_ge += __popc((((tb >> 8) | 0x01000100u) - G1) & 0x01000100u);          // bit 8 of 0x100 + byte - g
+            }
         } else {
-            uint32_t w[4] = {0u, 0u, 0u, 0u};
-            for (int e = 0; t0 + e < nv; ++e) w[e >> 1] |= (uint32_t)((const uint16_t*)a.sim)[t0 + e] << (16 * (e & 1));
-            kx[x] = make_uint4(w[0], w[1], w[2], w[3]);
+#pragma unroll
+            for (int e = 0; e < kResKeys; ++e) {
+                const uint32_t tb = key_of(e) >> 8, ok = (valid >> e) & 1u;
+                c_eq += (int)(ok & (uint32_t)(tb == g));
+                c_ge += (int)(ok & (uint32_t)(tb >= g));
+            }
         }
+        float r0 = (float)__popc(thm), r1 = (float)(c_ge - c_eq), r2 = (float)c_eq, r3 = 0.f;   // (exact: sums below 2^24)
+        wave_sum4_dpp63(r0, r1, r2, r3);
+        if (lane == 63) { atomicAdd(&hcnt[0], (int)r0); atomicAdd(&hcnt[1], (int)r1); atomicAdd(&hcnt[2], (int)r2); }
     }
     __syncthreads();
-    auto pick = [&](int rem, int& bin, int& above) {
+    sub[7] = wall_clock64() - stamp0;                         // level-0 counts
+    // pick: the bin of the rem-th largest entry of a 256-bin histogram (+ more copies of it), and the entries above it
+    auto pick = [&](const int* h, int copies, int rem, int& bin, int& above) {
         const int top = 255 - 4 * lane;
         int vv[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) vv[e] = dpart[0][top - e] + dpart[1][top - e];
+        for (int e = 0; e < 4; ++e) {
+            vv[e] = h[top - e];
+            for (int x = 1; x < copies; ++x) vv[e] += h[x * 256 + top - e];
+        }
         const int sum = vv[0] + vv[1] + vv[2] + vv[3];
         const int incl = wave_incl_scan_dpp(sum);
         const int first = __ffsll((long long)__ballot(incl >= rem)) - 1;
-        int ab = incl - sum, b = top;
-        if (ab + vv[0] >= rem) { b = top; }
-        else if (ab + vv[0] + vv[1] >= rem) { ab += vv[0]; b = top - 1; }
-        else if (ab + vv[0] + vv[1] + vv[2] >= rem) { ab += vv[0] + vv[1]; b = top - 2; }
-        else { ab += vv[0] + vv[1] + vv[2]; b = top - 3; }
-        bin = __builtin_amdgcn_readlane(b, first);
+        int ab = incl - sum, bsel = top;
+        if (ab + vv[0] >= rem) { bsel = top; }
+        else if (ab + vv[0] + vv[1] >= rem) { ab += vv[0]; bsel = top - 1; }
+        else if (ab + vv[0] + vv[1] + vv[2] >= rem) { ab += vv[0] + vv[1]; bsel = top - 2; }
+        else { ab += vv[0] + vv[1] + vv[2]; bsel = top - 3; }
+        bin = __builtin_amdgcn_readlane(bsel, first);
         above = __builtin_amdgcn_readlane(ab, first);
     };
     if (wv == 0) {
-        int cnt = lane < kL0Copies ? scratch[lane] : 0;
-        cnt = __builtin_amdgcn_readlane(wave_incl_scan_dpp(cnt), 63);
+        const int cnt = hcnt[0];
         bool topk;
         long long k;
         if (pp.k_given >= 0) {
@@ -494,9 +514,34 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
                 if (k < 0) k = 0;
             }
         }
-        int bin = 0, above = 0;
-        if (topk && k > 0) pick((int)k, bin, above);
-        if (lane == 0) { bcast[0] = topk ? 1 : 0; bcast[1] = cnt; bcast[2] = (int)k; bcast[3] = bin; bcast[4] = (int)k - above; bcast[9] = -1; }
+        const int above = hcnt[1], at = hcnt[2];
+        const bool held = topk && k > 0 && above < (int)k && (int)k <= above + at;
+        if (lane == 0) {
+            bcast[0] = topk ? 1 : 0; bcast[1] = cnt; bcast[2] = (int)k; bcast[3] = pp.p0_guess; bcast[4] = (int)k - above; bcast[9] = -1;
+            bcast[10] = (topk && k > 0 && !held) ? 1 : 0;                           // the guess failed: the general level 0 below
+        }
+    }
+    __syncthreads();
+    if (bcast[10]) {                                         // (uniform; rare)
+        // the 256-bin histogram after all: runs of equal top bytes counted in registers, one LDS atomic per change
+        int cur = -1, run = 0;
+#pragma unroll
+        for (int e = 0; e < kResKeys; ++e) {
+            const int tb = ((valid >> e) & 1u) ? (int)(key_of(e) >> 8) : -1;
+            if (tb != cur) {
+                if (cur >= 0) atomicAdd(&hist0[cur], run);
+                cur = tb; run = 0;
+            }
+            ++run;
+        }
+        if (cur >= 0) atomicAdd(&hist0[cur], run);
+        __syncthreads();
+        if (wv == 0) {
+            int bin, above;
+            pick(hist0, 1, bcast[2], bin, above);
+            if (lane == 0) { bcast[3] = bin; bcast[4] = bcast[2] - above; }
+        }
+        __syncthreads();
     }
     __syncthreads();
     const bool is_topk = bcast[0] != 0;
@@ -504,49 +549,43 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
     const bool topk = is_topk && k_sel > 0;
     uint32_t kth = 0;
     int need = 0, tstar = -1;
-    // my 32 keys as masks (bit e <-> slot 32 * tid + e)
-    const int t_base = tid * kResKeys;
-    auto key_of = [&](int e) -> uint32_t {
-        const uint4& w4 = kx[e >> 3];
-        const uint32_t w = ((e >> 1) & 3) == 0 ? w4.x : ((e >> 1) & 3) == 1 ? w4.y : ((e >> 1) & 3) == 2 ? w4.z : w4.w;
-        return order_key<DT>((w >> (16 * (e & 1))) & 0xffffu);
-    };
+    uint32_t mm;
     if (topk) {                                              // (uniform)
-        const int p0 = bcast[3];
-        int colsum = 0;
+        // level 1: the low bytes of the keys whose top byte is the k-th key's, 8 copies against same-bin collisions
+        const uint32_t p0 = (uint32_t)bcast[3];
+        int* h1 = hist1 + (lane & 7) * 256;
 #pragma unroll
-        for (int j = 0; j < kResSlices / 2; ++j) {
-            int x = 0;
-            if (q + j * 2 < n_slices) x = p0 == pp.p0_guess ? specv[j] : t16_slice(a.t16_end, q + j * 2)[t16_bin(((uint32_t)p0 << 8) | (uint32_t)c)];
-            colsum += x;
+        for (int e = 0; e < kResKeys; ++e) {
+            const uint32_t key = key_of(e);
+            atomicAdd(&h1[key & 0xffu], (int)(((valid >> e) & 1u) & (uint32_t)((key >> 8) == p0)));
         }
-        dpart[q][c] = colsum;                                // (level 0's sums have been consumed: wave 0 only, before the barrier above)
         __syncthreads();
         if (wv == 0) {
             int p1, above;
-            pick(bcast[4], p1, above);
-            if (lane == 0) { bcast[5] = (p0 << 8) | p1; bcast[6] = bcast[4] - above; }
+            pick(hist1, 8, bcast[4], p1, above);
+            if (lane == 0) { bcast[5] = (int)((p0 << 8) | (uint32_t)p1); bcast[6] = bcast[4] - above; }
         }
         __syncthreads();
         kth = (uint32_t)bcast[5];
         need = bcast[6];
-    }
-    // the level-0 / level-1 words I needed are in registers or LDS now
-    if (tid == 0) add_agent(&a.bar->readers[0], 1u);
-    uint32_t eqm = 0, gtm = 0, thm = 0;
+        stamp[2] = wall_clock64() - stamp0;                   // decision + k-th key known
+        uint32_t eqm = 0, gtm = 0;
 #pragma unroll
-    for (int e = 0; e < kResKeys; ++e) {
-        const uint32_t key = key_of(e);
-        const bool in = t_base + e < nv;
-        eqm |= (uint32_t)(in & (key == kth)) << e;
-        gtm |= (uint32_t)(in & (key > kth)) << e;
-        thm |= (uint32_t)(in & (key >= pp.thr_key) & (key != nan_key<DT>())) << e;
-    }
-    if (topk) {
+        for (int e = 0; e < kResKeys; ++e) {
+            const uint32_t key = key_of(e);
+            eqm |= (uint32_t)(key == kth) << e;
+            gtm |= (uint32_t)(key > kth) << e;
+        }
+        eqm &= valid; gtm &= valid;
+        sub[0] = wall_clock64() - stamp0;                     // key masks
         // t*: the slot of the need-th entry equal to the k-th key (ties taken in ascending by-patch position)
         const int mine = __popc(eqm);
-        int total;
-        const int ex = block_excl_scan<kResWaves>(mine, scratch, total);
+        const int wincl = wave_incl_scan_dpp(mine);
+        if (lane == 63) scratch[wv] = wincl;
+        __syncthreads();
+        int ex = wincl - mine;
+#pragma unroll
+        for (int x = 0; x < kResWaves; ++x) ex += x < wv ? scratch[x] : 0;
         if (ex < need && need <= ex + mine) {
             uint32_t m = eqm;
             for (int x = ex + 1; x < need; ++x) m &= m - 1;        // drop the lowest set bit need - ex - 1 times
@@ -554,74 +593,58 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
         }
         __syncthreads();
         tstar = bcast[9];
-    }
-    uint32_t mm;
-    if (is_topk) {
-        mm = 0;
-        if (topk) {
-            const int upto = tstar - t_base;                // ties at slots <= t* are taken
-            const uint32_t tie_take = upto >= 31 ? 0xffffffffu : upto < 0 ? 0u : ((2u << upto) - 1u);
-            mm = gtm | (eqm & tie_take);
-        }
+        const int upto = tstar - t_base;                    // ties at slots <= t* are taken
+        const uint32_t tie_take = upto >= 31 ? 0xffffffffu : upto < 0 ? 0u : ((2u << upto) - 1u);
+        mm = gtm | (eqm & tie_take);
     } else {
-        mm = thm;
+        stamp[2] = wall_clock64() - stamp0;
+        mm = is_topk ? 0u : thm;
     }
     if (tid == 0) mm &= ~1u;                                // slot 0 never folds
-    slotmask[tid] = mm;
+    sub[1] = wall_clock64() - stamp0;                         // tie slot, member bits of my slots
+    slotword(tid) = mm;
     __syncthreads();
     // ---- member bits by POSITION: thread t owns positions [ppt * t, ppt * (t + 1)), ppt = 32 or 64
     const int words = L > kResMaxNv ? 2 : 1;
     uint32_t pm0 = 0u, pm1 = 0u;
     {
         const int i0 = tid * 32 * words;
-        if constexpr (kHint) {
-            int x = i0 - pre;                               // index inside the visual span
-            int f = 0, p = 0, s = 0;                        // frame / patch / slot of position x (x <= 0: of the span's start)
-            if (x > 0 && x < nv) { f = x / P; p = x - f * P; s = p * F + f; }
-            auto word = [&]() {
-                uint32_t m = 0;
-#pragma unroll 8
+        const __amdgpu_buffer_rsrc_t irs = make_rsrc(a.inv, ((uint32_t)L * 4u + 15u) & ~15u);      // (whole words: see `sim` above)
+#pragma unroll 1
+        for (int w = 0; w < words; ++w) {
+            const int ib = i0 + w * 32;
+            uint32_t m = 0;
+            if constexpr (kHint) {
+                // 32 consecutive positions touch at most two frames (patch_num >= 32: the launcher's condition): position
+                // x = f * P + p of the visual span sits at slot p * F + f
+                const int x = ib - pre;
+                const int base = x > 0 ? x : 0;
+                const int f0 = base / P;
+                const int d0 = x - f0 * P;                      // (may be negative before the span: masked by `in`)
+#pragma unroll
                 for (int e = 0; e < 32; ++e) {
-                    if (x >= 0 && x < nv) {
-                        m |= ((slotmask[s >> 5] >> (s & 31)) & 1u) << e;
-                        s += F;
-                        if (++p == P) { p = 0; ++f; s = f; }
-                    }
-                    ++x;
+                    const bool in = (unsigned)(x + e) < (unsigned)nv;
+                    const int dd = d0 + e;
+                    const int pe = dd < P ? dd : dd - P, fe = dd < P ? f0 : f0 + 1;
+                    const int sl = in ? pe * F + fe : 0;
+                    m |= (in ? slotbit(sl) : 0u) << e;
                 }
-                return m;
-            };
-            pm0 = word();
-            if (words == 2) pm1 = word();
-        } else {
-            const __amdgpu_buffer_rsrc_t irs = make_rsrc(a.inv, (uint32_t)L * 4u);
-            auto word = [&](int ib) {
-                uint32_t m = 0;
+            } else {
 #pragma unroll 2
                 for (int ch = 0; ch < 8; ++ch) {
-                    const int ic = ib + ch * 4;
-                    uint32_t sl[4];
-                    if (ic + 4 <= L || ic >= L) {           // (past L: zeros, masked below; the partial group: element by element)
-                        const uint4 a0 = buf_load16s(irs, (uint32_t)ic * 4u, 0u);
-                        sl[0] = a0.x; sl[1] = a0.y; sl[2] = a0.z; sl[3] = a0.w;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) sl[e] = ic + e < L ? (uint32_t)a.inv[ic + e] : 0u;
-                    }
+                    const uint4 a0 = buf_load16s(irs, (uint32_t)(ib + ch * 4) * 4u, 0u);          // (past L: masked below)
+                    const uint32_t sl[4] = {a0.x, a0.y, a0.z, a0.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const int i = ib + ch * 4 + e;
-                        const uint32_t s = sl[e];
-                        const uint32_t bit = (i < L && s < (uint32_t)nv) ? (slotmask[s >> 5] >> (s & 31)) & 1u : 0u;
-                        m |= bit << (ch * 4 + e);
+                        const bool in = ib + ch * 4 + e < L && sl[e] < (uint32_t)nv;
+                        m |= (in ? slotbit(in ? (int)sl[e] : 0) : 0u) << (ch * 4 + e);
                     }
                 }
-                return m;
-            };
-            pm0 = word(i0);
-            if (words == 2) pm1 = word(i0 + 32);
+            }
+            if (w == 0) pm0 = m; else pm1 = m;
         }
     }
+    sub[2] = wall_clock64() - stamp0;                         // position words
     // ---- two exclusive scans in one: members before my slot word (high half) / before my position words (low half)
     int members_total;
     {
@@ -636,11 +659,12 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
         if (members_total != (total & 0xffff)) members_total = -1;          // (the two views of the member set disagree: reported)
     }
     __syncthreads();
+    stamp[3] = wall_clock64() - stamp0;                       // member bits by slot and position, prefix sums
     const int l_out = L - (members_total < 0 ? 0 : members_total);
     const bool plan_bad = members_total < 0 || (err_bits != 0);
     const bool apply = !plan_bad && a.out != nullptr && a.L_cap >= (long long)l_out;
     auto members_before_pos = [&](int i) { return pospre[i >> 5] + __popc(posmask[i >> 5] & ((1u << (i & 31)) - 1u)); };
-    auto members_before_slot = [&](int t) { return slotpre[t >> 5] + __popc(slotmask[t >> 5] & ((1u << (t & 31)) - 1u)); };
+    auto members_before_slot = [&](int t) { return slotpre[t >> 5] + __popc(slotword(t >> 5) & ((1u << (t & 31)) - 1u)); };
     if (bid == 0) {
         if (tid < FF_STAT_WORDS) {
             long long vres = 0;
@@ -667,25 +691,84 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
     }
     if (plan_bad) return;                                   // (the host resets the workspace)
 
-    // ---- member / keep / dst: the plan's arrays, a slice per workgroup (the merge kernel that follows a plan-only launch, the
-    // attention-mask gather and the diagnostics read them)
-    {
-        const int b0 = (int)((long long)bid * L / G), b1 = (int)((long long)(bid + 1) * L / G);
-        for (int i = b0 + tid; i < b1; i += kResThreads) {
+    const bool folded = l_out != L;
+    const int b0 = (int)((long long)bid * L / G), b1 = (int)((long long)(bid + 1) * L / G);      // my slice of positions / slots
+    // ---- member / keep / dst: the plan's arrays (the merge kernel that follows a plan-only launch, the attention-mask gather and
+    // the diagnostics read them) and - when the launch folds - the by-patch order of the compacted sequence + its inverse (the
+    // next merge call skips K0).  By `nthr` threads, `rt` of them this one.
+    auto index_roles = [&](int rt, int nthr) {
+        for (int i = b0 + rt; i < b1; i += nthr) {
             const uint32_t mbit = (posmask[i >> 5] >> (i & 31)) & 1u;
             a.keep[i] = (uint8_t)(mbit ^ 1u);
             a.dst[i] = mbit ? -1 : i - members_before_pos(i);
-            a.member[i] = i < nv ? (uint8_t)((slotmask[i >> 5] >> (i & 31)) & 1u) : (uint8_t)0;
+            a.member[i] = i < nv ? (uint8_t)slotbit(i) : (uint8_t)0;
         }
-    }
-    const bool folded = l_out != L;
-    auto readers_leave = [&]() {                            // second count: the last workgroup through resets the word for the next launch
-        if (add_agent(&a.bar->readers[0], 1u) + 1 == 2u * (unsigned)G) st_agent(&a.bar->readers[0], 0u);
+        if (!apply || !folded || !a.order_next) return;
+        for (int t = b0 + rt; t < b1; t += nthr) {
+            int rank, i;
+            if (t < nv) {
+                if (slotbit(t)) continue;
+                rank = t - members_before_slot(t);
+                if constexpr (kHint) i = pos_hint(t);
+                else i = a.order[t];
+            } else {
+                rank = t - members_total;
+                if constexpr (kHint) i = (t - nv) < pre ? (t - nv) : t;
+                else i = a.order[t];
+            }
+            const int np = i - members_before_pos(i);
+            a.order_next[rank] = np;
+            a.inv_next[np] = rank;
+        }
     };
-    if (!apply) {                                           // plan only: ff_ctx_merge_apply follows (it also clears the tables)
-        if (tid == 0) readers_leave();
+    if (!apply) {                                           // plan only: ff_ctx_merge_apply follows
+        index_roles(tid, kResThreads);
         return;
     }
+    // ---- auxiliary rows (position tables, patch types) of the kept positions of my slice: one task = one row of one (tensor,
+    // outer slice), 16 lanes each, kBatch tasks per round with the loads ahead of the stores; by `ngrp` groups of 16 lanes
+    auto aux_roles = [&](int grp, int ngrp, int l16, auto batch) {
+        constexpr int kBatch = decltype(batch)::value;
+        if (!folded || a.aux.n <= 0) return;
+        int per = 0;
+        for (int x = 0; x < a.aux.n; ++x) per += (int)a.aux.a[x].outer;
+        const int T = (b1 - b0) * per;
+        struct Task { const char* sp; char* dq; int rbytes; int fast; };
+        auto task = [&](int t) -> Task {
+            Task k{nullptr, nullptr, 0, 0};
+            if (t < T) {
+                const int i = b0 + t / per;
+                int kq = t % per, x = 0;
+                while (kq >= (int)a.aux.a[x].outer) { kq -= (int)a.aux.a[x].outer; ++x; }
+                if (!((posmask[i >> 5] >> (i & 31)) & 1u)) {
+                    const ff_aux_t& ax = a.aux.a[x];
+                    k.sp = aux_src_row(ax, kq, i, L);
+                    k.dq = (char*)ax.dst + ((int64_t)kq * a.L_cap + (i - members_before_pos(i))) * ax.row_bytes;
+                    k.rbytes = (int)ax.row_bytes;
+                    k.fast = ax.row_bytes <= 256 && !(((uintptr_t)k.sp | (uintptr_t)k.dq | (uintptr_t)ax.row_bytes) & 15);
+                }
+            }
+            return k;
+        };
+        for (int t0 = grp * kBatch; t0 < T; t0 += ngrp * kBatch) {
+            Task k[kBatch];
+            uint4 u[kBatch];
+#pragma unroll
+            for (int z = 0; z < kBatch; ++z) {
+                k[z] = task(t0 + z);
+                u[z] = make_uint4(0, 0, 0, 0);
+                if (k[z].fast && l16 * 16 < k[z].rbytes) u[z] = *(const uint4*)(k[z].sp + l16 * 16);
+            }
+#pragma unroll
+            for (int z = 0; z < kBatch; ++z) {
+                if (k[z].fast && l16 * 16 < k[z].rbytes) *(uint4*)(k[z].dq + l16 * 16) = u[z];
+                if (k[z].sp && !k[z].fast) copy_row(k[z].sp, k[z].dq, k[z].rbytes, l16, 16);       // (odd sizes, long rows)
+            }
+        }
+    };
+    // a wave that holds no rows (rows of fewer than 8 tiles) does the short roles while the others fold: it walks past the fold
+    // below at once
+    const bool spare_wave = nt < kResWaves;
 
     // ======================================================================================================================
     // C. fold + compaction from the resident rows
@@ -693,7 +776,7 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
         const __amdgpu_buffer_rsrc_t ores = make_rsrc(a.out, (uint32_t)(a.L_cap * (long long)rb));
         // member bits of my slots and of the 64 behind them; output row of every anchor (by lane)
         const int js = s0 + lane;
-        const bool mbit = lane < n && ((slotmask[js >> 5] >> (js & 31)) & 1u);
+        const bool mbit = lane < n && slotbit(js);
         const unsigned long long memw = __ballot(mbit);
         int dv = 0;
         if (lane < n && !mbit) {
@@ -705,26 +788,17 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
         float acc[E];
         int open_r = -1, open_n = 0;
         auto flush = [&]() {
+            // T(a / div) == T(a * RN(1 / div)) for every bf16-valued a and divisor T(k): ff_merge_body.h
             float o[E];
             const uint32_t off = (uint32_t)open_r * rb;
             if (open_n > 0) {
-                const float div = A::rnd((float)(open_n + 1));
-                if constexpr (DT == FF_BF16) {
-                    // T(a / div) == T(a * RN(1 / div)) for every bf16-valued a and divisor T(k): ff_merge_body.h
-                    const float r = 1.0f / div;
+                const float r = 1.0f / A::rnd((float)(open_n + 1));
 #pragma unroll
-                    for (int e = 0; e < E; ++e) o[e] = acc[e] * r;
-                    buf_store16s<2>(ores, vcol, off, A::pack_rne(o));
-                    return;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < E; ++e) o[e] = A::rnd(acc[e] / div);
-                }
+                for (int e = 0; e < E; ++e) o[e] = acc[e] * r;
+                buf_store16s<2>(ores, vcol, off, A::pack_rne(o));
             } else {
-#pragma unroll
-                for (int e = 0; e < E; ++e) o[e] = acc[e];
+                buf_store16s<2>(ores, vcol, off, A::pack(acc));
             }
-            buf_store16s<2>(ores, vcol, off, A::pack(o));
         };
         auto take = [&](const uint4& x, int i) {            // i: static row index
             if (!((memw >> i) & 1ull)) {
@@ -743,14 +817,16 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
 #pragma unroll 4
         for (int i = 0; i < RL; ++i)
             if (i < n) take(*lrow(i), i);
+        sub[4] = wall_clock64() - stamp0;                     // LDS rows folded
 #pragma unroll
         for (int i = 0; i < RV; ++i)
             if (RL + i < n) take(v[i], RL + i);
+        sub[5] = wall_clock64() - stamp0;                     // VGPR rows folded
         // the open run may go on in the following segments: those rows come from L2 / the Infinity Cache
         if (open_r >= 0) {
             for (int t = s1; t < nv;) {
                 const int tt = t + lane;
-                const bool mb = tt < nv && ((slotmask[tt >> 5] >> (tt & 31)) & 1u);
+                const bool mb = tt < nv && slotbit(tt);
                 const unsigned long long mw = __ballot(mb);
                 const int run = mw == ~0ull ? kWave : __ffsll((long long)~mw) - 1;      // leading members of this window
                 int iw = 0;
@@ -779,6 +855,7 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
             }
             flush();
         }
+        sub[6] = wall_clock64() - stamp0;                     // runs continued into the next segments
         // non-visual rows (kept as they are): row q of the order's tail goes to workgroup q mod G
         const int n_tail = L - nv;
         for (int qq = bid; qq < n_tail; qq += G) {
@@ -789,68 +866,23 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
             buf_store16s<2>(ores, vcol, (uint32_t)(i - members_before_pos(i)) * rb, x);
         }
     }
-    if (folded) {
-        // ---- auxiliary rows (position tables, patch types): 16 lanes per kept position of my slice
-        if (a.aux.n > 0) {
-            const int b0 = (int)((long long)bid * L / G), b1 = (int)((long long)(bid + 1) * L / G);
-            for (int i = b0 + (tid >> 4); i < b1; i += kResThreads / 16) {
-                if ((posmask[i >> 5] >> (i & 31)) & 1u) continue;
-                const int r = i - members_before_pos(i);
-                for (int x = 0; x < a.aux.n; ++x) {
-                    const ff_aux_t& ax = a.aux.a[x];
-                    for (int64_t ou = 0; ou < ax.outer; ++ou)
-                        copy_row(aux_src_row(ax, ou, i, L), (char*)ax.dst + (ou * a.L_cap + r) * ax.row_bytes, ax.row_bytes, tid & 15, 16);
-                }
-            }
-        }
-        // ---- by-patch order of the compacted sequence + its inverse (the next merge call skips K0)
-        if (a.order_next) {
-            const int b0 = (int)((long long)bid * L / G), b1 = (int)((long long)(bid + 1) * L / G);
-            for (int t = b0 + tid; t < b1; t += kResThreads) {
-                int rank, i;
-                if (t < nv) {
-                    if ((slotmask[t >> 5] >> (t & 31)) & 1u) continue;
-                    rank = t - members_before_slot(t);
-                    if constexpr (kHint) i = pos_hint(t);
-                    else i = a.order[t];
-                } else {
-                    rank = t - members_total;
-                    if constexpr (kHint) i = (t - nv) < pre ? (t - nv) : t;
-                    else i = a.order[t];
-                }
-                const int np = i - members_before_pos(i);
-                a.order_next[rank] = np;
-                a.inv_next[np] = rank;
-            }
-        }
-    }
-    // ---- clear the select tables for the next call - once every workgroup has READ them (counted above; nobody waits for
-    // long: the readers finished a fold phase ago)
-    bool clear_ok = true;
-    if (tid == 0) {
-        for (unsigned spins = 0; ld_agent(&a.bar->readers[0]) < (unsigned)G; ++spins) {
-            __builtin_amdgcn_s_sleep(2);
-            if (spins > (1u << 16)) { clear_ok = false; break; }
-        }
-        bcast[14] = clear_ok ? 1 : 0;
-    }
+    stamp[4] = wall_clock64() - stamp0;                       // my rows folded and written (this wave)
+#ifdef FF_RES_SYNCROLES
     __syncthreads();
-    if (bcast[14]) {
-        if (bid < kL0Copies)
-            for (int z = tid; z < kL0Stride; z += kResThreads) a.l0[bid * kL0Stride + z] = 0;
-        if (tid < n) {
-            const uint32_t key = order_key<DT>(simk[tid]);
-            t16_slice(a.t16_end, (s0 + tid) / kSelSlice)[t16_bin(key)] = 0;
-        }
-    } else if (tid == 0) {
-        atomicOr((unsigned long long*)(a.stats + FF_STAT_ERROR), (unsigned long long)FF_ERR_BIT_RESIDENT);       // (seen by the next call)
+#endif
+    if (!spare_wave) {
+        index_roles(tid, kResThreads);
+        aux_roles(tid >> 4, kResThreads / 16, tid & 15, std::integral_constant<int, 4>{});
+    } else if (wv == kResWaves - 1) {
+        index_roles(lane, kWave);
+        aux_roles(lane >> 4, kWave / 16, lane & 15, std::integral_constant<int, 8>{});
     }
-    __syncthreads();
-    if (tid == 0) {
-        // second count: the last workgroup through resets the word for the next launch
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        readers_leave();
-        if (bid == 0 && folded && a.order_next) {
+    stamp[5] = wall_clock64() - stamp0;                       // short roles done
+    if (bid == 0 && tid == 0) {
+        stamp[6] = wall_clock64() - stamp0;
+        for (int x = 0; x < 7; ++x) a.stats[FF_STAT_T_PLAN + x] = stamp[x];
+        for (int x = 0; x < 8; ++x) a.stats[FF_STAT_T_ORDER + x] = sub[x];
+        if (folded && a.order_next) {
             a.stats[FF_STAT_NV] = nv - (L - l_out);          // the next call (order_valid) skips K0, which would set these
             a.stats[FF_STAT_FTN] = ftn - (L - l_out);
         }
@@ -890,8 +922,6 @@ bool merge_resident_fits(int dtype, int64_t L, int64_t d, int64_t nv, bool adden
 ResBar* ws_resbar(void* ws);
 
 PlanParams merge_plan_params(int dtype, double thr, double sub, double ratio_lb, long long force_k);
-int* ws_l0(void* ws);
-int* ws_t16_end(void* ws, size_t ws_bytes);
 
 template <int DT, bool kHint>
 static int launch_res(const ResArgs& a, int cus, hipStream_t st) {
@@ -925,9 +955,6 @@ int launch_merge_resident(const ResLaunch& p, hipStream_t st) {
     a.inv = p.inv;
     a.hint_pre = (int)p.hint_pre; a.hint_patches = (int)p.hint_patches; a.hint_frames = (int)p.hint_frames;
     a.sim = p.sim;
-    a.l0 = ws_l0(p.ws);
-    a.t16_end = ws_t16_end(p.ws, p.ws_bytes);
-    a.thr = (float)p.thr;
     a.pp = merge_plan_params(p.dtype, p.thr, p.sub, p.ratio_lb, p.force_k);
     a.pp.n_slices = (int)((p.nv + kSelSlice - 1) / kSelSlice);
     a.member = p.member; a.keep = p.keep; a.dst = p.dst;

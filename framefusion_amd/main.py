@@ -73,7 +73,7 @@ class _Scratch:
 
     def ensure(self, L: int):
         if L > self.cap:
-            cap = max(L, 1024)
+            cap = (max(L, 1024) + 63) & ~63          # (whole 16-byte words behind every int32 / T array)
             dev = self.device
             if self.cap and self.last_stream is not None:
                 # kernels of the stream that used the old buffers last may still read them: keep the
