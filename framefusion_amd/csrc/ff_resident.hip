@@ -155,7 +155,9 @@ __device__ inline bool res_barrier(ResBar* gb, int bid, int nwg, unsigned tag) {
             if (wall_clock64() - t0 > 200000) { st_agent(&gb->abort_tag[0], tag); ok = false; break; }
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // (no acquire fence: everything read across workgroups behind the barrier - the similarities, the error word - was stored
+    // write-through / by an atomic and is loaded with agent-scope loads, which do not look at the CU's L1; an L1 invalidation
+    // costs ~1.5 us per workgroup here)
     return ok;
 }
 
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
     const __amdgpu_buffer_rsrc_t sres_rsrc = make_rsrc(a.sim, ((uint32_t)nv * 2u + 15u) & ~15u);
     uint4 kx[kResKeys / 8];
 #pragma unroll
-    for (int x = 0; x < kResKeys / 8; ++x) kx[x] = buf_load16s(sres_rsrc, (uint32_t)(t_base + x * 8) * 2u, 0u);
+    for (int x = 0; x < kResKeys / 8; ++x) kx[x] = buf_load16s<16>(sres_rsrc, (uint32_t)(t_base + x * 8) * 2u, 0u);      // (aux 16 = sc1: agent scope)
     const long long err_bits = (long long)__hip_atomic_load((unsigned long long*)(a.stats + FF_STAT_ERROR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t valid = nv - t_base >= 32 ? 0xffffffffu : (nv - t_base <= 0 ? 0u : (1u << (nv - t_base)) - 1u);
     // raw bits -> keys, both halves of a word at once: negative values are inverted, the others get the sign bit; NaN -> 0xffff
@@ -437,15 +439,16 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
         kk[4 * x] = keys2(kx[x].x); kk[4 * x + 1] = keys2(kx[x].y); kk[4 * x + 2] = keys2(kx[x].z); kk[4 * x + 3] = keys2(kx[x].w);
     }
     auto key_of = [&](int e) -> uint32_t { return (e & 1) ? kk[e >> 1] >> 16 : kk[e >> 1] & 0xffffu; };
+    // (the masks below are built in four independent pieces: one OR chain of 32 links is latency, not work, with two waves per SIMD)
     // threshold set (main.py:113): key >= thr_key and not NaN, as ONE unsigned compare
-    uint32_t thm = 0;
+    uint32_t thm;
     {
         const uint32_t span = 0xffffu - pp.thr_key;
+        uint32_t t4[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int e = 0; e < kResKeys; ++e) thm |= (uint32_t)((key_of(e) - pp.thr_key) < span) << e;
-        thm &= valid;
+        for (int e = 0; e < kResKeys; ++e) t4[e & 3] |= (uint32_t)((key_of(e) - pp.thr_key) < span) << e;
+        thm = ((t4[0] | t4[1]) | (t4[2] | t4[3])) & valid;
     }
-    sub[3] = wall_clock64() - stamp0;                         // keys there, threshold set
     // ---- level 0, speculated: the k-th similarity of a video sits in the binade of typical thresholds (pp.p0_guess, as the
     // three-launch plan guesses): count my keys whose top byte is ABOVE / EQUAL to the guess - both halves of a word at once -
     // and let the totals say whether the guess holds.  (A 256-bin histogram of top bytes in LDS costs microseconds here: a
@@ -455,13 +458,15 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
         int c_ge = 0, c_eq = 0;
         if (valid == 0xffffffffu) {
             const uint32_t G1 = g * 0x00010001u, G8 = g * 0x01000100u;
+            int ce[2] = {0, 0}, cg[2] = {0, 0};
 #pragma unroll
             for (int x = 0; x < kResKeys / 2; ++x) {
                 const uint32_t tb = kk[x] & 0xff00ff00u;
                 const uint32_t z = tb ^ G8;                                              // a half is zero <=> its top byte == g
-                c_eq += __popc((z - 0x00010001u) & ~z & 0x80008000u);
-                c_ge += __popc((((tb >> 8) | 0x01000100u) - G1) & 0x01000100u);          // bit 8 of 0x100 + byte - g
+                ce[x & 1] += __popc((z - 0x00010001u) & ~z & 0x80008000u);
+                cg[x & 1] += __popc((((tb >> 8) | 0x01000100u) - G1) & 0x01000100u);     // bit 8 of 0x100 + byte - g
             }
+            c_eq = ce[0] + ce[1]; c_ge = cg[0] + cg[1];
         } else {
 #pragma unroll
             for (int e = 0; e < kResKeys; ++e) {
@@ -474,9 +479,9 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
         wave_sum4_dpp63(r0, r1, r2, r3);
         if (lane == 63) { atomicAdd(&hcnt[0], (int)r0); atomicAdd(&hcnt[1], (int)r1); atomicAdd(&hcnt[2], (int)r2); }
     }
-    __syncthreads();
+    __syncthreads();                                         // #1
     sub[7] = wall_clock64() - stamp0;                         // level-0 counts
-    // pick: the bin of the rem-th largest entry of a 256-bin histogram (+ more copies of it), and the entries above it
+    // pick: the bin of the rem-th largest entry of a 256-bin histogram (+ more copies of it), and the entries above it - by one wave
     auto pick = [&](const int* h, int copies, int rem, int& bin, int& above) {
         const int top = 255 - 4 * lane;
         int vv[4];
@@ -496,180 +501,182 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
         bin = __builtin_amdgcn_readlane(bsel, first);
         above = __builtin_amdgcn_readlane(ab, first);
     };
-    if (wv == 0) {
-        const int cnt = hcnt[0];
-        bool topk;
+    // ---- the decision, by every wave for itself (the same scalars from the same LDS words: no broadcast, no barrier)
+    const int count = uniform(hcnt[0]);
+    bool is_topk;
+    int k_sel;
+    {
         long long k;
         if (pp.k_given >= 0) {
-            topk = true;                                  // fixed-sparsity policy (modeling_qwen2_baseline.py:920,1001)
+            is_topk = true;                               // fixed-sparsity policy (modeling_qwen2_baseline.py:920,1001)
             k = pp.k_given > nv ? (long long)nv : pp.k_given;
         } else {
             // main.py:114-116 in double, as python: ratio = count / ftn ; ratio < sub ?
-            const double ratio = ftn > 0 ? (double)cnt / (double)ftn : 0.0;
-            topk = !(ratio < pp.sub);
+            const double ratio = ftn > 0 ? (double)count / (double)ftn : 0.0;
+            is_topk = !(ratio < pp.sub);
             k = 0;
-            if (topk) {
+            if (is_topk) {
                 k = (long long)(pp.sub * (double)ftn);   // int(sub * ftn), main.py:122
                 if (k > nv) k = nv;
                 if (k < 0) k = 0;
             }
         }
-        const int above = hcnt[1], at = hcnt[2];
-        const bool held = topk && k > 0 && above < (int)k && (int)k <= above + at;
-        if (lane == 0) {
-            bcast[0] = topk ? 1 : 0; bcast[1] = cnt; bcast[2] = (int)k; bcast[3] = pp.p0_guess; bcast[4] = (int)k - above; bcast[9] = -1;
-            bcast[10] = (topk && k > 0 && !held) ? 1 : 0;                           // the guess failed: the general level 0 below
-        }
+        k_sel = uniform((int)k);
     }
-    __syncthreads();
-    if (bcast[10]) {                                         // (uniform; rare)
-        // the 256-bin histogram after all: runs of equal top bytes counted in registers, one LDS atomic per change
-        int cur = -1, run = 0;
-#pragma unroll
-        for (int e = 0; e < kResKeys; ++e) {
-            const int tb = ((valid >> e) & 1u) ? (int)(key_of(e) >> 8) : -1;
-            if (tb != cur) {
-                if (cur >= 0) atomicAdd(&hist0[cur], run);
-                cur = tb; run = 0;
-            }
-            ++run;
-        }
-        if (cur >= 0) atomicAdd(&hist0[cur], run);
-        __syncthreads();
-        if (wv == 0) {
-            int bin, above;
-            pick(hist0, 1, bcast[2], bin, above);
-            if (lane == 0) { bcast[3] = bin; bcast[4] = bcast[2] - above; }
-        }
-        __syncthreads();
-    }
-    __syncthreads();
-    const bool is_topk = bcast[0] != 0;
-    const int count = bcast[1], k_sel = bcast[2];
     const bool topk = is_topk && k_sel > 0;
     uint32_t kth = 0;
-    int need = 0, tstar = -1;
+    int need = 0;
     uint32_t mm;
     if (topk) {                                              // (uniform)
+        int p0 = pp.p0_guess, rem = k_sel - uniform(hcnt[1]);
+        if (!(rem >= 1 && rem <= uniform(hcnt[2]))) {
+            // the guess failed (rare): the 256-bin histogram after all - runs of equal top bytes counted in registers, one LDS
+            // atomic per change
+            int cur = -1, run = 0;
+#pragma unroll
+            for (int e = 0; e < kResKeys; ++e) {
+                const int tb = ((valid >> e) & 1u) ? (int)(key_of(e) >> 8) : -1;
+                if (tb != cur) {
+                    if (cur >= 0) atomicAdd(&hist0[cur], run);
+                    cur = tb; run = 0;
+                }
+                ++run;
+            }
+            if (cur >= 0) atomicAdd(&hist0[cur], run);
+            __syncthreads();
+            int above;
+            pick(hist0, 1, k_sel, p0, above);
+            rem = k_sel - above;
+        }
         // level 1: the low bytes of the keys whose top byte is the k-th key's, 8 copies against same-bin collisions
-        const uint32_t p0 = (uint32_t)bcast[3];
         int* h1 = hist1 + (lane & 7) * 256;
 #pragma unroll
         for (int e = 0; e < kResKeys; ++e) {
             const uint32_t key = key_of(e);
-            atomicAdd(&h1[key & 0xffu], (int)(((valid >> e) & 1u) & (uint32_t)((key >> 8) == p0)));
+            atomicAdd(&h1[key & 0xffu], (int)(((valid >> e) & 1u) & (uint32_t)((key >> 8) == (uint32_t)p0)));
         }
-        __syncthreads();
-        if (wv == 0) {
-            int p1, above;
-            pick(hist1, 8, bcast[4], p1, above);
-            if (lane == 0) { bcast[5] = (int)((p0 << 8) | (uint32_t)p1); bcast[6] = bcast[4] - above; }
+        __syncthreads();                                     // #2
+        if (tid < 256) {
+            int sum8 = 0;
+#pragma unroll
+            for (int x = 0; x < 8; ++x) sum8 += hist1[x * 256 + tid];
+            hist0[tid] = sum8;                               // (level 0's bins are not needed any more)
         }
-        __syncthreads();
-        kth = (uint32_t)bcast[5];
-        need = bcast[6];
+        __syncthreads();                                     // #2b
+        int p1, above1;
+        pick(hist0, 1, rem, p1, above1);
+        kth = ((uint32_t)p0 << 8) | (uint32_t)p1;
+        need = rem - above1;
         stamp[2] = wall_clock64() - stamp0;                   // decision + k-th key known
-        uint32_t eqm = 0, gtm = 0;
+        uint32_t e4[4] = {0u, 0u, 0u, 0u}, g4[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int e = 0; e < kResKeys; ++e) {
             const uint32_t key = key_of(e);
-            eqm |= (uint32_t)(key == kth) << e;
-            gtm |= (uint32_t)(key > kth) << e;
+            e4[e & 3] |= (uint32_t)(key == kth) << e;
+            g4[e & 3] |= (uint32_t)(key > kth) << e;
         }
-        eqm &= valid; gtm &= valid;
+        const uint32_t eqm = ((e4[0] | e4[1]) | (e4[2] | e4[3])) & valid, gtm = ((g4[0] | g4[1]) | (g4[2] | g4[3])) & valid;
         sub[0] = wall_clock64() - stamp0;                     // key masks
-        // t*: the slot of the need-th entry equal to the k-th key (ties taken in ascending by-patch position)
+        // ties at the k-th value are taken in ascending by-patch position: I take those of mine whose rank among all ties is
+        // below `need`
         const int mine = __popc(eqm);
         const int wincl = wave_incl_scan_dpp(mine);
         if (lane == 63) scratch[wv] = wincl;
-        __syncthreads();
+        __syncthreads();                                     // #3
         int ex = wincl - mine;
 #pragma unroll
         for (int x = 0; x < kResWaves; ++x) ex += x < wv ? scratch[x] : 0;
-        if (ex < need && need <= ex + mine) {
+        const int take_n = need - ex;
+        uint32_t tie = take_n >= mine ? eqm : 0u;
+        if (take_n > 0 && take_n < mine) {
             uint32_t m = eqm;
-            for (int x = ex + 1; x < need; ++x) m &= m - 1;        // drop the lowest set bit need - ex - 1 times
-            bcast[9] = t_base + (__ffs((int)m) - 1);
+            for (int x = 0; x < take_n; ++x) { tie |= m & (0u - m); m &= m - 1; }        // the lowest take_n set bits
         }
-        __syncthreads();
-        tstar = bcast[9];
-        const int upto = tstar - t_base;                    // ties at slots <= t* are taken
-        const uint32_t tie_take = upto >= 31 ? 0xffffffffu : upto < 0 ? 0u : ((2u << upto) - 1u);
-        mm = gtm | (eqm & tie_take);
+        mm = gtm | tie;
     } else {
         stamp[2] = wall_clock64() - stamp0;
         mm = is_topk ? 0u : thm;
     }
     if (tid == 0) mm &= ~1u;                                // slot 0 never folds
-    sub[1] = wall_clock64() - stamp0;                         // tie slot, member bits of my slots
+    sub[1] = wall_clock64() - stamp0;                         // member bits of my slots
     slotword(tid) = mm;
-    __syncthreads();
-    // ---- member bits by POSITION: thread t owns positions [ppt * t, ppt * (t + 1)), ppt = 32 or 64
-    const int words = L > kResMaxNv ? 2 : 1;
-    uint32_t pm0 = 0u, pm1 = 0u;
+    __syncthreads();                                         // #4
+    // ---- member bits by POSITION: position i = 512 e + tid in round e, so that the lanes of a wave look at 64 consecutive
+    // positions (their slots lie F / 32 words apart: no bank pile-up) and ONE ballot is two words of the position bitmap
     {
-        const int i0 = tid * 32 * words;
-        const __amdgpu_buffer_rsrc_t irs = make_rsrc(a.inv, ((uint32_t)L * 4u + 15u) & ~15u);      // (whole words: see `sim` above)
-#pragma unroll 1
-        for (int w = 0; w < words; ++w) {
-            const int ib = i0 + w * 32;
-            uint32_t m = 0;
+        const int rounds = (L + kResThreads - 1) / kResThreads;
+        const __amdgpu_buffer_rsrc_t irs = make_rsrc(a.inv, (uint32_t)L * 4u);
+        int pf = 0, pp_ = 0, q512 = 0, r512 = 0, shift_f = 0;
+        if constexpr (kHint) {
+            // x = i - pre = f * P + p inside the visual span; kept non-negative by `shift_f` whole frames for the division
+            shift_f = (pre + P - 1) / P;
+            const unsigned xx = (unsigned)(tid - pre + shift_f * P);
+            pf = (int)(xx / (unsigned)P); pp_ = (int)(xx - (unsigned)pf * (unsigned)P);
+            q512 = kResThreads / P; r512 = kResThreads - q512 * P;
+        }
+        auto slot_of = [&](int e, bool& in) -> int {      // the slot of position 512 e + tid (0 if it has none)
+            const int i = e * kResThreads + tid;
+            int sl;
             if constexpr (kHint) {
-                // 32 consecutive positions touch at most two frames (patch_num >= 32: the launcher's condition): position
-                // x = f * P + p of the visual span sits at slot p * F + f
-                const int x = ib - pre;
-                const int base = x > 0 ? x : 0;
-                const int f0 = base / P;
-                const int d0 = x - f0 * P;                      // (may be negative before the span: masked by `in`)
-#pragma unroll
-                for (int e = 0; e < 32; ++e) {
-                    const bool in = (unsigned)(x + e) < (unsigned)nv;
-                    const int dd = d0 + e;
-                    const int pe = dd < P ? dd : dd - P, fe = dd < P ? f0 : f0 + 1;
-                    const int sl = in ? pe * F + fe : 0;
-                    m |= (in ? slotbit(sl) : 0u) << e;
-                }
+                in = (unsigned)(i - pre) < (unsigned)nv;
+                sl = in ? pp_ * F + (pf - shift_f) : 0;
+                pp_ += r512; pf += q512;
+                if (pp_ >= P) { pp_ -= P; ++pf; }
             } else {
-#pragma unroll 2
-                for (int ch = 0; ch < 8; ++ch) {
-                    const uint4 a0 = buf_load16s(irs, (uint32_t)(ib + ch * 4) * 4u, 0u);          // (past L: masked below)
-                    const uint32_t sl[4] = {a0.x, a0.y, a0.z, a0.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const bool in = ib + ch * 4 + e < L && sl[e] < (uint32_t)nv;
-                        m |= (in ? slotbit(in ? (int)sl[e] : 0) : 0u) << (ch * 4 + e);
-                    }
-                }
+                const uint32_t sv = i < L ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(irs, i * 4, 0, 0) : 0xffffffffu;
+                in = sv < (uint32_t)nv;
+                sl = in ? (int)sv : 0;
             }
-            if (w == 0) pm0 = m; else pm1 = m;
+            return sl;
+        };
+        for (int e = 0; e < rounds; e += 4) {                // (rounds past the end: positions >= L have no slot)
+            bool in0, in1, in2, in3;
+            const int s0_ = slot_of(e, in0), s1_ = slot_of(e + 1, in1), s2_ = slot_of(e + 2, in2), s3_ = slot_of(e + 3, in3);
+            const uint32_t b0_ = slotbit(s0_), b1_ = slotbit(s1_), b2_ = slotbit(s2_), b3_ = slotbit(s3_);
+            const unsigned long long w0 = __ballot(in0 && b0_), w1 = __ballot(in1 && b1_), w2 = __ballot(in2 && b2_), w3 = __ballot(in3 && b3_);
+            if (lane < 8) {
+                const unsigned long long wsel = (lane >> 1) == 0 ? w0 : (lane >> 1) == 1 ? w1 : (lane >> 1) == 2 ? w2 : w3;
+                const int word = (e + (lane >> 1)) * 16 + wv * 2 + (lane & 1);
+                if (word < 1024) posmask[word] = (uint32_t)(wsel >> (32 * (lane & 1)));
+            }
         }
     }
+    __syncthreads();                                         // #5
     sub[2] = wall_clock64() - stamp0;                         // position words
-    // ---- two exclusive scans in one: members before my slot word (high half) / before my position words (low half)
+    // ---- two exclusive scans in one: members before my slot word (high half) / before my two position words (low half)
     int members_total;
     {
-        const int packed = (__popc(mm) << 16) | (__popc(pm0) + __popc(pm1));
-        int total;
-        const int ex = block_excl_scan<kResWaves>(packed, scratch, total);
+        const int nw = (L + 31) >> 5;
+        const uint32_t w0 = 2 * tid < nw ? posmask[2 * tid] : 0u, w1 = 2 * tid + 1 < nw ? posmask[2 * tid + 1] : 0u;
+        const int packed = (__popc(mm) << 16) | (__popc(w0) + __popc(w1));
+        const int wincl = wave_incl_scan_dpp(packed);
+        if (lane == 63) scratch[16 + wv] = wincl;
+        __syncthreads();                                     // #6
+        int ex = wincl - packed, total = 0;
+#pragma unroll
+        for (int x = 0; x < kResWaves; ++x) { const int t = scratch[16 + x]; ex += x < wv ? t : 0; total += t; }
         slotpre[tid] = ex >> 16;
-        const int pb = ex & 0xffff;
-        if (words == 1) { posmask[tid] = pm0; pospre[tid] = pb; }
-        else { posmask[2 * tid] = pm0; pospre[2 * tid] = pb; posmask[2 * tid + 1] = pm1; pospre[2 * tid + 1] = pb + __popc(pm0); }
+        pospre[2 * tid] = ex & 0xffff;
+        pospre[2 * tid + 1] = (ex & 0xffff) + __popc(w0);
         members_total = total >> 16;
         if (members_total != (total & 0xffff)) members_total = -1;          // (the two views of the member set disagree: reported)
     }
-    __syncthreads();
+    __syncthreads();                                         // #7
     stamp[3] = wall_clock64() - stamp0;                       // member bits by slot and position, prefix sums
     const int l_out = L - (members_total < 0 ? 0 : members_total);
     const bool plan_bad = members_total < 0 || (err_bits != 0);
     const bool apply = !plan_bad && a.out != nullptr && a.L_cap >= (long long)l_out;
     auto members_before_pos = [&](int i) { return pospre[i >> 5] + __popc(posmask[i >> 5] & ((1u << (i & 31)) - 1u)); };
     auto members_before_slot = [&](int t) { return slotpre[t >> 5] + __popc(slotword(t >> 5) & ((1u << (t & 31)) - 1u)); };
-    if (bid == 0) {
-        if (tid < FF_STAT_WORDS) {
+    if (bid == 0 && wv == kResWaves - 1) {
+        // the result block leaves through the last wave of workgroup 0 (the one that holds no rows when the rows have fewer than
+        // 8 tiles): one lane per word, no LDS, no workgroup barrier - the other waves are already folding
+        long long e = err_bits;
+        if (members_total < 0) e |= FF_ERR_BIT_RESIDENT;
+        if (lane < FF_STAT_WORDS && lane != FF_STAT_SEQ) {
             long long vres = 0;
             const double ratio = ftn > 0 ? (double)count / (double)ftn : 0.0;
-            switch (tid) {
+            switch (lane) {
                 case FF_STAT_NV: vres = nv; break;
                 case FF_STAT_FTN: vres = ftn; break;
                 case FF_STAT_COUNT: vres = count; break;
@@ -683,11 +690,14 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
                 case FF_STAT_APPLIED: vres = apply ? 1 : 0; break;
                 default: break;
             }
-            sres[tid] = vres;
+            if (e) vres = 0;
+            if (lane == FF_STAT_ERROR) vres = e;
+            if (!e && lane != FF_STAT_ERROR && lane < FF_STAT_T_ORDER) a.stats[lane] = vres;
+            if (lane == FF_STAT_ERROR) a.stats[lane] = 0;                       // reported: the next call starts clean
+            __hip_atomic_store(&a.host_mapped[lane], vres, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
-        long long e = err_bits;
-        if (members_total < 0) e |= FF_ERR_BIT_RESIDENT;
-        publish_words(e != 0, e);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        if (lane == 0) __hip_atomic_store(&a.host_mapped[FF_STAT_SEQ], (int64_t)a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (plan_bad) return;                                   // (the host resets the workspace)
 
