@@ -59,7 +59,7 @@ class FFMergeCall(C.Structure):
                 ("force_k", C.c_int64), ("fold", C.c_int64),
                 ("hint_pre", C.c_int64), ("hint_frames", C.c_int64), ("stream", C.c_void_p), ("n_aux", C.c_int64),
                 ("aux", FFAux * MAX_AUX),
-                ("mask", C.c_void_p), ("mask_out", C.c_void_p), ("mask_elem_bytes", C.c_int64)]
+                ("mask", C.c_void_p), ("mask_out", C.c_void_p), ("mask_elem_bytes", C.c_int64), ("late_outputs", C.c_int64)]
 
 
 # head of ff_merge_call_t up to and including n_aux; MAX_AUX aux entries (AUX_ENTRY: 5 x 8 bytes each) and the mask triple follow
@@ -68,6 +68,7 @@ MERGE_CALL_AUX_OFFSET = MERGE_CALL_HEAD.size
 AUX_ENTRY = struct.Struct("=2Q3q")
 MERGE_CALL_MASK_OFFSET = MERGE_CALL_AUX_OFFSET + MAX_AUX * AUX_ENTRY.size
 MASK_TRIPLE = struct.Struct("=2Qq")
+MERGE_CALL_LATE_OFFSET = MERGE_CALL_MASK_OFFSET + MASK_TRIPLE.size
 
 
 class FFMergeResult(C.Structure):
@@ -155,12 +156,15 @@ PROTOTYPES = {
     "ff_ctx_merge_submit": (_i32, [_vp, _vp]),
     "ff_ctx_merge_collect": (_i32, [_vp, _vp, _vp]),
     "ff_ctx_merge_one_launch": (_i32, [_vp, _vp]),
+    "ff_ctx_merge_mail": (_i32, [_vp, _vp]),
     "ff_ctx_prune": (_i32, [_vp, _vp]),
     "ff_ctx_prune_from_qk": (_i32, [_vp, _vp, _vp]),
     "ff_ctx_gather_mask": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "ff_ctx_reset": (_i32, [_vp, _vp]),
     "ff_ctx_expect_tables": (None, [_vp]),
     "ff_abi_sizeof": (_sz, [_i32]),
+    "ff_host_alloc": (_vp, [_sz]),
+    "ff_host_free": (None, [_vp]),
     "ff_ctx_last_query_importance": (_i32, [_vp, _vp, _vp, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f64, _i32, _vp, _vp, _i64, _i64,
                                             _i64, _vp, _sz, _vp]),
     "ff_merge_step": (_i32, [_vp, _vp, _vp, _i32, _i64, _i64, _i64, _vp, _i64, _i32, _f64, _f64, _f64, _vp, _vp, _vp, _vp,

@@ -1,6 +1,8 @@
 // C-ABI glue: version, error strings, workspace sizing and the fused merge step that enqueues
 // K0 -> K1 -> K2+K3 -> K4 from a single host call (one FrameFusion.forward merge call,
 // framefusion/main.py:104-138).
+#include <string.h>
+
 #include "ff_common.h"
 #include "ff_resident.h"
 #include "ff_source_hash.h"
@@ -25,7 +27,7 @@ int launch_merge_compact(const void* hidden, const void* addend, void* hidden_ou
                          const uint8_t* keep, const ff_aux_t* aux_host, int n_aux, int32_t* order_next,
                          int32_t* inv_next, int64_t* stats, hipStream_t st, bool skip_identity, void* zero_a,
                          size_t zero_a_bytes, const void* zero_keys, int64_t zero_n, int zero_key_dt, int* t16_end,
-                         const int32_t* src, int64_t l_out);
+                         const int32_t* src, int64_t l_out, int64_t guard_lout = -1);
 int launch_similarity_any(const void* hidden, const void* addend, int dtype, int64_t L, int64_t d, const int64_t* ptype,
                           int32_t* order, int32_t* inv, int64_t* stats, void* sim, int* l0, int* t16_end, double thr,
                           int64_t hint_pre, int64_t hint_patches, int64_t hint_frames, hipStream_t st);
@@ -93,13 +95,14 @@ static int merge_finish(const void* hidden, const void* addend, void* hidden_out
                         const int32_t* order, const int32_t* inv, const void* sim, uint8_t* member, int32_t* dst,
                         uint8_t* keep, int64_t* stats, int64_t* stats_host_mapped, int64_t seq, const ff_aux_t* aux_host,
                         int n_aux, int32_t* order_next, int32_t* inv_next, void* ws, size_t ws_bytes,
-                        ff_stream_t stream, int phase = 3, int64_t min_cap = -1) {
+                        ff_stream_t stream, int phase = 3, int64_t min_cap = -1, bool guarded = false) {
     // phase: 1 = the plan only (no output field is looked at), 2 = the merge kernel only (behind a plan whose result the caller
-    // has seen: L_cap >= min_cap = its l_out is enough), 3 = both (L_cap >= L: the output length is not known yet)
+    // has seen: L_cap >= min_cap = its l_out is enough), 3 = both (L_cap >= L: the output length is not known yet - or `guarded`:
+    // buffers of a GUESSED length; the merge kernel writes nothing unless the plan's l_out is exactly L_cap)
     if (!hidden || (!hidden_out && (phase & 2)) || !order || !inv || !sim || !member || !dst || !keep || !stats || !ws) return FF_ERR_ARG;
     if ((order_next == nullptr) != (inv_next == nullptr)) return FF_ERR_ARG;
     if (ws_bytes < ff_workspace_bytes(L, 1)) return FF_ERR_WORKSPACE;
-    if ((phase & 2) && L_cap < (phase == 3 ? L : min_cap)) return FF_ERR_ARG;
+    if ((phase & 2) && L_cap < (phase == 3 ? (guarded ? 1 : L) : min_cap)) return FF_ERR_ARG;
     if (dtype != FF_F32 && dtype != FF_BF16 && dtype != FF_F16) return FF_ERR_ARG;
     if (n_aux < 0 || n_aux > FF_MAX_AUX || (n_aux > 0 && !aux_host)) return FF_ERR_ARG;
     const int64_t esz = dtype == FF_F32 ? 4 : 2;
@@ -121,7 +124,7 @@ static int merge_finish(const void* hidden, const void* addend, void* hidden_out
     if (rc || !(phase & 2)) return rc;
     return ff::launch_merge_compact(hidden, addend, hidden_out, dtype, L, d, L_cap, order, member, fold, dst, keep, aux_host,
                                     n_aux, order_next, inv_next, stats, (hipStream_t)stream, true, za, zab, sim, L, dtype,
-                                    ff::ws_t16_end(ws, ws_bytes), nullptr, -1);
+                                    ff::ws_t16_end(ws, ws_bytes), nullptr, -1, (guarded && phase == 3 && L_cap < L) ? L_cap : -1);
 }
 
 extern "C" int ff_merge_finish(const void* hidden, const void* addend, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
@@ -252,6 +255,16 @@ extern "C" int ff_ctx_reset(ff_ctx_t* c, ff_stream_t stream) {
     return ctx_clean(c, (hipStream_t)stream);
 }
 
+extern "C" void* ff_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) return nullptr;
+    memset(p, 0, bytes);
+    return p;
+}
+extern "C" void ff_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
 extern "C" size_t ff_abi_sizeof(int which) {
     switch (which) {
         case 0: return sizeof(ff_ctx_t);
@@ -333,12 +346,12 @@ static int ctx_wait(ff_ctx_t* c, hipStream_t st, int64_t* waited_ns) {
     return rc;
 }
 
-static int ctx_finish_enqueue(ff_ctx_t* c, const ff_merge_call_t* a, int phase = 3, int64_t min_cap = -1) {
+static int ctx_finish_enqueue(ff_ctx_t* c, const ff_merge_call_t* a, int phase = 3, int64_t min_cap = -1, bool guarded = false) {
     if (a->fold != FF_FOLD_SEQUENTIAL && a->fold != FF_FOLD_MEAN) return FF_ERR_ARG;
     int rc = merge_finish(a->hidden, a->addend, a->hidden_out, (int)a->dtype, a->L, a->d, a->L_cap, a->threshold, a->sub,
                           a->ratio_lb, a->force_k < 0 ? -1 : (long long)a->force_k, (int)a->fold, c->order, c->inv, c->sim,
                           c->member, c->dst, c->keep, c->stats, c->stats_host, c->seq, a->aux, (int)a->n_aux, c->order_next,
-                          c->inv_next, c->ws, c->ws_bytes, a->stream, phase, min_cap);
+                          c->inv_next, c->ws, c->ws_bytes, a->stream, phase, min_cap, guarded);
     if (rc) return rc;
     if (phase & 2) c->dirty = 0;           // (the merge kernel is what clears the select tables)
     return rc;
@@ -353,11 +366,12 @@ static int ctx_finish(ff_ctx_t* c, const ff_merge_call_t* a, ff_merge_result_t* 
     r->unhinted = 0;
     r->wait_ns = 0;
     r->applied = 0;
-    bool resident = c->res_active != 0;            // the first attempt is the one-launch kernel
+    bool resident = c->res_active == 1;            // the first attempt is the one-launch kernel
+    const bool guarded = c->res_active == 2;       // ... or three launches, the merge kernel blind into buffers of a guessed length
     c->res_active = 0;
     for (int attempt = 0;; ++attempt) {
         if (!(enqueued && attempt == 0)) {
-            rc = ctx_finish_enqueue(c, a, phase);
+            rc = ctx_finish_enqueue(c, a, phase, -1, guarded && phase == 3);
             if (rc) { c->dirty = 1; c->order_len = 0; return rc; }
         }
         int64_t waited = 0;
@@ -395,8 +409,10 @@ static int ctx_finish(ff_ctx_t* c, const ff_merge_call_t* a, ff_merge_result_t* 
         r->k = h[FF_STAT_K];
         r->l_out = h[FF_STAT_LOUT];
         if (resident) {
-            if (h[FF_STAT_APPLIED]) c->dirty = 0;       // (it has cleared the select tables itself)
+            if (h[FF_STAT_APPLIED]) c->dirty = 0;       // (the one-launch kernel leaves the select tables alone)
             else phase = 1;                              // the plan only: the merge kernel is still to come
+        } else if (guarded && phase == 3 && r->l_out != a->L && r->l_out != a->L_cap) {
+            phase = 1;                                   // the blind merge kernel found another length than its buffers': nothing written
         }
         break;
     }
@@ -491,18 +507,24 @@ extern "C" int ff_ctx_merge_submit(ff_ctx_t* c, const ff_merge_call_t* a) {
     bool hinted = false;
     if (c->res_off > 0) c->res_off -= 1;
     if (!ctx_resident(c, a, &nv, &ftn, &hinted)) {
+        if (a->late_outputs) return FF_ERR_ARG;          // (outputs by mail: the one-launch kernel only)
         c->res_off += c->res_off > 0 ? 1 : 0;            // (ff_ctx_merge_begin counts the call)
         rc = ff_ctx_merge_begin(c, a);
         if (rc) return rc;
         if (a->mask && !a->mask_out) rc = FF_ERR_ARG;
-        if (!rc) rc = ctx_finish_enqueue(c, a);
+        // buffers of fewer than L rows: exactly sized outputs for a GUESSED length (the top-k branch's, main.py:122) - the merge
+        // kernel goes out blind all the same and writes nothing unless the plan's l_out is that length (collect: applied = 0)
+        const bool guarded = a->hidden_out && a->L_cap < a->L;
+        if (!rc) rc = ctx_finish_enqueue(c, a, 3, -1, guarded);
         if (rc) { c->in_flight = 0; c->dirty = 1; c->order_len = 0; return rc; }
         c->in_flight = 4;                    // submitted: only ff_ctx_merge_collect may follow
+        c->res_active = guarded ? 2 : 0;
         return FF_OK;
     }
     if (a->mask && !a->mask_out && a->hidden_out) return FF_ERR_ARG;
-    for (int x = 0; x < (a->hidden_out ? (int)a->n_aux : 0); ++x)
-        if (!a->aux[x].src || !a->aux[x].dst || a->aux[x].row_bytes < 1 || a->aux[x].outer < 1 || a->aux[x].src_outer_bytes < 0) return FF_ERR_ARG;
+    const bool late = a->late_outputs != 0;
+    for (int x = 0; x < ((a->hidden_out || late) ? (int)a->n_aux : 0); ++x)
+        if (!a->aux[x].src || (!late && !a->aux[x].dst) || a->aux[x].row_bytes < 1 || a->aux[x].outer < 1 || a->aux[x].src_outer_bytes < 0) return FF_ERR_ARG;
     hipStream_t st = (hipStream_t)a->stream;
     rc = ctx_clean(c, st);
     if (rc) return rc;
@@ -518,10 +540,36 @@ extern "C" int ff_ctx_merge_submit(ff_ctx_t* c, const ff_merge_call_t* a) {
     p.stats = c->stats; p.host_mapped = c->stats_host; p.seq = c->seq; p.aux = a->aux; p.n_aux = (int)a->n_aux;
     p.thr = a->threshold; p.sub = a->sub; p.ratio_lb = a->ratio_lb; p.force_k = a->force_k < 0 ? -1 : (long long)a->force_k;
     p.ws = c->ws; p.ws_bytes = c->ws_bytes;
+    p.mail = nullptr;
+    if (late) {
+        // the outputs follow by mail: the slot is invalidated first (plain host stores; the kernel compares the sequence word)
+        volatile int64_t* m = c->stats_host + FF_MAIL_WORD;
+        m[0] = 0;
+        p.mail = c->stats_host + FF_MAIL_WORD;
+        p.hidden_out = nullptr; p.L_cap = 0;
+    }
     rc = ff::launch_merge_resident(p, st);
     if (rc) { c->order_len = 0; return rc; }
     c->in_flight = 4;
     c->res_active = 1;
+    return FF_OK;
+}
+
+extern "C" int ff_ctx_merge_mail(ff_ctx_t* c, const ff_merge_call_t* a) {
+    if (!a) return FF_ERR_ARG;
+    int rc = ctx_check(c, a->L);
+    if (rc) return rc;
+    if (c->in_flight != 4 || c->res_active != 1) return FF_ERR_STATE;
+    if (a->n_aux < 0 || a->n_aux > FF_MAX_AUX) return FF_ERR_ARG;
+    if ((uintptr_t)a->hidden_out & 15) return FF_ERR_ALIGN;
+    for (int x = 0; x < (a->hidden_out ? (int)a->n_aux : 0); ++x)
+        if (!a->aux[x].dst) return FF_ERR_ARG;
+    int64_t* m = c->stats_host + FF_MAIL_WORD;
+    m[1] = (int64_t)(uintptr_t)a->hidden_out;
+    m[2] = a->hidden_out ? a->L_cap : 0;
+    m[3] = a->hidden_out ? a->n_aux : 0;
+    for (int x = 0; x < FF_MAX_AUX; ++x) m[4 + x] = x < a->n_aux ? (int64_t)(uintptr_t)a->aux[x].dst : 0;
+    __atomic_store_n(&m[0], c->seq, __ATOMIC_RELEASE);
     return FF_OK;
 }
 

@@ -29,10 +29,10 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_compact(
     const int32_t* __restrict__ order, const uint8_t* __restrict__ member, int fold,
     const int32_t* __restrict__ dst, const uint8_t* __restrict__ keep, AuxPack aux, int n_main,
     int n_aux_blocks, int n_next_blocks, int32_t* __restrict__ order_next, int32_t* __restrict__ inv_next,
-    int64_t* __restrict__ stats, const int64_t* __restrict__ identity_stats, ZeroJob zero, int slots) {
+    int64_t* __restrict__ stats, const int64_t* __restrict__ identity_stats, ZeroJob zero, int slots, long long guard_lout) {
     merge_compact_body<DT, kAdd>(hidden, addend, out, row_bytes, L, L_cap, order, member, fold, dst, keep, aux, n_main,
                                  n_aux_blocks, n_next_blocks, order_next, inv_next, stats, identity_stats, zero, slots,
-                                 (int)blockIdx.x, (int)blockIdx.y);
+                                 (int)blockIdx.x, (int)blockIdx.y, guard_lout);
 }
 
 // The prune's gather by OUTPUT rows (prune_gather_body) + the short roles of a prune launch: auxiliary rows, table clearing.
@@ -181,7 +181,7 @@ int launch_merge_compact(const void* hidden, const void* addend, void* hidden_ou
                          const uint8_t* keep, const ff_aux_t* aux_host, int n_aux, int32_t* order_next,
                          int32_t* inv_next, int64_t* stats, hipStream_t st, bool skip_identity, void* zero_a,
                          size_t zero_a_bytes, const void* zero_keys, int64_t zero_n, int zero_key_dt, int* t16_end,
-                         const int32_t* src, int64_t l_out) {
+                         const int32_t* src, int64_t l_out, int64_t guard_lout) {
     AuxPack pack;
     pack.n = keep ? n_aux : 0;
     for (int x = 0; x < pack.n; ++x) pack.a[x] = aux_host[x];
@@ -225,7 +225,7 @@ int launch_merge_compact(const void* hidden, const void* addend, void* hidden_ou
 #define FF_MC_LAUNCH(DT, ADD)                                                                                          \
     hipLaunchKernelGGL((k_merge_compact<DT, ADD>), grid, dim3(kMergeThreads), 0, st, h, (const char*)addend, o,          \
                        (uint32_t)row_bytes, (int)L, L_cap, order, member, fold, dst, keep, pack, n_main, n_aux_blocks,  \
-                       n_next_blocks, order_next, inv_next, stats, ident, zero, slots)
+                       n_next_blocks, order_next, inv_next, stats, ident, zero, slots, (long long)guard_lout)
     switch (dtype) {
         case FF_F32: if (addend) FF_MC_LAUNCH(FF_F32, true); else FF_MC_LAUNCH(FF_F32, false); break;
         case FF_BF16: if (addend) FF_MC_LAUNCH(FF_BF16, true); else FF_MC_LAUNCH(FF_BF16, false); break;
@@ -254,7 +254,7 @@ extern "C" int ff_merge_compact(const void* hidden, void* hidden_out, int dtype,
     if (L == 0) return FF_OK;
     return ff::launch_merge_compact(hidden, nullptr, hidden_out, dtype, L, d, L_cap, order, member, fold, dst, keep, aux_host, n_aux,
                                     nullptr, nullptr, nullptr,
-                                    (hipStream_t)stream, false, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, -1);
+                                    (hipStream_t)stream, false, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, -1, -1);
 }
 
 extern "C" int ff_gather_mask(const void* mask, void* out, int64_t elem_bytes, int64_t L, int64_t L_cap,

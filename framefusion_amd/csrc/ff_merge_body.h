@@ -121,7 +121,7 @@ __device__ inline void merge_compact_body(
     const int32_t* __restrict__ dst, const uint8_t* __restrict__ keep, const AuxPack& aux, int n_main,
     int n_aux_blocks, int n_next_blocks, int32_t* __restrict__ order_next, int32_t* __restrict__ inv_next,
     int64_t* __restrict__ stats, const int64_t* __restrict__ identity_stats, const ZeroJob& zero, int slots,
-    const int bx, const int by) {
+    const int bx, const int by, const long long guard_lout = -1) {
     using A = Act<DT>;
     constexpr int E = A::kPer16;
     constexpr int kDepth = 4;                     // row pieces requested per batch (two batches in flight)
@@ -136,6 +136,9 @@ __device__ inline void merge_compact_body(
     // nothing folded (a merge call whose threshold set is empty, main.py:264-266): the reduced
     // sequence IS the input, the caller keeps using its own tensors and this launch writes nothing
     if (identity_stats && identity_stats[FF_STAT_MERGED] == 0) return;
+    // enqueued blind into buffers of `guard_lout` rows (exactly sized outputs allocated for the length the top-k branch gives,
+    // main.py:122): if the plan decided otherwise nothing is written - the host sees the result block and repeats the launch
+    if (guard_lout >= 0 && identity_stats && identity_stats[FF_STAT_LOUT] != guard_lout) return;
     if (bx >= n_main + n_aux_blocks) {
         // ---- by-patch order of the COMPACTED sequence, for the next merge call (order maintenance):
         // the surviving slots keep their relative by-patch order and dst[] is monotonic in the

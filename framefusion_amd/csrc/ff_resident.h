@@ -30,6 +30,7 @@ struct ResLaunch {
     long long force_k;
     void* ws;
     size_t ws_bytes;
+    const int64_t* mail;          // != NULL: outputs by mail (ff_ctx_merge_mail)
 };
 
 // Does a merge call of this shape run as the one-launch kernel?  `nv`: visual tokens as the host knows them (<= 0: unknown).

@@ -52,6 +52,8 @@ struct ResBar {
     unsigned top[32];
     unsigned gen[8][32];
     unsigned abort_tag[32];
+    unsigned long long mail_tag[16];     // outputs by mail, relayed into device memory by ONE wave: tag (= seq) ...
+    unsigned long long mail[16];         // ... and the words {., hidden_out, L_cap, n_aux, dst[4]}
 };
 static_assert(sizeof(ResBar) <= 4096, "ff_plan.hip reserves 4 KB of the workspace front");
 
@@ -79,6 +81,7 @@ struct ResArgs {
     long long seq;
     AuxPack aux;
     ResBar* bar;
+    const int64_t* mail;          // != NULL: the outputs come by mail (pinned host words {seq, hidden_out, L_cap, n_aux, dst[4]})
 };
 
 // sum of four floats over the wave at once (each total in lane 63): four independent DPP chains interleaved, so that no
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
     // ---- the result block leaves through the first wave of one workgroup (word SEQ last: what the host polls)
     auto publish_words = [&](bool err_only, long long err) {      // called by the whole workgroup, sres[] complete
         __syncthreads();
-        if (tid < FF_STAT_WORDS && tid != FF_STAT_SEQ) {
+        if (tid < FF_STAT_T_ORDER && tid != FF_STAT_SEQ) {             // (the words behind are the host's: FF_MAIL_WORD)
             long long vres = err_only ? 0 : sres[tid];
             if (tid == FF_STAT_ERROR) vres = err;
             if (!err_only && tid != FF_STAT_ERROR && tid < FF_STAT_T_ORDER) a.stats[tid] = vres;
@@ -408,6 +411,27 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
         // repeats the call through the three launches
         publish_words(true, FF_ERR_BIT_RESIDENT);
         return;
+    }
+
+    // ---- outputs by mail: ONE wave of the launch reads the host's words (a device read of host memory is a PCIe round trip,
+    // ~2.5 us, and the link takes only a few dozen of them at a time: every workgroup asking for itself cost 270 us) and relays
+    // them into device memory, where everybody picks them up behind the plan
+    if (a.mail && bid == G - 1 && wv == kResWaves - 1) {
+        int ok = 1;
+        if (lane == 0) {
+            for (unsigned spins = 0; __hip_atomic_load(&a.mail[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != (int64_t)a.seq; ++spins) {
+                __builtin_amdgcn_s_sleep(16);
+                if (spins > (1u << 17)) { ok = 0; break; }              // (~0.5 s: a dead host)
+            }
+        }
+        ok = __builtin_amdgcn_readfirstlane(ok);
+        unsigned long long w = 0;
+        if (lane < FF_MAIL_WORDS) w = (unsigned long long)__hip_atomic_load(&a.mail[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (lane == 1 && !ok) w = 0;                                     // (no outputs: the launch stops behind its plan)
+        if (lane == 3 && !ok) w = ~0ull;                                 // (... and says why)
+        if (lane < FF_MAIL_WORDS) __hip_atomic_store(&a.bar->mail[lane], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(&a.bar->mail_tag[0], (unsigned long long)a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
     // ======================================================================================================================
@@ -665,7 +689,44 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
     stamp[3] = wall_clock64() - stamp0;                       // member bits by slot and position, prefix sums
     const int l_out = L - (members_total < 0 ? 0 : members_total);
     const bool plan_bad = members_total < 0 || (err_bits != 0);
-    const bool apply = !plan_bad && a.out != nullptr && a.L_cap >= (long long)l_out;
+    // ---- the outputs: in the launch arguments, or by mail - the host allocated them while the rows were read and wrote their
+    // addresses into pinned memory BEFORE it started to wait for the result block, so whoever waits here waits for a store that
+    // is already on its way (bounded all the same: a dead host must not hang the device)
+    char* out_ptr = a.out;
+    long long out_cap = a.L_cap;
+    int aux_n = a.aux.n;
+    unsigned long long* auxdst = (unsigned long long*)sres;          // [FF_MAX_AUX] destinations of the auxiliary tensors (LDS)
+    if (tid < FF_MAX_AUX) auxdst[tid] = (unsigned long long)(uintptr_t)a.aux.a[tid].dst;
+    if (a.mail) {
+        if (tid == 0) {
+            int ok = 1;
+            for (unsigned spins = 0; __hip_atomic_load(&a.bar->mail_tag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned long long)a.seq; ++spins) {
+                __builtin_amdgcn_s_sleep(2);
+                if (spins > (1u << 20)) { ok = 0; break; }
+            }
+            bcast[13] = ok;
+        }
+        if (tid >= kWave && tid < kWave + FF_MAIL_WORDS) sres[16 + tid - kWave] = 0;       // (slots of the relayed words)
+        __syncthreads();
+        if (tid < FF_MAIL_WORDS && bcast[13])
+            sres[16 + tid] = (long long)__hip_atomic_load(&a.bar->mail[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const bool lost = !bcast[13] || sres[16 + 3] == -1ll;
+        if (lost) {
+            if (tid == 0) atomicOr((unsigned long long*)(a.stats + FF_STAT_ERROR), (unsigned long long)FF_ERR_BIT_RESIDENT);
+            out_ptr = nullptr;
+            aux_n = 0;
+        } else {
+            out_ptr = (char*)(uintptr_t)sres[16 + 1];
+            out_cap = sres[16 + 2];
+            const int n_mail = (int)sres[16 + 3];
+            aux_n = out_ptr ? (n_mail < FF_MAX_AUX ? n_mail : FF_MAX_AUX) : 0;
+            if (tid < FF_MAX_AUX) auxdst[tid] = (unsigned long long)sres[16 + 4 + tid];
+        }
+    }
+    __syncthreads();
+    sub[3] = wall_clock64() - stamp0;                         // outputs known (mail read)
+    const bool apply = !plan_bad && (l_out == L || (out_ptr != nullptr && out_cap >= (long long)l_out));
     auto members_before_pos = [&](int i) { return pospre[i >> 5] + __popc(posmask[i >> 5] & ((1u << (i & 31)) - 1u)); };
     auto members_before_slot = [&](int t) { return slotpre[t >> 5] + __popc(slotword(t >> 5) & ((1u << (t & 31)) - 1u)); };
     if (bid == 0 && wv == kResWaves - 1) {
@@ -673,7 +734,7 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
         // 8 tiles): one lane per word, no LDS, no workgroup barrier - the other waves are already folding
         long long e = err_bits;
         if (members_total < 0) e |= FF_ERR_BIT_RESIDENT;
-        if (lane < FF_STAT_WORDS && lane != FF_STAT_SEQ) {
+        if (lane < FF_STAT_T_ORDER && lane != FF_STAT_SEQ) {            // (the words behind are the host's: FF_MAIL_WORD)
             long long vres = 0;
             const double ratio = ftn > 0 ? (double)count / (double)ftn : 0.0;
             switch (lane) {
@@ -739,9 +800,9 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
     // outer slice), 16 lanes each, kBatch tasks per round with the loads ahead of the stores; by `ngrp` groups of 16 lanes
     auto aux_roles = [&](int grp, int ngrp, int l16, auto batch) {
         constexpr int kBatch = decltype(batch)::value;
-        if (!folded || a.aux.n <= 0) return;
+        if (!folded || aux_n <= 0) return;
         int per = 0;
-        for (int x = 0; x < a.aux.n; ++x) per += (int)a.aux.a[x].outer;
+        for (int x = 0; x < aux_n; ++x) per += (int)a.aux.a[x].outer;
         const int T = (b1 - b0) * per;
         struct Task { const char* sp; char* dq; int rbytes; int fast; };
         auto task = [&](int t) -> Task {
@@ -753,7 +814,7 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
                 if (!((posmask[i >> 5] >> (i & 31)) & 1u)) {
                     const ff_aux_t& ax = a.aux.a[x];
                     k.sp = aux_src_row(ax, kq, i, L);
-                    k.dq = (char*)ax.dst + ((int64_t)kq * a.L_cap + (i - members_before_pos(i))) * ax.row_bytes;
+                    k.dq = (char*)(uintptr_t)auxdst[x] + ((int64_t)kq * out_cap + (i - members_before_pos(i))) * ax.row_bytes;
                     k.rbytes = (int)ax.row_bytes;
                     k.fast = ax.row_bytes <= 256 && !(((uintptr_t)k.sp | (uintptr_t)k.dq | (uintptr_t)ax.row_bytes) & 15);
                 }
@@ -783,7 +844,7 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
     // ======================================================================================================================
     // C. fold + compaction from the resident rows
     if (folded && data_wave) {
-        const __amdgpu_buffer_rsrc_t ores = make_rsrc(a.out, (uint32_t)(a.L_cap * (long long)rb));
+        const __amdgpu_buffer_rsrc_t ores = make_rsrc(out_ptr, (uint32_t)(out_cap * (long long)rb));
         // member bits of my slots and of the 64 behind them; output row of every anchor (by lane)
         const int js = s0 + lane;
         const bool mbit = lane < n && slotbit(js);
@@ -970,9 +1031,10 @@ int launch_merge_resident(const ResLaunch& p, hipStream_t st) {
     a.member = p.member; a.keep = p.keep; a.dst = p.dst;
     a.order_next = p.order_next; a.inv_next = p.inv_next;
     a.stats = p.stats; a.host_mapped = p.host_mapped; a.seq = p.seq;
-    a.aux.n = p.hidden_out ? p.n_aux : 0;
+    a.aux.n = (p.hidden_out || p.mail) ? p.n_aux : 0;
     for (int x = 0; x < FF_MAX_AUX; ++x) a.aux.a[x] = x < a.aux.n ? p.aux[x] : ff_aux_t{nullptr, nullptr, 0, 0, 0};
     a.bar = ws_resbar(p.ws);
+    a.mail = p.mail;
     const bool hint = p.hint_frames > 0;
     return hint ? launch_res<FF_BF16, true>(a, cus, st) : launch_res<FF_BF16, false>(a, cus, st);
 }

@@ -71,6 +71,17 @@ class _Scratch:
 
     _BUFFERS = ("order", "order_next", "inv", "inv_next", "member", "dst", "keep", "sim32", "ws", "stats")
 
+    def __del__(self):
+        ptr = getattr(self, "stats_host_ptr", None)
+        if ptr:
+            self.stats_host_ptr = None
+            try:
+                if self.last_stream is not None:
+                    self.last_stream.synchronize()       # (a kernel that still publishes into the block must have finished)
+                _lib.load().ff_host_free(ptr)
+            except Exception:                            # noqa: BLE001 (interpreter shutdown)
+                pass
+
     def ensure(self, L: int):
         if L > self.cap:
             cap = (max(L, 1024) + 63) & ~63          # (whole 16-byte words behind every int32 / T array)
@@ -91,9 +102,17 @@ class _Scratch:
             self.ws_bytes = int(_lib.load().ff_workspace_bytes(cap, 1))
             self.ws = torch.zeros(self.ws_bytes, dtype=torch.uint8, device=dev)   # select tables start clean
             self.stats = torch.zeros(_lib.STAT_WORDS, dtype=torch.int64, device=dev)
-            self.stats_host = torch.zeros(_lib.STAT_WORDS, dtype=torch.int64).pin_memory()
-            self.stats_host_ptr = self.stats_host.data_ptr()     # device-visible (pinned, UVA)
-            self.stats_np = self.stats_host.numpy()              # shares the pinned memory
+            # the result block (device -> host) and the output mail (host -> device, read by a RUNNING kernel): coherent pinned
+            # memory from the library's own runtime (torch's pin_memory() is only guaranteed visible at kernel boundaries)
+            if getattr(self, "stats_host_ptr", None):
+                pass                                             # (one block per scratch: its size does not depend on the capacity)
+            else:
+                self.stats_host_ptr = _lib.load().ff_host_alloc(_lib.STAT_WORDS * 8)
+                if not self.stats_host_ptr:
+                    raise FrameFusionHipError("ff_host_alloc failed (pinned, coherent host memory for the result block)")
+                import numpy as np
+                self.stats_np = np.ctypeslib.as_array((C.c_int64 * _lib.STAT_WORDS).from_address(self.stats_host_ptr))
+                self.stats_host = torch.from_numpy(self.stats_np)
             c = self.ctx
             c.cap = cap
             c.order, c.order_next = self.order.data_ptr(), self.order_next.data_ptr()
@@ -160,7 +179,7 @@ class _Scratch:
                 outer = s.numel() // (L * last)
                 # (from the strides of THIS call, never from an attribute a caller's tensor may carry from an earlier life)
                 outer_bytes = known if known is not None else (0 if s.is_contiguous() else _outer_stride(s) * s.element_size())
-            pack(block, offset + size * n, s.data_ptr(), o.data_ptr(), row, outer, outer_bytes)
+            pack(block, offset + size * n, s.data_ptr(), o.data_ptr() if o is not None else 0, row, outer, outer_bytes)
             n += 1
         return n
 
@@ -454,8 +473,13 @@ class FrameFusion(nn.Module):
         lib = _lib.load()
         st = self._merge_prepare(hidden_states, position_embeddings, attention_mask, residual)
         sc = st["sc"]
-        if self.one_launch and lib.ff_ctx_merge_one_launch(sc.ctx_ptr, sc.call_ptr):
-            return self._merge_one_launch(st)
+        one = bool(self.one_launch and lib.ff_ctx_merge_one_launch(sc.ctx_ptr, sc.call_ptr))
+        guess = st.get("L_guess")
+        if one or (self.compact_outputs and guess is not None and 0 < guess < st["L"]):
+            # everything goes out in ONE crossing: the one-launch kernel when the activation fits on the chip; else the three
+            # launches with the merge kernel blind into outputs of the guessed length (no plan -> host -> merge kernel bubble)
+            st["one_launch"] = one
+            return self._merge_submitted(st)
         rc = lib.ff_ctx_merge_begin(sc.ctx_ptr, sc.call_ptr)
         if rc:
             _fail(rc, "merge")
@@ -478,25 +502,44 @@ class FrameFusion(nn.Module):
     # Qwen2-VL-7B prefills do) and is read ONCE.  False: always the three launches (A/B measurements, tests).
     one_launch = True
 
-    def _merge_one_launch(self, st):
-        """Outputs first, then ONE crossing that enqueues ONE kernel (ff_ctx_merge_submit), then the wait (ff_ctx_merge_collect).
-        Exactly sized outputs (the default) are allocated for the length the top-k branch gives (main.py:122, host arithmetic); if
-        the plan decides otherwise - or no length can be guessed - the launch stops behind its plan (`applied` = 0) and the merge
+    def _merge_submitted(self, st):
+        """Outputs first, then ONE crossing that enqueues the whole call (ff_ctx_merge_submit: the one-launch kernel, or K1 + plan +
+        merge kernel), then the wait (ff_ctx_merge_collect).  Exactly sized outputs (the default) are allocated for the length the
+        top-k branch gives (main.py:122, host arithmetic) and the merge kernel / phase goes out BLIND into them, guarded on the
+        device: if the plan decides otherwise - or no length can be guessed - nothing is written (`applied` = 0) and the merge
         kernel follows alone, into outputs of the length the result block names (ff_ctx_merge_apply)."""
         lib = _lib.load()
         sc, L = st["sc"], st["L"]
-        st["one_launch"] = True
-        if self.compact_outputs:
-            guess = st.get("L_guess")
-            if guess is not None and 0 < guess < L:
-                self._merge_outputs(st, guess)
+
+        def outputs():
+            if self.compact_outputs:
+                guess = st.get("L_guess")
+                if guess is not None and 0 < guess < L:
+                    self._merge_outputs(st, guess)
+                else:
+                    self._no_outputs(st)                 # (only the one-launch kernel gets here: it stops behind its plan)
             else:
-                self._no_outputs(st)
+                self._merge_outputs(st)
+        late = 1 if st.get("one_launch") else 0
+        _PACK_I64.pack_into(sc.call, _lib.MERGE_CALL_LATE_OFFSET, late)
+        if late:
+            # the one-launch kernel needs its outputs ~35 us after it starts: launch first (the auxiliary SOURCES go with the
+            # launch), allocate under it, hand the addresses over in pinned memory (ff_ctx_merge_mail: plain stores, written
+            # before the wait below begins)
+            self._no_outputs(st)
+            self._merge_sources(st)
+            rc = lib.ff_ctx_merge_submit(sc.ctx_ptr, sc.call_ptr)
+            if rc:
+                _fail(rc, "merge")
+            outputs()
+            rc = lib.ff_ctx_merge_mail(sc.ctx_ptr, sc.call_ptr)
+            if rc:
+                _fail(rc, "merge")
         else:
-            self._merge_outputs(st)
-        rc = lib.ff_ctx_merge_submit(sc.ctx_ptr, sc.call_ptr)
-        if rc:
-            _fail(rc, "merge")
+            outputs()
+            rc = lib.ff_ctx_merge_submit(sc.ctx_ptr, sc.call_ptr)
+            if rc:
+                _fail(rc, "merge")
         rc = lib.ff_ctx_merge_collect(sc.ctx_ptr, sc.call_ptr, sc.res_ptr)
         if rc or sc.res.applied:
             return self._merge_complete(st, rc)
@@ -507,6 +550,28 @@ class FrameFusion(nn.Module):
             self._merge_outputs(st, L_out)
         rc = lib.ff_ctx_merge_apply(sc.ctx_ptr, sc.call_ptr, sc.res_ptr)
         return self._merge_complete(st, rc)
+
+    def _merge_sources(self, st):
+        """The SOURCE half of the auxiliary entries (patch types + position tensors, destinations 0): no allocation."""
+        sc, L, call = st["sc"], st["L"], st["sc"].call
+        pe = st["position_embeddings"]
+        if type(pe) == list:
+            assert len(pe) == 2
+            for t in pe:
+                if t.ndim not in (3, 4) or t.shape[-2] != L:
+                    raise FrameFusionHipError(f"position embedding of shape {tuple(t.shape)} does not have "
+                                              f"{L} tokens on its second-to-last axis")
+            srcs = [_token_dense(pe[0]), _token_dense(pe[1])]
+        elif type(pe) == torch.Tensor:
+            if pe.ndim != 2:
+                raise NotImplementedError("Only support 2D position embeddings")
+            srcs = [pe.contiguous()]
+        else:
+            raise NotImplementedError("Only support list or tensor for position embeddings")
+        st["late_srcs"] = srcs                               # (kept alive until the call is over)
+        _lib.AUX_ENTRY.pack_into(call, _lib.MERGE_CALL_AUX_OFFSET, st["ptype"].data_ptr(), 0, 8, 1, 0)
+        n_aux = 1 + sc.put_aux(call, _lib.MERGE_CALL_AUX_OFFSET + _lib.AUX_ENTRY.size, ((s, None) for s in srcs), L, room=_lib.MAX_AUX - 1)
+        _PACK_I64.pack_into(call, _lib.MERGE_CALL_AUX_OFFSET - 8, n_aux)
 
     def _no_outputs(self, st, hidden=None):
         """The output half of the call block, empty: a plan-only submit (hidden = None) / an apply that writes nothing."""
@@ -637,6 +702,7 @@ class FrameFusion(nn.Module):
         _lib.MERGE_CALL_HEAD.pack_into(sc.call, 0, hidden.data_ptr(), addend_ptr, 0, ptype.data_ptr(), code, L, d, L, P,
                                        order_valid, self._threshold_for(dtype), sub, self.ratio_lower_bound, -1,
                                        _lib.FOLD_SEQUENTIAL, hint_pre, hint_frames, stream or 0, 0)
+        _PACK_I64.pack_into(sc.call, _lib.MERGE_CALL_LATE_OFFSET, 0)
         sc.order_gen = None                  # until the call has come back
         # the number of non-text tokens, where the host can know it without asking the device (see _merge_exact_tail)
         ftn = None

@@ -61,8 +61,8 @@ enum {
     FF_STAT_ERROR = 11,    /* bit mask of device-side checks that failed, FF_ERR_BIT_*; cleared once published */
     FF_STAT_APPLIED = 12,  /* one-launch merge call: 1 = the outputs are written (or nothing folds), 0 = the plan only -
                               member / keep / dst are in place, the merge kernel is still to come (L_cap < l_out or no outputs) */
-    FF_STAT_T_ORDER = 16,  /* 2 words: shader-clock cycles of K0's second launch (diagnostics)    */
-    FF_STAT_T_PLAN = 24,   /* 7 words: steady-counter stamps of the plan kernel's phases (diagnostics) */
+    FF_STAT_T_ORDER = 16,  /* device block only: 8 diagnostic words (K0's cycles; sub-phase stamps of the one-launch kernel) */
+    FF_STAT_T_PLAN = 24,   /* 7 words: steady-counter stamps of the plan kernel's / the one-launch kernel's phases (diagnostics) */
     FF_STAT_WORDS = 32
 };
 
@@ -384,7 +384,8 @@ typedef struct ff_ctx {
     int32_t* dst;          /* [cap]                                                                     */
     uint8_t* keep;         /* [cap]                                                                     */
     int64_t* stats;        /* [FF_STAT_WORDS] device, zero-initialised                                  */
-    int64_t* stats_host;   /* [FF_STAT_WORDS] pinned host memory the DEVICE can write (hipHostMalloc)   */
+    int64_t* stats_host;   /* [FF_STAT_WORDS] pinned host memory the DEVICE can write (hipHostMalloc); words
+                              FF_MAIL_WORD.. are written by the HOST and read by the device (ff_ctx_merge_mail)    */
     void* ws;              /* ff_workspace_bytes(cap, .) bytes, zero-initialised                        */
     size_t ws_bytes;
     /* ---- library state (zero-initialise; read-only for the owner) ---- */
@@ -428,6 +429,8 @@ typedef struct ff_merge_call {
                                     (result->l_out != L); when l_out == L the sequence - and its mask -
                                     stay as they are and mask_out is left untouched (ABI v8 on)         */
     int64_t mask_elem_bytes;
+    int64_t late_outputs;        /* ff_ctx_merge_submit of a one-launch call only: != 0 = hidden_out / L_cap / aux[].dst are
+                                    not set yet - they follow by ff_ctx_merge_mail while the kernel reads the rows (ABI v10) */
 } ff_merge_call_t;
 
 /* What the host needs from the call (everything else stays on the device). */
@@ -480,6 +483,15 @@ int ff_ctx_merge_collect(ff_ctx_t* ctx, const ff_merge_call_t* call, ff_merge_re
  * Two such kernels never run side by side on a device without one of them timing out (each needs every CU until its barrier):
  * a host that keeps two samples in flight on two streams sets ctx->res_off to a large number on both contexts. */
 int ff_ctx_merge_one_launch(const ff_ctx_t* ctx, const ff_merge_call_t* call);
+
+/* Outputs by mail (ABI v10): a one-launch call needs its output buffers only when its plan is done, ~35 us after the launch.
+ * ff_ctx_merge_submit with call->late_outputs != 0 enqueues the kernel at once; the host allocates the outputs while the rows are
+ * being read, sets hidden_out / L_cap / aux[].dst in `call` and hands them over with ff_ctx_merge_mail (plain stores into the pinned
+ * block behind ctx->stats_host, words FF_MAIL_WORD..; no HIP call), then calls ff_ctx_merge_collect.  The kernel picks the mail up
+ * behind its plan (it waits for it if it must: the host writes it unconditionally, before it starts waiting for the result - no
+ * cycle).  hidden_out = NULL in the mail = no outputs: the launch stops behind its plan (applied = 0). */
+enum { FF_MAIL_WORD = 16, FF_MAIL_WORDS = 8 };      /* {seq, hidden_out, L_cap, n_aux, aux[0..3].dst} */
+int ff_ctx_merge_mail(ff_ctx_t* ctx, const ff_merge_call_t* call);
 
 /* The merge call for EXACTLY SIZED outputs (ABI v9) - what the reference returns: hidden_states[token_mask, :], the position
  * embeddings and the attention mask gathered with the same mask (framefusion/main.py:132-138, 161-178).  The host learns l_out
@@ -564,6 +576,13 @@ int ff_ctx_reset(ff_ctx_t* ctx, ff_stream_t stream);
  * filled) - ff_last_query_attention with sel_ws = ctx->ws: if the matching ff_ctx_prune never comes,
  * the next call resets the workspace. */
 void ff_ctx_expect_tables(ff_ctx_t* ctx);
+
+/* Host memory the device and the host both see COHERENTLY while a kernel runs (hipHostMalloc: coherent | mapped) - what
+ * ctx->stats_host must be when outputs go by mail (the kernel polls words the host writes mid-launch; the default pinned
+ * allocation of most frameworks is only guaranteed visible at kernel boundaries: measured ~600 us late).  The two calls of
+ * the ABI that allocate; nothing else does. */
+void* ff_host_alloc(size_t bytes);
+void ff_host_free(void* p);
 
 /* sizeof() of the structures above as THIS library was compiled (0: ff_ctx_t, 1: ff_merge_call_t,
  * 2: ff_merge_result_t, 3: ff_prune_call_t, 4: ff_aux_t, 5: ff_lq_args_t), so a binding can verify its own layout. */
