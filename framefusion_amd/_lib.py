@@ -125,32 +125,19 @@ PROTOTYPES = {
     "ff_pair_similarity": (_i32, [_vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "ff_plan_merge": (_i32, [_vp, _i32, _vp, _i64, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ff_plan_from_index": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "ff_plan_prune": (_i32, [_vp, _i32, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ff_merge_compact": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _vp, _i32, _vp, _vp, C.POINTER(FFAux), _i32,
                                 _vp]),
-    "ff_gather_mask": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "ff_gather_tokens_by_index": (_i32, [_vp, _i64, _i64, C.POINTER(FFAux), _i32, _vp]),
     "ff_gather_tokens_by_mask": (_i32, [_vp, _i64, _i64, _vp, _vp, C.POINTER(FFAux), _i32, _vp]),
     "ff_head_mean": (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _vp]),
     "ff_last_query_attention": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f64, _i32, _vp, _vp, _vp, _i64, _i64,
                                        _vp, _sz, _vp, _sz, _vp]),
     "ff_last_query_workspace_bytes": (_sz, [_i32, _i64, _i64, _i64, _i64]),
-    "ff_merge_begin": (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _i64, _i32, _f64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _sz,
-                              _vp]),
-    "ff_merge_finish": (_i32, [_vp, _vp, _vp, _i32, _i64, _i64, _i64, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                               _i64, C.POINTER(FFAux), _i32, _vp, _vp, _vp, _sz, _vp]),
-    "ff_prune_step": (_i32, [_vp, _vp, _vp, _i32, _i64, _i64, _i64, _vp, _i32, _i64, _i64, _vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp,
-                             _vp, C.POINTER(FFAux), _i32, _vp, _sz, _vp]),
-    "ff_plan_topk": (_i32, [_vp, _i32, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "ff_merge_finish_topk": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                    _i64, C.POINTER(FFAux), _i32, _vp, _vp, _vp, _sz, _vp]),
     "ff_token_span": (_i32, [_vp, _i64, _i64, _vp, _vp]),
     "ff_fill_patch_type": (_i32, [_vp, _i64, C.POINTER(FFSegment), _i64, _vp]),
     "ff_patch_type_from_mask": (_i32, [_vp, _i64, _i64, _vp, _vp, _vp]),
     "ff_ctx_merge_begin": (_i32, [_vp, _vp]),
     "ff_ctx_merge_finish": (_i32, [_vp, _vp, _vp]),
-    "ff_ctx_merge": (_i32, [_vp, _vp, _vp]),
-    "ff_ctx_merge_plan": (_i32, [_vp, _vp]),
     "ff_ctx_merge_wait": (_i32, [_vp, _vp, _vp]),
     "ff_ctx_merge_apply": (_i32, [_vp, _vp, _vp]),
     "ff_ctx_merge_submit": (_i32, [_vp, _vp]),
@@ -161,7 +148,6 @@ PROTOTYPES = {
     "ff_ctx_prune_from_qk": (_i32, [_vp, _vp, _vp]),
     "ff_ctx_gather_mask": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "ff_ctx_reset": (_i32, [_vp, _vp]),
-    "ff_ctx_expect_tables": (None, [_vp]),
     "ff_abi_sizeof": (_sz, [_i32]),
     "ff_host_alloc": (_vp, [_sz]),
     "ff_host_free": (None, [_vp]),

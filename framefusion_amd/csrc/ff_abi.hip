@@ -31,6 +31,8 @@ int launch_merge_compact(const void* hidden, const void* addend, void* hidden_ou
 int launch_similarity_any(const void* hidden, const void* addend, int dtype, int64_t L, int64_t d, const int64_t* ptype,
                           int32_t* order, int32_t* inv, int64_t* stats, void* sim, int* l0, int* t16_end, double thr,
                           int64_t hint_pre, int64_t hint_patches, int64_t hint_frames, hipStream_t st);
+int gather_mask(const void* mask, void* out, int64_t elem_bytes, int64_t L, int64_t L_cap, const int32_t* dst,
+                const int64_t* stats, int32_t* scratch, ff_stream_t stream);
 int launch_head_mean(const void* attn_w, int dtype, int64_t H, int64_t num, int64_t S, void* importance,
                      int64_t lo, int64_t hi, int* l0, int* t16_end, hipStream_t st);
 }  // namespace ff
@@ -62,7 +64,8 @@ extern "C" size_t ff_workspace_bytes(int64_t L, int64_t patch_num) {
     return ff::plan_ws_front_bytes(L) + ((size_t)(L / 4096) + 1) * 64 + 256 + ff::plan_ws_tail_bytes(L);
 }
 
-extern "C" int ff_merge_begin(const void* hidden, const void* addend, int dtype, int64_t L, int64_t d, const int64_t* patch_type,
+// first half of a merge call: K0 (unless order_valid / hinted) + K1, which also accumulates the select tables of the call
+static int merge_begin(const void* hidden, const void* addend, int dtype, int64_t L, int64_t d, const int64_t* patch_type,
                               int64_t patch_num, int order_valid, double threshold, int32_t* order, int32_t* inv,
                               void* sim, int64_t* stats, int64_t seq, int64_t hint_pre, int64_t hint_frames, void* ws,
                               size_t ws_bytes, ff_stream_t stream) {
@@ -127,27 +130,6 @@ static int merge_finish(const void* hidden, const void* addend, void* hidden_out
                                     ff::ws_t16_end(ws, ws_bytes), nullptr, -1, (guarded && phase == 3 && L_cap < L) ? L_cap : -1);
 }
 
-extern "C" int ff_merge_finish(const void* hidden, const void* addend, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
-                               double threshold, double sub, double ratio_lb, const int32_t* order, const int32_t* inv,
-                               const void* sim, uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
-                               int64_t* stats_host_mapped, int64_t seq, const ff_aux_t* aux_host, int n_aux,
-                               int32_t* order_next, int32_t* inv_next, void* ws, size_t ws_bytes, ff_stream_t stream) {
-    return merge_finish(hidden, addend, hidden_out, dtype, L, d, L_cap, threshold, sub, ratio_lb, -1, FF_FOLD_SEQUENTIAL, order, inv,
-                        sim, member, dst, keep, stats, stats_host_mapped, seq, aux_host, n_aux, order_next, inv_next, ws,
-                        ws_bytes, stream);
-}
-
-extern "C" int ff_merge_finish_topk(const void* hidden, void* hidden_out, int dtype, int64_t L, int64_t d,
-                                    int64_t L_cap, int64_t k, int fold, const int32_t* order, const int32_t* inv,
-                                    const void* sim, uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
-                                    int64_t* stats_host_mapped, int64_t seq, const ff_aux_t* aux_host, int n_aux,
-                                    int32_t* order_next, int32_t* inv_next, void* ws, size_t ws_bytes,
-                                    ff_stream_t stream) {
-    if (k < 0 || (fold != FF_FOLD_SEQUENTIAL && fold != FF_FOLD_MEAN)) return FF_ERR_ARG;
-    return merge_finish(hidden, nullptr, hidden_out, dtype, L, d, L_cap, 0.0, 0.0, 0.0, k, fold, order, inv, sim, member, dst, keep,
-                        stats, stats_host_mapped, seq, aux_host, n_aux, order_next, inv_next, ws, ws_bytes, stream);
-}
-
 extern "C" int ff_merge_step(const void* hidden, const void* addend, void* hidden_out, int dtype, int64_t L, int64_t d, int64_t L_cap,
                              const int64_t* patch_type, int64_t patch_num, int order_valid, double threshold,
                              double sub, double ratio_lb, int32_t* order, int32_t* inv, void* sim, uint8_t* member,
@@ -155,14 +137,16 @@ extern "C" int ff_merge_step(const void* hidden, const void* addend, void* hidde
                              int64_t seq, const ff_aux_t* aux_host, int n_aux, int64_t hint_pre,
                              int64_t hint_frames, int32_t* order_next, int32_t* inv_next, void* ws, size_t ws_bytes,
                              ff_stream_t stream) {
-    int rc = ff_merge_begin(hidden, addend, dtype, L, d, patch_type, patch_num, order_valid, threshold, order, inv, sim, stats,
-                            seq, hint_pre, hint_frames, ws, ws_bytes, stream);
+    int rc = merge_begin(hidden, addend, dtype, L, d, patch_type, patch_num, order_valid, threshold, order, inv, sim, stats,
+                         seq, hint_pre, hint_frames, ws, ws_bytes, stream);
     if (rc) return rc;
-    return ff_merge_finish(hidden, addend, hidden_out, dtype, L, d, L_cap, threshold, sub, ratio_lb, order, inv, sim, member, dst,
-                           keep, stats, stats_host_mapped, seq, aux_host, n_aux, order_next, inv_next, ws, ws_bytes, stream);
+    return merge_finish(hidden, addend, hidden_out, dtype, L, d, L_cap, threshold, sub, ratio_lb, -1, FF_FOLD_SEQUENTIAL, order, inv,
+                        sim, member, dst, keep, stats, stats_host_mapped, seq, aux_host, n_aux, order_next, inv_next, ws, ws_bytes,
+                        stream);
 }
 
-extern "C" int ff_prune_step(const void* hidden, const void* addend, void* hidden_out, int dtype, int64_t S, int64_t d, int64_t L_cap,
+// one prune call (main.py:61-101): head mean (+ select tables) -> plan -> gather by output rows
+static int prune_step(const void* hidden, const void* addend, void* hidden_out, int dtype, int64_t S, int64_t d, int64_t L_cap,
                              const void* attn_w, int w_dtype, int64_t H, int64_t num, void* importance,
                              int tables_ready,
                              int64_t start, int64_t n_img, int64_t k, uint8_t* member, int32_t* dst, uint8_t* keep,
@@ -277,10 +261,6 @@ extern "C" size_t ff_abi_sizeof(int which) {
     }
 }
 
-extern "C" void ff_ctx_expect_tables(ff_ctx_t* c) {
-    if (c) c->dirty = 1;
-}
-
 static int ctx_begin(ff_ctx_t* c, const ff_merge_call_t* a, bool hinted) {
     hipStream_t st = (hipStream_t)a->stream;
     int rc = ctx_clean(c, st);
@@ -290,7 +270,7 @@ static int ctx_begin(ff_ctx_t* c, const ff_merge_call_t* a, bool hinted) {
     c->seq += 1;
     c->dirty = 1;                // until finish has enqueued the kernel that clears the select tables
     c->in_flight = 1;
-    return ff_merge_begin(a->hidden, a->addend, (int)a->dtype, a->L, a->d, a->patch_type, a->patch_num, order_valid,
+    return merge_begin(a->hidden, a->addend, (int)a->dtype, a->L, a->d, a->patch_type, a->patch_num, order_valid,
                           a->threshold, c->order, c->inv, c->sim, c->stats, c->seq, a->hint_pre,
                           hinted ? a->hint_frames : 0, c->ws, c->ws_bytes, a->stream);
 }
@@ -430,7 +410,7 @@ static int ctx_after_result(ff_ctx_t* c, const ff_merge_call_t* a, const ff_merg
     // the attention mask follows once the call is known to be valid and to fold something: nothing for an attempt whose layout
     // hint was wrong, nothing when the sequence stays as it is (the caller keeps its own mask)
     if (a->mask && r->l_out != a->L) {
-        rc = ff_gather_mask(a->mask, a->mask_out, a->mask_elem_bytes, a->L, a->L_cap, c->dst, c->stats,
+        rc = ff::gather_mask(a->mask, a->mask_out, a->mask_elem_bytes, a->L, a->L_cap, c->dst, c->stats,
                             ff::ws_scratch_ints(c->ws, c->cap), a->stream);
         if (rc) { c->dirty = 1; c->order_len = 0; return rc; }
     }
@@ -583,27 +563,18 @@ extern "C" int ff_ctx_merge_collect(ff_ctx_t* c, const ff_merge_call_t* a, ff_me
 }
 
 // ---- the merge call for exactly sized outputs: the host sees l_out BEFORE the merge kernel is enqueued --------------------------
-// begin (K1) -> ff_ctx_merge_plan (plan kernel enqueued, nothing waited for) -> ff_ctx_merge_wait (result block; a wrong layout
+// begin (K1) -> ff_ctx_merge_wait (plan kernel enqueued, then the wait for the result block; a wrong layout
 // hint is repeated through K0 here) -> the host sizes its outputs to l_out -> ff_ctx_merge_apply (merge kernel, mask gather,
 // order swap).  Costs the GPU the host's reaction time between plan and merge kernel (~10-20 us) and saves the input-length
 // output buffers (or the copy out of them).
-extern "C" int ff_ctx_merge_plan(ff_ctx_t* c, const ff_merge_call_t* a) {
-    if (!a) return FF_ERR_ARG;
-    int rc = ctx_check(c, a->L);
-    if (rc) return rc;
-    if (c->in_flight != 1) return FF_ERR_STATE;
-    rc = ctx_finish_enqueue(c, a, 1);
-    if (rc) { c->in_flight = 0; c->dirty = 1; c->order_len = 0; return rc; }
-    c->in_flight = 2;
-    return FF_OK;
-}
-
 extern "C" int ff_ctx_merge_wait(ff_ctx_t* c, const ff_merge_call_t* a, ff_merge_result_t* r) {
     if (!a || !r) return FF_ERR_ARG;
     int rc = ctx_check(c, a->L);
     if (rc) return rc;
-    if (c->in_flight != 2) return FF_ERR_STATE;
-    return ctx_finish(c, a, r, true, 1);            // (leaves in_flight = 3 on success)
+    if (c->in_flight != 1) return FF_ERR_STATE;
+    rc = ctx_finish_enqueue(c, a, 1);                  // the plan kernel behind K1; no output field is looked at
+    if (rc) { c->in_flight = 0; c->dirty = 1; c->order_len = 0; return rc; }
+    return ctx_finish(c, a, r, true, 1);               // (leaves in_flight = 3 on success)
 }
 
 extern "C" int ff_ctx_merge_apply(ff_ctx_t* c, const ff_merge_call_t* a, const ff_merge_result_t* r) {
@@ -619,25 +590,20 @@ extern "C" int ff_ctx_merge_apply(ff_ctx_t* c, const ff_merge_call_t* a, const f
     return ctx_after_result(c, a, r);
 }
 
-extern "C" int ff_ctx_merge(ff_ctx_t* c, const ff_merge_call_t* a, ff_merge_result_t* r) {
-    int rc = ff_ctx_merge_begin(c, a);
-    if (rc) return rc;
-    return ff_ctx_merge_finish(c, a, r);
-}
-
 extern "C" int ff_ctx_gather_mask(ff_ctx_t* c, const void* mask, void* mask_out, int64_t elem_bytes, int64_t L, int64_t L_cap,
                                   ff_stream_t stream) {
     int rc = ctx_check(c, L);
     if (rc) return rc;
     // only behind the merge call whose keep set is still in the context: same L, finished, folded something, nothing begun since
     if (c->in_flight || c->dirty || c->last_L != L || L == 0 || c->last_l_out == L || L_cap < c->last_l_out) return FF_ERR_STATE;
-    return ff_gather_mask(mask, mask_out, elem_bytes, L, L_cap, c->dst, c->stats, ff::ws_scratch_ints(c->ws, c->cap), stream);
+    return ff::gather_mask(mask, mask_out, elem_bytes, L, L_cap, c->dst, c->stats, ff::ws_scratch_ints(c->ws, c->cap), stream);
 }
 
 extern "C" int ff_ctx_prune(ff_ctx_t* c, const ff_prune_call_t* a) {
     if (!a) return FF_ERR_ARG;
     int rc = ctx_check(c, a->S);
     if (rc) return rc;
+    if (c->in_flight) return FF_ERR_STATE;               // (a merge call of this context is still open)
     if (a->mask && !a->mask_out) return FF_ERR_ARG;
     hipStream_t st = (hipStream_t)a->stream;
     if (a->tables_ready != 0 && a->tables_ready != 1) return FF_ERR_ARG;
@@ -648,13 +614,13 @@ extern "C" int ff_ctx_prune(ff_ctx_t* c, const ff_prune_call_t* a) {
     c->last_L = 0;
     c->dirty = 1;
     c->order_len = 0;              // the sequence changes and no order is maintained through a prune
-    rc = ff_prune_step(a->hidden, a->addend, a->hidden_out, (int)a->dtype, a->S, a->d, a->L_cap, a->attn_w, (int)a->w_dtype,
+    rc = prune_step(a->hidden, a->addend, a->hidden_out, (int)a->dtype, a->S, a->d, a->L_cap, a->attn_w, (int)a->w_dtype,
                        a->H, a->num, c->sim, (int)a->tables_ready, a->start, a->n_img, a->k, c->member, c->dst, c->keep,
                        c->stats, a->aux, (int)a->n_aux, c->ws, c->ws_bytes, a->stream);
     if (rc) return rc;
     c->dirty = 0;
     if (a->mask)
-        rc = ff_gather_mask(a->mask, a->mask_out, a->mask_elem_bytes, a->S, a->L_cap, c->dst, c->stats,
+        rc = ff::gather_mask(a->mask, a->mask_out, a->mask_elem_bytes, a->S, a->L_cap, c->dst, c->stats,
                             ff::ws_scratch_ints(c->ws, c->cap), a->stream);
     return rc;
 }

@@ -257,8 +257,12 @@ extern "C" int ff_merge_compact(const void* hidden, void* hidden_out, int dtype,
                                     (hipStream_t)stream, false, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, -1, -1);
 }
 
-extern "C" int ff_gather_mask(const void* mask, void* out, int64_t elem_bytes, int64_t L, int64_t L_cap,
-                              const int32_t* dst, const int64_t* stats, int32_t* scratch, ff_stream_t stream) {
+// Square attention-mask gather (main.py:137-138, 99-100): out[r, c] = mask[src[r], src[c]] for the kept rows / columns; dst: the
+// plan's row of every position (-1 = dropped); stats: the plan's result block (FF_STAT_LOUT is read on the device); scratch: [L]
+// int32, 16-byte aligned (receives the position of every output row).  Two launches.
+namespace ff {
+int gather_mask(const void* mask, void* out, int64_t elem_bytes, int64_t L, int64_t L_cap,
+                const int32_t* dst, const int64_t* stats, int32_t* scratch, ff_stream_t stream) {
     if (!mask || !out || !dst || !stats || !scratch || L < 0 || L_cap < 0) return FF_ERR_ARG;
     if (elem_bytes != 1 && elem_bytes != 2 && elem_bytes != 4 && elem_bytes != 8) return FF_ERR_ARG;
     if (L >= (1ll << 31)) return FF_ERR_UNSUPPORTED;
@@ -276,6 +280,7 @@ extern "C" int ff_gather_mask(const void* mask, void* out, int64_t elem_bytes, i
     }
     return (int)hipGetLastError();
 }
+}  // namespace ff
 
 // ---- stand-alone token gathers for the reference's public position handlers (main.py:142-178) -------------------
 // position_embedding_handler_at_pruning(pe, keep_indexs): pe[..., keep_indexs, :] - rows in the order of an index

@@ -918,21 +918,6 @@ extern "C" int ff_plan_merge(const void* sim, int dtype, const int32_t* order, i
                                  ws_bytes, false, nullptr, 0, (hipStream_t)stream, -1);
 }
 
-extern "C" int ff_plan_topk(const void* sim, int dtype, const int32_t* order, int64_t L, int64_t k, uint8_t* member,
-                            int32_t* dst, uint8_t* keep, int64_t* stats, void* ws, size_t ws_bytes,
-                            ff_stream_t stream) {
-    int rc = check_plan_args(sim, member, dst, keep, stats, L, ws, ws_bytes);
-    if (rc) return rc;
-    if (!order || k < 0) return FF_ERR_ARG;
-    if (dtype != FF_F32 && dtype != FF_BF16 && dtype != FF_F16) return FF_ERR_ARG;
-    if (!aligned16(sim) || !aligned16(dst) || !aligned16(keep) || !aligned16(ws) || !aligned16(order) ||
-        ((uintptr_t)member & 7))
-        return FF_ERR_ALIGN;
-    if (L == 0) return FF_OK;
-    return ff::launch_plan_merge(sim, dtype, order, nullptr, L, 0.0, 0.0, 0.0, member, dst, keep, stats, ws, ws_bytes,
-                                 false, nullptr, 0, (hipStream_t)stream, k);
-}
-
 extern "C" int ff_plan_from_index(const int64_t* merge_index, int64_t n_merge, const int32_t* order, int64_t L,
                                   uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats, void* ws,
                                   size_t ws_bytes, ff_stream_t stream) {
@@ -944,16 +929,3 @@ extern "C" int ff_plan_from_index(const int64_t* merge_index, int64_t n_merge, c
     return ff::launch_plan_from_index(merge_index, n_merge, order, L, member, dst, keep, stats, (hipStream_t)stream);
 }
 
-extern "C" int ff_plan_prune(const void* importance, int dtype, int64_t S, int64_t start, int64_t n_img,
-                             int64_t k, uint8_t* member, int32_t* dst, uint8_t* keep, int64_t* stats,
-                             void* ws, size_t ws_bytes, ff_stream_t stream) {
-    int rc = check_plan_args(importance, member, dst, keep, stats, S, ws, ws_bytes);
-    if (rc) return rc;
-    if (dtype != FF_F32 && dtype != FF_BF16 && dtype != FF_F16) return FF_ERR_ARG;
-    if (start < 0 || n_img < 0 || start + n_img > S || k < 0) return FF_ERR_ARG;
-    if (!aligned16(importance) || !aligned16(dst) || !aligned16(keep) || !aligned16(ws) || ((uintptr_t)member & 7))
-        return FF_ERR_ALIGN;
-    if (S == 0) return FF_OK;
-    return ff::launch_plan_prune(importance, dtype, S, start, n_img, k, member, dst, keep, stats, ws, ws_bytes, false,
-                                 (hipStream_t)stream);
-}

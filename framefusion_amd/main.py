@@ -247,7 +247,7 @@ class FrameFusion(nn.Module):
         self.ratio_lower_bound = ratio_lower_bound
         # compact_outputs = True (the default since round 5): exactly sized outputs, what the reference returns
         # (main.py:132-138).  The host waits for the plan's result block, sizes the outputs to l_out and only then enqueues
-        # the merge kernel (ff_ctx_merge_plan / _wait / _apply): the GPU idles for the host's reaction time between the two
+        # the merge kernel (ff_ctx_merge_wait / _apply): the GPU idles for the host's reaction time between the two
         # kernels (~10-20 us), nothing is over-allocated, nothing is copied.  False: the merge kernel is enqueued blind, right
         # behind the plan, into buffers of the INPUT length, and narrow() views of them are returned (a view keeps its whole
         # buffer alive: 302 MB for a 91 MB result at 64 x 576 x 4096) - the opt-in fast path: no idle gap.  End to end the two
@@ -484,12 +484,9 @@ class FrameFusion(nn.Module):
         if rc:
             _fail(rc, "merge")
         if self.compact_outputs:
-            # exactly sized outputs (the default): the plan goes out behind K1, the host waits for l_out, sizes the outputs to it
-            # and only then enqueues the merge kernel - no input-length buffers, no copy; the GPU idles for the host's reaction
-            # time between the two kernels instead
-            rc = lib.ff_ctx_merge_plan(sc.ctx_ptr, sc.call_ptr)
-            if rc:
-                _fail(rc, "merge")
+            # exactly sized outputs (the default) and no length to guess: the plan goes out behind K1, the host waits for l_out,
+            # sizes the outputs to it and only then enqueues the merge kernel - no input-length buffers, no copy; the GPU idles
+            # for the host's reaction time between the two kernels instead
             return self._merge_exact_tail(st)
         self._merge_outputs(st)
         # The one device->host hand-off of the call: the plan kernel stores the result block into pinned
@@ -600,8 +597,8 @@ class FrameFusion(nn.Module):
         st = self._merge_prepare(hidden_states, position_embeddings, attention_mask, residual)
         sc = st["sc"]
         lib = _lib.load()
-        if self.compact_outputs:                 # exactly sized outputs: K1 + plan now, outputs and merge kernel at collect()
-            rc = lib.ff_ctx_merge_begin(sc.ctx_ptr, sc.call_ptr) or lib.ff_ctx_merge_plan(sc.ctx_ptr, sc.call_ptr)
+        if self.compact_outputs:                 # exactly sized outputs: K1 now; plan, outputs and merge kernel at collect()
+            rc = lib.ff_ctx_merge_begin(sc.ctx_ptr, sc.call_ptr)        # (the plan follows with the wait, at collect())
             st["exact"] = True
             guess = st.get("L_guess")
             if not rc and guess is not None and 0 < guess < st["L"]:     # the top-k branch's outputs, allocated under K1

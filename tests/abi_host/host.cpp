@@ -98,7 +98,7 @@ static int full_mode(int F, int P, int d, int pre, int L, const std::vector<uint
     // flight calls; here with one sample: a collect before any submit and a second submit in between must be refused)
     if (ff_ctx_merge_collect(&ctx, &call, &res[0]) != FF_ERR_STATE) { fprintf(stderr, "collect without submit was not refused\n"); return 6; }
     FF(ff_ctx_merge_submit(&ctx, &call));
-    if (ff_ctx_merge_plan(&ctx, &call) != FF_ERR_STATE) { fprintf(stderr, "plan on a submitted call was not refused\n"); return 6; }
+    if (ff_ctx_merge_wait(&ctx, &call, &res[0]) != FF_ERR_STATE) { fprintf(stderr, "wait on a submitted call was not refused\n"); return 6; }
     FF(ff_ctx_merge_collect(&ctx, &call, &res[0]));
     const int64_t l1 = res[0].l_out;
     std::vector<uint8_t> keep1(L);
@@ -114,10 +114,9 @@ static int full_mode(int F, int P, int d, int pre, int L, const std::vector<uint
     call2.aux[1] = ff_aux_t{dtab_out[0], dtab_out2[0], dh * 2, planes, (int64_t)L * dh * 2};
     call2.aux[2] = ff_aux_t{dtab_out[1], dtab_out2[1], dh * 2, planes, (int64_t)L * dh * 2};
     const int64_t swaps_before = ctx.swaps;
-    // ... through the exact-output flow (ABI v9): plan behind K1, wait for l_out, size the outputs to it (L_cap = l_out: the aux
+    // ... through the exact-output flow: K1, then plan + wait for l_out, size the outputs to it (L_cap = l_out: the aux
     // planes come out l_out rows apart), then the merge kernel
     FF(ff_ctx_merge_begin(&ctx, &call2));
-    FF(ff_ctx_merge_plan(&ctx, &call2));
     if (ff_ctx_merge_apply(&ctx, &call2, &res[1]) != FF_ERR_STATE) { fprintf(stderr, "apply before wait was not refused\n"); return 6; }
     FF(ff_ctx_merge_wait(&ctx, &call2, &res[1]));
     const int64_t l2 = res[1].l_out;

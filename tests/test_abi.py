@@ -86,8 +86,6 @@ def test_argument_validation_without_gpu():
     assert lib.ff_pair_similarity(16, 1, 10, 3, 16, 16, 16, 16, None) == -2           # 6-byte rows: alignment
     assert lib.ff_pair_similarity(24, 1, 10, 64, 16, 16, 16, 16, None) == -2          # base not 16-byte aligned
     assert lib.ff_plan_merge(None, 1, None, 10, 0.6, 0.7, 0.1, None, None, None, None, None, 0, None) == -1
-    assert lib.ff_plan_prune(16, 1, 10, 8, 5, 2, 16, 16, 16, 16, 16, 1 << 24, None) == -1  # start + n_img > S
-    assert lib.ff_plan_prune(16, 1, 10, 2, 5, 2, 16, 16, 16, 16, 16, 64, None) == -4       # workspace too small
     assert lib.ff_merge_compact(None, None, 1, 10, 64, 10, None, None, 1, None, None, None, 0, None) == -1
     assert lib.ff_head_mean(None, 1, 4, 1, 10, None, None) == -1
     assert lib.ff_last_query_attention(16, 16, 1, 6, 4, 1, 10, 64, 0, 0, 0.1, 1, None, 16, None, 0, 0, None, 0, 16, 1 << 20, None) == -1  # H % H_kv
@@ -152,11 +150,10 @@ def test_context_calls_validate_before_any_hip_call():
     ctx.ws_bytes = lib.ff_workspace_bytes(1024, 1)
     assert lib.ff_ctx_merge_finish(a(ctx), a(call), a(res)) == _lib.ERR_STATE     # finish without begin
     # the exact-output flow is a state machine too: plan needs a begun call, wait a planned one, apply a known result
-    assert lib.ff_ctx_merge_plan(a(ctx), a(call)) == _lib.ERR_STATE
     assert lib.ff_ctx_merge_wait(a(ctx), a(call), a(res)) == _lib.ERR_STATE
     assert lib.ff_ctx_merge_apply(a(ctx), a(call), a(res)) == _lib.ERR_STATE
     assert lib.ff_ctx_merge_collect(a(ctx), a(call), a(res)) == _lib.ERR_STATE
-    assert lib.ff_ctx_merge_plan(a(ctx), None) == -1 and lib.ff_ctx_merge_wait(a(ctx), a(call), None) == -1
+    assert lib.ff_ctx_merge_wait(a(ctx), None, a(res)) == -1 and lib.ff_ctx_merge_wait(a(ctx), a(call), None) == -1
     pc = _lib.FFPruneCall()
     pc.S = 4096
     assert lib.ff_ctx_prune(a(ctx), a(pc)) == -1
@@ -197,3 +194,79 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "CSRC", str(tmp_path / "no_sources"))       # nothing to build from either
     with pytest.raises(_lib.FrameFusionHipError, match="no CPU/eager fallback"):
         _lib.load()
+
+
+# the state diagram of include/framefusion_hip.h as a table: entry point -> the states (ctx->in_flight) it is legal in
+_MERGE_ENTRIES = {
+    "ff_ctx_merge_begin": (0, 1),
+    "ff_ctx_merge_finish": (1,),
+    "ff_ctx_merge_wait": (1,),
+    "ff_ctx_merge_apply": (3,),
+    "ff_ctx_merge_submit": (0, 1),
+    "ff_ctx_merge_collect": (4,),
+    "ff_ctx_merge_mail": (4,),
+    "ff_ctx_prune": (0,),
+    "ff_ctx_prune_from_qk": (0,),
+    "ff_ctx_last_query_importance": (0,),
+    "ff_ctx_gather_mask": (0,),
+}
+
+
+def test_every_illegal_transition_is_refused_and_changes_nothing():
+    """Every (state, entry point) pair the diagram does not allow returns FF_ERR_STATE before any HIP call and leaves the
+    context exactly as it was (so it is still usable: ff_ctx_reset, or the legal call, may follow).  The legal pairs are
+    exercised on the GPU (tests/test_gpu_parity.py, tests/test_gpu_abi_host.py); here a legal call may fail for any other
+    reason - there is no device - but never with FF_ERR_STATE."""
+    lib = _lib.load()
+    a = C.addressof
+    states = (0, 1, 3, 4)
+    assert set(s for legal in _MERGE_ENTRIES.values() for s in legal) <= set(states)
+    assert sorted(n for n in _lib.PROTOTYPES if n.startswith("ff_ctx_") and n not in ("ff_ctx_reset", "ff_ctx_merge_one_launch")) == sorted(_MERGE_ENTRIES)
+
+    def fresh(state):
+        ctx, call, res, pc, lq = _lib.FFCtx(), _lib.FFMergeCall(), _lib.FFMergeResult(), _lib.FFPruneCall(), _lib.FFLqArgs()
+        for f in ("order", "order_next", "inv", "inv_next", "sim", "member", "dst", "keep", "stats", "ws"):
+            setattr(ctx, f, 4096)
+        host = (C.c_int64 * _lib.STAT_WORDS)()
+        ctx.stats_host = C.addressof(host)
+        ctx.cap = 1024
+        ctx.ws_bytes = lib.ff_workspace_bytes(1024, 1)
+        ctx.in_flight = state
+        ctx.res_active = 1 if state == 4 else 0
+        ctx.seq = 7
+        call.L, call.d, call.dtype, call.patch_num, call.fold, call.force_k = 512, 64, _lib.FF_BF16, 8, _lib.FOLD_SEQUENTIAL, -1
+        call.hidden = call.patch_type = 4096
+        res.l_out = 100
+        pc.S, pc.d, pc.n_img, pc.k, pc.H, pc.num, pc.dtype, pc.w_dtype = 512, 64, 100, 5, 1, 1, _lib.FF_BF16, _lib.FF_BF16
+        pc.hidden = pc.hidden_out = pc.attn_w = 4096
+        pc.L_cap = 512
+        lq.dtype, lq.H, lq.H_kv, lq.num, lq.dh = _lib.FF_BF16, 4, 4, 1, 64
+        return ctx, call, res, pc, lq, host
+
+    def invoke(name, ctx, call, res, pc, lq):
+        fn = getattr(lib, name)
+        if name in ("ff_ctx_merge_begin", "ff_ctx_merge_submit", "ff_ctx_merge_mail"):
+            return fn(a(ctx), a(call))
+        if name in ("ff_ctx_merge_finish", "ff_ctx_merge_wait", "ff_ctx_merge_apply", "ff_ctx_merge_collect"):
+            return fn(a(ctx), a(call), a(res))
+        if name == "ff_ctx_prune":
+            return fn(a(ctx), a(pc))
+        if name == "ff_ctx_prune_from_qk":
+            return fn(a(ctx), a(pc), a(lq))
+        if name == "ff_ctx_last_query_importance":
+            return fn(a(ctx), 4096, 4096, _lib.FF_BF16, 4, 4, 1, 512, 64, 0, 0, 0.125, 1, None, 4096, 0, 100, 5, 4096, 1 << 20, None)
+        return fn(a(ctx), 4096, 4096, 2, 512, 512, None)          # ff_ctx_gather_mask
+
+    snapshot = lambda ctx: bytes(C.string_at(a(ctx), C.sizeof(ctx)))
+    refused = 0
+    for name, legal in _MERGE_ENTRIES.items():
+        for state in states:
+            if state in legal:
+                continue
+            ctx, call, res, pc, lq, host = fresh(state)
+            before = snapshot(ctx)
+            assert invoke(name, ctx, call, res, pc, lq) == _lib.ERR_STATE, (name, state)
+            assert snapshot(ctx) == before, (name, state)
+            refused += 1
+            assert lib.ff_ctx_reset(a(ctx), None) == 0 and ctx.in_flight == 0      # ... and the way out works from anywhere
+    assert refused == sum(len(states) - len(v) for v in _MERGE_ENTRIES.values())

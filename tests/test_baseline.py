@@ -3,7 +3,7 @@ framefusion/models/qwen2/modeling_qwen2_baseline.py:26-43, 860-1203).
 
 tests/golden/baseline.npz holds what the reference's own merging block produced on seeded inputs
 (oracle/make_golden_baseline.py).  CPU: the oracle restatement against those vectors.  GPU: the HIP
-path (ff_merge_begin + ff_merge_finish_topk with FF_FOLD_MEAN, through framefusion_amd.baseline)
+path (ff_ctx_merge_begin + ff_ctx_merge_finish with force_k and FF_FOLD_MEAN, through framefusion_amd.baseline)
 against the vectors, against the oracle over a multi-layer schedule, at full size, and inside a
 random-weight transformers Qwen2.
 """
