@@ -123,8 +123,12 @@ static int prune_mode(int argc, char** argv) {
     // the workspace protocol: the select tables are clean again
     std::vector<uint8_t> ws(sc.ctx.ws_bytes);
     CK(hipMemcpy(ws.data(), sc.ctx.ws, ws.size(), hipMemcpyDeviceToHost));
+    // (the level-0 table at the front, the per-slice level-1 tables down from the end; what lies between is the plan's tag and
+    // granule words, which are not zero by design)
     size_t dirty = 0;
-    for (uint8_t b : ws) dirty += b != 0;
+    const size_t l0_bytes = 16 * 260 * 4, tail = ((size_t)(sc.ctx.cap + 4095) / 4096 + 1) * 65536 * 4;
+    for (size_t i = 0; i < l0_bytes; ++i) dirty += ws[i] != 0;
+    for (size_t i = ws.size() - (tail < ws.size() ? tail : 0); i < ws.size(); ++i) dirty += ws[i] != 0;
     printf("L_OUT %lld WS_DIRTY_BYTES %zu CTX_DIRTY %lld\n", (long long)l_out, dirty, (long long)sc.ctx.dirty);
     printf("IMP_FNV %016llx\nKEEP_FNV %016llx\n", (unsigned long long)fnv16(imp), (unsigned long long)fnv8(keep));
     printf("HIDDEN_A_FNV %016llx\nHIDDEN_B_FNV %016llx\n", (unsigned long long)fnv16(oa), (unsigned long long)fnv16(ob));
