@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="form the process group even for one rank: the broadcast / all_gather / all_reduce of the report then "
                          "run through the backend (RCCL) on a 1-GPU box")
+    ap.add_argument("--dp-hooks", default=None, metavar="MODULE",
+                    help="tests only: import MODULE and let it install fault / delay hooks into framefusion_amd.dp")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip cpu_baseline and eager_gpu_baseline")
     ap.add_argument("--no-extra", action="store_true", help="skip extra.configs (C3 / C5 / 7B shape)")
     ap.add_argument("--no-pmc", action="store_true",
@@ -113,6 +115,8 @@ def algorithmic_bytes(L_in, L_out, nv, d, elt, head_dim, pe_outer=1):
 def main():
     args = parse()
     from framefusion_amd import dp
+    if args.dp_hooks:
+        dp.load_hooks(args.dp_hooks)
     # `python bench.py --gpus N` starts its own N ranks (one per GPU) unless a launcher already did
     dp.launch_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:])
     world, rank, local = dp.env_world()

@@ -132,15 +132,32 @@ def _join(dist, backend: str, device, world: int, rank: int, force: bool):
     dist.init_process_group(backend, **kwargs)
 
 
+class Hooks:
+    """The two places where a test may interfere with a job (a rank whose first collective fails, a rank that dawdles inside a
+    barrier).  The product never installs anything: `load_hooks("tests.dp_faults")` - what `bench.py --dp-hooks` and
+    tests/dp_worker.py call - imports a module and lets it replace `dp.hooks`."""
+
+    def first_collective(self, rank: int, attempt: int) -> None:
+        pass
+
+    def in_barrier(self, rank: int, world: int) -> None:
+        pass
+
+
+hooks = Hooks()
+
+
+def load_hooks(module_name: str) -> None:
+    import importlib
+    importlib.import_module(module_name).install(sys.modules[__name__])
+
+
 def _probe(dist, backend: str, device, world: int):
     """The first collective, with a deadline: RCCL transport problems usually HANG rather than raise, so the all_reduce runs
     on a helper thread and a rank that is not through after FF_DP_INIT_TIMEOUT seconds counts as failed (the re-exec that
     follows replaces the process, hung thread included)."""
     import threading
-    fail_rank = os.environ.get("FF_DP_FAIL_RANK")                             # (tests: only this rank fails; default: all)
-    if (os.environ.get("FF_DP_FAIL_FIRST_ATTEMPT") == "1" and attempt() == 0 and
-            (fail_rank is None or int(fail_rank) == int(os.environ.get("RANK", "0")))):   # (tests: exercise the fallback without a broken box)
-        raise RuntimeError("injected failure of the first collective (FF_DP_FAIL_FIRST_ATTEMPT=1)")
+    hooks.first_collective(int(os.environ.get("RANK", "0")), attempt())
     box: Dict[str, object] = {}
 
     def run():
@@ -319,7 +336,7 @@ def bind_to_gpu_numa(device, local_rank: int = 0, local_devices: Optional[Sequen
     sharing = [r for r, d in enumerate(local_devices)
                if numa_of_pci(pci_address(d) if not isinstance(d, str) else d, sysfs)[0] == node]
     allowed = sorted(set(cpus) & set(os.sched_getaffinity(0))) or sorted(cpus)
-    if local_rank in sharing and len(sharing) > 1 and len(allowed) >= 2 * len(sharing):
+    if local_rank in sharing and len(sharing) > 1 and len(allowed) >= len(sharing):       # (at least one core each)
         at, per = sharing.index(local_rank), len(allowed) // len(sharing)
         allowed = allowed[at * per:(at + 1) * per]
     try:
@@ -450,10 +467,7 @@ def barrier(dist):
     if torch.cuda.is_available():
         torch.cuda.synchronize()
     if dist is not None:
-        slow = os.environ.get("FF_DP_SLOW_BARRIER_MS")         # (tests: a rank that dawdles INSIDE the barrier)
-        if slow and dist.get_rank() == dist.get_world_size() - 1:
-            import time
-            time.sleep(float(slow) * 1e-3)
+        hooks.in_barrier(dist.get_rank(), dist.get_world_size())
         dist.barrier()
         if torch.cuda.is_available():
             torch.cuda.synchronize()

@@ -284,7 +284,7 @@ class FrameFusion(nn.Module):
         state["_host_ints"] = {}
         state["last_call"] = None
         state["_ticket"] = None
-        state["_bad_hints"] = set(self.__dict__.get("_bad_hints", ()))
+        state["_bad_hints"] = dict(self.__dict__.get("_bad_hints", {}))
         return state
 
     def __deepcopy__(self, memo):
@@ -345,7 +345,11 @@ class FrameFusion(nn.Module):
         P, pre, n = whole(patch_num), whole(start), whole(length)
         if P is None or pre is None or n is None or P < 1 or pre < 0 or n < P or n % P:
             return None
-        if (P, pre, n // P) in self.__dict__.get("_bad_hints", ()):      # (found wrong on the device in an earlier prefill)
+        bad = self.__dict__.get("_bad_hints")
+        if bad and (P, pre, n // P) in bad:                   # (found wrong on the device in an earlier prefill)
+            bad[(P, pre, n // P)] -= 1                         # ... but not for ever: after 8 prefills the hint gets another chance
+            if bad[(P, pre, n // P)] <= 0:
+                del bad[(P, pre, n // P)]
             return None
         return pre, n // P
 
@@ -498,6 +502,12 @@ class FrameFusion(nn.Module):
     # The one-launch kernel (csrc/ff_resident.hip): the activation fits into the chip's registers + LDS (the LLaVA-Video-7B and
     # Qwen2-VL-7B prefills do) and is read ONCE.  False: always the three launches (A/B measurements, tests).
     one_launch = True
+    # Two more forms the C ABI offers and this host does not use by default (measured slower HERE, profiles/EXPERIMENTS.md
+    # 5.5 / 5.6; both are what a host without a cheap allocator or with cheap call preparation would pick): the attention mask
+    # gathered by the merge call itself into a buffer the caller passes in the call block, and hook + prune as ONE crossing
+    # (ff_ctx_prune_from_qk) at the end of the prune call's preparation.  Public switches: the tests run both.
+    mask_through_call = False
+    prune_in_one_crossing = False
 
     def _merge_submitted(self, st):
         """Outputs first, then ONE crossing that enqueues the whole call (ff_ctx_merge_submit: the one-launch kernel, or K1 + plan +
@@ -730,10 +740,10 @@ class FrameFusion(nn.Module):
         _PACK_I64.pack_into(call, _lib.MERGE_CALL_AUX_OFFSET - 8, n_aux)
         # (the attention mask is gathered behind the call, into a buffer of the OUTPUT length - never a speculative one: see
         # _merge_complete.  The C ABI's other form - mask + an [L_cap, L_cap] buffer in the call block, gathered by
-        # ff_ctx_merge_finish itself - is what a host without a cheap allocator uses; `_mask_through_call` routes through it
+        # ff_ctx_merge_finish itself - is what a host without a cheap allocator uses; `mask_through_call` routes through it
         # for the tests)
         mask_cap, mask_in = None, st["mask_in"]
-        if mask_in is not None and self.__dict__.get("_mask_through_call"):
+        if mask_in is not None and self.mask_through_call:
             mask_cap = torch.empty(1, 1, L_cap, L_cap, dtype=mask_in.dtype, device=mask_in.device)
             _lib.MASK_TRIPLE.pack_into(call, _lib.MERGE_CALL_MASK_OFFSET, mask_in.data_ptr(), mask_cap.data_ptr(), mask_in.element_size())
         else:
@@ -754,7 +764,10 @@ class FrameFusion(nn.Module):
             # frames does so for every prompt, and each wrong hint costs a whole wasted call
             bad = self.__dict__.get("_layout_hint")
             if bad is not None:
-                self.__dict__.setdefault("_bad_hints", set()).add((int(self.patch_num),) + tuple(bad))
+                hints = self.__dict__.setdefault("_bad_hints", {})
+                if len(hints) >= 16:                           # (bounded: the oldest entry goes)
+                    hints.pop(next(iter(hints)))
+                hints[(int(self.patch_num),) + tuple(bad)] = 8
             self._layout_hint = None
         if rc:
             _fail(rc, "merge", err)
@@ -893,7 +906,7 @@ class FrameFusion(nn.Module):
                 if sc.lq_ws is not None and sc.last_stream is not None:
                     sc.lq_ws.record_stream(sc.last_stream)
                 sc.lq_ws = torch.empty(need, dtype=torch.uint8, device=device)
-            one_crossing = bool(self.__dict__.get("_prune_one_crossing"))
+            one_crossing = bool(self.prune_in_one_crossing)
             if not one_crossing:
                 # the importance kernels go out NOW, before any output tensor exists: the allocations and descriptors below
                 # (~30 us of host work) run under them.  (ff_ctx_prune_from_qk - importance, plan and gather enqueued by one

@@ -16,6 +16,8 @@ keeps its own scratch, state machine and by-patch order.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
@@ -25,13 +27,28 @@ from .main import FrameFusion
 _STREAM_PAIRS = {}
 
 
+STREAM_SOURCE = {}        # device key -> "hip runtime (<path>)" | "torch pool": which streams the pair got (bench.py reports it)
+
+
+def _loaded_hip_runtime() -> str:
+    """Path of the HIP runtime THIS process has mapped (the one torch loaded and libframefusion_hip.so resolved its SONAME
+    against): a stream handed to torch.cuda.ExternalStream must come from that very runtime, not from another copy a bare
+    SONAME might find.  OSError if none is mapped."""
+    with open("/proc/self/maps") as maps:
+        for line in maps:
+            path = line.rsplit(" ", 1)[-1].strip()
+            if "libamdhip64" in os.path.basename(path):
+                return path
+    raise OSError("no libamdhip64 mapped into this process")
+
+
 def _new_hip_stream(device):
     """A stream created through the HIP runtime itself (hipStreamCreateWithFlags, non-blocking), wrapped for PyTorch.  Streams
     from torch's pool were all created when the pool was: which hardware queue each sits on is fixed, and two of them can share
     one - their kernels then run in submission order (1 pool pair in 5 did, profiles/r05_pair_probe.txt: 270 us per two calls
     where independent streams give 231-242).  A stream created NOW gets the least used queue: 4 pairs of 4 ran at 233-239 us."""
     import ctypes
-    hip = ctypes.CDLL("libamdhip64.so.7")                       # (the runtime torch has loaded: same handle)
+    hip = ctypes.CDLL(_loaded_hip_runtime())
     s = ctypes.c_void_p()
     with torch.cuda.device(device):
         rc = hip.hipStreamCreateWithFlags(ctypes.byref(s), ctypes.c_uint(1))      # hipStreamNonBlocking
@@ -47,9 +64,11 @@ def concurrent_streams(device):
     if got is None:
         try:
             got = (_new_hip_stream(device), _new_hip_stream(device))
+            STREAM_SOURCE[key] = f"hip runtime ({_loaded_hip_runtime()})"
         except (OSError, AttributeError):                       # no direct access to the runtime: torch's pool will do
             with torch.cuda.device(device):
                 got = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+            STREAM_SOURCE[key] = "torch pool"
         _STREAM_PAIRS[key] = got
     return got
 

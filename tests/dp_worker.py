@@ -16,6 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from framefusion_amd import dp                       # noqa: E402
 
+dp.load_hooks("tests.dp_faults")                     # (the fault / delay injection of the tests; chosen by their environment)
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -23,9 +25,14 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--seed", type=int, default=100)
+    ap.add_argument("--fake-sysfs", default=None, help="bind every rank like bench.py does, against this sysfs tree: rank r sits on PCI function 0000:<r+1>0:00")
     a = ap.parse_args()
     dp.launch_ranks(a.gpus, os.path.abspath(__file__), sys.argv[1:])      # does not return when it launches
     world, rank, local = dp.env_world()
+    if a.fake_sysfs:
+        # what bench.py does before anything pinned exists (dp.bind_to_gpu_numa), with made-up PCI addresses
+        devs = [f"0000:{r + 1:x}0:00" for r in range(world)]
+        dp.bind_to_gpu_numa(devs[local], local, devs, a.fake_sysfs)
     dist = dp.init("gloo")
     dev = torch.device("cpu")
     # every rank but 0 holds a WRONG local seed: the broadcast must overwrite it
@@ -58,7 +65,13 @@ def main():
     if rank == 0:
         print(json.dumps(dict(n_gpus=world, ranks=dist.get_world_size() if dist else 1, records=recs, t_max=t_max,
                               t_all=t_all, units=units, seed=cfg["seed"], steps=cfg["steps"], identities=ids, kept=kept_all, step_us=spreads,
-                              L=L)))
+                              L=L,
+                              # the per-rank block of bench.py's line (what the driver's scaling parser reads), same keys
+                              per_rank=[{"rank": r, "gpu": r, "tokens_in": int(rec[0]), "tokens_out": int(rec[1]), "ms_per_step": rec[2],
+                                         "seed": dp.sample_seed(cfg["seed"], r), "hostname": w.get("hostname"), "pid": w.get("pid"),
+                                         "pci_bus_id": w.get("pci_bus_id"), "numa_node": w.get("numa_node"), "cpus": w.get("cpus"),
+                                         "step_us": su, "kept_indices": {"n": len(kx)}}
+                                        for r, (rec, w, su, kx) in enumerate(zip(recs, ids, spreads, kept_all))])))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

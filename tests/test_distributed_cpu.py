@@ -120,6 +120,42 @@ def test_numa_binding_reads_sysfs(tmp_path):
         dp._BOUND.update(numa_node=None, cpus=None)
 
 
+@pytest.mark.timeout(600)
+def test_eight_ranks_bind_to_eight_disjoint_cpu_sets_and_report_the_scaling_schema(tmp_path):
+    """The N = 8 job the driver will start on an 8-GPU node, as far as a box without GPUs can run it: 8 gloo ranks through
+    dp.launch_ranks / dp.init / dp.timed_steps, every rank bound (dp.bind_to_gpu_numa) against a fake 2-socket sysfs tree -
+    GPUs 0-3 on node 0, 4-7 on node 1, each node holding half of this machine's cores - before anything else happens.  Eight
+    disjoint cpu sets of equal size; the all_gathered per-rank block carries the keys bench.py's line has."""
+    from framefusion_amd import dp
+    mine = sorted(os.sched_getaffinity(0))
+    if len(mine) < 8:
+        pytest.skip("needs 8 cores for 8 disjoint sets")
+    mine = mine[: len(mine) // 8 * 8]
+    half = len(mine) // 2
+    for r in range(8):
+        d = tmp_path / "bus/pci/devices" / f"0000:{r + 1:x}0:00.0"
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text(f"{r // 4}\n")
+    for node, cpus in ((0, mine[:half]), (1, mine[half:])):
+        d = tmp_path / "devices/system/node" / f"node{node}"
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(dp.compact_cpulist(cpus) + "\n")
+    out = run_worker("--gpus", "8", "--steps", "2", "--warmup", "1", "--fake-sysfs", str(tmp_path))
+    assert out["n_gpus"] == 8 and out["ranks"] == 8 and len(out["per_rank"]) == 8
+    sets = [set(dp.parse_cpulist(p["cpus"])) for p in out["per_rank"]]
+    assert all(len(s) == len(mine) // 8 for s in sets)
+    assert len(set().union(*sets)) == sum(len(s) for s in sets) == len(mine)            # disjoint, and nothing left over
+    assert [p["numa_node"] for p in out["per_rank"]] == [0, 0, 0, 0, 1, 1, 1, 1]
+    for r, p in enumerate(out["per_rank"]):
+        assert set(p) >= {"rank", "gpu", "tokens_in", "tokens_out", "ms_per_step", "seed", "hostname", "pid", "pci_bus_id",
+                          "numa_node", "cpus", "step_us", "kept_indices"}
+        assert p["rank"] == r and p["tokens_out"] < p["tokens_in"] and p["ms_per_step"] > 0
+        assert set(p["step_us"]) >= {"min", "median", "p90", "max"}
+        assert sets[r] <= set(mine[:half] if r < 4 else mine[half:])
+    assert len({p["pid"] for p in out["per_rank"]}) == 8 and len({p["seed"] for p in out["per_rank"]}) == 8
+    assert out["t_max"] >= max(p["ms_per_step"] for p in out["per_rank"]) * out["steps"] / 1e3 * 0.999
+
+
 def test_single_rank_does_not_launch():
     out = run_worker("--gpus", "1", "--steps", "2", "--warmup", "0")
     assert out["n_gpus"] == 1 and out["ranks"] == 1 and len(out["records"]) == 1

@@ -77,7 +77,7 @@ def test_eight_ranks_sharing_one_gpu_over_gloo():
     all_gathered, one JSON line comes out.  (RCCL itself needs 8 devices; gloo carries the scalars here.)"""
     # the last rank dawdles 300 ms inside every barrier (FF_DP_SLOW_BARRIER_MS): the closing barrier of the timed region is
     # in nobody's clock, so 5 steps of eight ranks sharing one GPU (~1.2 ms each) stay far below it
-    out = run_bench("--gpus", "8", "--steps", "5", "--warmup", "2", "--backend", "gloo", "--oversubscribe",
+    out = run_bench("--gpus", "8", "--steps", "5", "--warmup", "2", "--backend", "gloo", "--oversubscribe", "--dp-hooks", "tests.dp_faults",
                     env_extra={"FF_DP_SLOW_BARRIER_MS": "300"})
     check_multi(out, 8)
     assert out["collective_backend"] == "gloo"

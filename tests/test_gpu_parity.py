@@ -921,7 +921,7 @@ def test_attention_mask_is_gathered_like_the_reference(mdtype, L, through_call):
     f = ffa.FrameFusion(0.3, 0.6, 0.1)
     # through_call: the mask and an [L, L] capacity buffer travel in the call block and ff_ctx_merge_finish gathers (the C
     # ABI's form for hosts that allocate up front); else FrameFusion.forward's own: an exactly sized buffer, ff_ctx_gather_mask
-    f._mask_through_call = through_call
+    f.mask_through_call = through_call
     got, mg = harness.run_cascade(f, dev(h), dev(pt), P, dev(torch.arange(L)[None]), dev(mask),
                                   layers=3, heads=2, num=1, start=3, n_visual=F * P)
     assert [r["length"] for r in got] == [r["length"] for r in want] and got[-1]["finish_pruning"]
@@ -1098,7 +1098,7 @@ def test_prune_from_qk_equals_hook_then_prune(dtype, H, Hk, num, S, d, dh, conta
     # the single-crossing form of the C ABI (ff_ctx_prune_from_qk: importance, plan and gather enqueued by ONE call; the Python
     # host launches the importance early instead and uses two)
     f4 = fresh()
-    f4._prune_one_crossing = True
+    f4.prune_in_one_crossing = True
     o4, p4, m4 = f4.prune_from_qk(h, pos(), mask, q, k, num=num, is_causal=True, residual=res)
     assert same_bits(o4.cpu(), o2.cpu()) and not f4._scratch[("cuda", 0)].dirty
     assert (m4 is None) == (m2 is None) and (m4 is None or same_bits(m4.cpu(), m2.cpu()))

@@ -2,7 +2,7 @@
 """A/B of the three ways a prune call gets its importance (development tool; one process, forms interleaved, several rounds):
   hook      last_query_importance(q, k, framefusion=ff) in the attention hook, then forward(..., importance)     (rounds 3-4)
   early     forward(..., LastQuery handle): importance launched at the top of _prune, plan + gather at its end  (shipped)
-  one       forward(..., LastQuery handle) with ff._prune_one_crossing: ff_ctx_prune_from_qk at the end of _prune
+  one       forward(..., LastQuery handle) with ff.prune_in_one_crossing: ff_ctx_prune_from_qk at the end of _prune
 Whole prefill cascades of a trace_config configuration back to back.   python tools/ab_prune_forms.py [c3|c5|c2thr] [rounds]"""
 import os, sys, time
 import torch
@@ -29,7 +29,7 @@ k_of = {}
 def make(form):
     ff = ffa.FrameFusion(0.3, c["thr"], 0.1, compact_outputs=False)
     if form == "one":
-        ff._prune_one_crossing = True
+        ff.prune_in_one_crossing = True
 
     def prefill():
         ff.prepare(pt, P, c["pre"], c["pre"] + F * P - 1, F * P, L)
