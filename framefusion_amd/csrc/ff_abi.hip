@@ -293,15 +293,15 @@ extern "C" int ff_ctx_merge_begin(ff_ctx_t* c, const ff_merge_call_t* a) {
 // threads of an oversubscribed host keep their cores.  The stream is looked at after 1 ms and then every ~50 us of
 // waiting: a drained or failed stream ends the wait.
 #include <sched.h>
-static int ctx_wait(ff_ctx_t* c, hipStream_t st, int64_t* waited_ns) {
-    volatile int64_t* host = c->stats_host;
+static int ctx_wait(ff_ctx_t* c, hipStream_t st, int64_t* waited_ns, int word = FF_STAT_SEQ, int shift = 0) {
+    volatile int64_t* host = c->stats_host + (word - FF_STAT_SEQ);      // (the loop below names the word FF_STAT_SEQ)
     const int64_t seq = c->seq;
     const int64_t t0 = now_ns();
     int64_t next_query = t0 + 1000000;               // first look at the stream after 1 ms
     int rc = FF_OK;
     int phase = 0;                                   // 0 spin, 1 yield, 2 sleep
     for (uint32_t spins = 0;; ++spins) {
-        if (__atomic_load_n(&host[FF_STAT_SEQ], __ATOMIC_ACQUIRE) == seq) break;
+        if ((__atomic_load_n(&host[FF_STAT_SEQ], __ATOMIC_ACQUIRE) >> shift) == seq) break;
         if (phase == 0) {
             cpu_relax();
             if ((spins & 255u) != 255u) continue;
@@ -318,7 +318,7 @@ static int ctx_wait(ff_ctx_t* c, hipStream_t st, int64_t* waited_ns) {
         hipError_t e = hipStreamQuery(st);
         if (e == hipErrorNotReady) continue;
         // the stream drained (or failed): the block is there now or never will be
-        if (__atomic_load_n(&host[FF_STAT_SEQ], __ATOMIC_ACQUIRE) == seq) break;
+        if ((__atomic_load_n(&host[FF_STAT_SEQ], __ATOMIC_ACQUIRE) >> shift) == seq) break;
         rc = e == hipSuccess ? FF_ERR_DEVICE : (int)e;
         break;
     }
@@ -347,6 +347,7 @@ static int ctx_finish(ff_ctx_t* c, const ff_merge_call_t* a, ff_merge_result_t* 
     r->wait_ns = 0;
     r->applied = 0;
     bool resident = c->res_active == 1;            // the first attempt is the one-launch kernel
+    bool pending = false;
     const bool guarded = c->res_active == 2;       // ... or three launches, the merge kernel blind into buffers of a guessed length
     c->res_active = 0;
     for (int attempt = 0;; ++attempt) {
@@ -389,12 +390,19 @@ static int ctx_finish(ff_ctx_t* c, const ff_merge_call_t* a, ff_merge_result_t* 
         r->k = h[FF_STAT_K];
         r->l_out = h[FF_STAT_LOUT];
         if (resident) {
-            if (h[FF_STAT_APPLIED]) c->dirty = 0;       // (the one-launch kernel leaves the select tables alone)
+            if (h[FF_STAT_APPLIED] == 1) c->dirty = 0;  // (the one-launch kernel leaves the select tables alone)
+            else if (h[FF_STAT_APPLIED] == 2) pending = true;      // the kernel waits for outputs of l_out rows, by mail
             else phase = 1;                              // the plan only: the merge kernel is still to come
         } else if (guarded && phase == 3 && r->l_out != a->L && r->l_out != a->L_cap) {
             phase = 1;                                   // the blind merge kernel found another length than its buffers': nothing written
         }
         break;
+    }
+    if (pending) {                         // ff_ctx_merge_apply hands over / confirms the outputs; no launch
+        c->in_flight = 3;
+        c->res_active = 3;
+        r->applied = 2;
+        return FF_OK;
     }
     if (phase == 1) {                      // the merge kernel is still to come (ff_ctx_merge_apply)
         c->in_flight = 3;
@@ -525,6 +533,8 @@ extern "C" int ff_ctx_merge_submit(ff_ctx_t* c, const ff_merge_call_t* a) {
         // the outputs follow by mail: the slot is invalidated first (plain host stores; the kernel compares the sequence word)
         volatile int64_t* m = c->stats_host + FF_MAIL_WORD;
         m[0] = 0;
+        m[FF_MAIL_WORDS] = 0;
+        c->stats_host[FF_STAT_ACK] = 0;
         p.mail = c->stats_host + FF_MAIL_WORD;
         p.hidden_out = nullptr; p.L_cap = 0;
     }
@@ -535,22 +545,33 @@ extern "C" int ff_ctx_merge_submit(ff_ctx_t* c, const ff_merge_call_t* a) {
     return FF_OK;
 }
 
-extern "C" int ff_ctx_merge_mail(ff_ctx_t* c, const ff_merge_call_t* a) {
-    if (!a) return FF_ERR_ARG;
-    int rc = ctx_check(c, a->L);
-    if (rc) return rc;
-    if (c->in_flight != 4 || c->res_active != 1) return FF_ERR_STATE;
+// the outputs of `a` into the next free mail slot of the call (1: before the result is known, 2: sized to it)
+static int ctx_mail(ff_ctx_t* c, const ff_merge_call_t* a) {
     if (a->n_aux < 0 || a->n_aux > FF_MAX_AUX) return FF_ERR_ARG;
     if ((uintptr_t)a->hidden_out & 15) return FF_ERR_ALIGN;
     for (int x = 0; x < (a->hidden_out ? (int)a->n_aux : 0); ++x)
         if (!a->aux[x].dst) return FF_ERR_ARG;
     int64_t* m = c->stats_host + FF_MAIL_WORD;
+    int slot = 1;
+    if (m[0] == c->seq * 4 + 1) {
+        if (m[FF_MAIL_WORDS] == c->seq * 4 + 2) return FF_ERR_STATE;          // both slots of this call are written
+        slot = 2;
+        m += FF_MAIL_WORDS;
+    }
     m[1] = (int64_t)(uintptr_t)a->hidden_out;
     m[2] = a->hidden_out ? a->L_cap : 0;
     m[3] = a->hidden_out ? a->n_aux : 0;
     for (int x = 0; x < FF_MAX_AUX; ++x) m[4 + x] = x < a->n_aux ? (int64_t)(uintptr_t)a->aux[x].dst : 0;
-    __atomic_store_n(&m[0], c->seq, __ATOMIC_RELEASE);
+    __atomic_store_n(&m[0], c->seq * 4 + slot, __ATOMIC_RELEASE);
     return FF_OK;
+}
+
+extern "C" int ff_ctx_merge_mail(ff_ctx_t* c, const ff_merge_call_t* a) {
+    if (!a) return FF_ERR_ARG;
+    int rc = ctx_check(c, a->L);
+    if (rc) return rc;
+    if (!((c->in_flight == 4 && c->res_active == 1) || (c->in_flight == 3 && c->res_active == 3))) return FF_ERR_STATE;
+    return ctx_mail(c, a);
 }
 
 extern "C" int ff_ctx_merge_collect(ff_ctx_t* c, const ff_merge_call_t* a, ff_merge_result_t* r) {
@@ -584,6 +605,35 @@ extern "C" int ff_ctx_merge_apply(ff_ctx_t* c, const ff_merge_call_t* a, const f
     if (c->in_flight != 3) return FF_ERR_STATE;
     if (a->mask && !a->mask_out) return FF_ERR_ARG;
     if (r->l_out != c->stats_host[FF_STAT_LOUT] || r->l_out < 0 || r->l_out > a->L) return FF_ERR_ARG;      // not this call's result
+    if (c->res_active == 3) {
+        // a one-launch kernel is waiting, rows in hand, for outputs of l_out rows: the call block's go out by mail unless a mail
+        // that holds them is on its way already (then the call block must name the same buffers), and the kernel's answer is
+        // awaited (~2 PCIe round trips).  "None came in time" (a host that took > 4 ms): the merge kernel follows as below.
+        if (!a->hidden_out || a->L_cap < r->l_out) return FF_ERR_ARG;
+        const int64_t* m = c->stats_host + FF_MAIL_WORD;
+        int sent = 0;
+        for (int slot = 2; slot >= 1 && !sent; --slot) {
+            const int64_t* ms = m + (slot - 1) * FF_MAIL_WORDS;
+            // (slot 1 was written before the result was known: it counts when it holds exactly l_out rows - a guess that came
+            // true - or a whole input; a longer guess is not what a caller of exactly sized outputs wants written)
+            if (ms[0] == c->seq * 4 + slot && ms[1] && (slot == 2 ? ms[2] >= r->l_out : (ms[2] == r->l_out || ms[2] >= a->L))) sent = slot;
+        }
+        if (sent && (m[(sent - 1) * FF_MAIL_WORDS + 1] != (int64_t)(uintptr_t)a->hidden_out || m[(sent - 1) * FF_MAIL_WORDS + 2] != a->L_cap))
+            return FF_ERR_ARG;
+        if (!sent) {
+            rc = ctx_mail(c, a);
+            if (rc) return rc;
+        }
+        c->res_active = 0;
+        c->in_flight = 0;
+        int64_t waited = 0;
+        rc = ctx_wait(c, (hipStream_t)a->stream, &waited, FF_STAT_ACK, 2);
+        if (rc) { c->dirty = 1; c->order_len = 0; return rc; }
+        if ((c->stats_host[FF_STAT_ACK] & 3) != 3) {
+            c->dirty = 0;
+            return ctx_after_result(c, a, r);
+        }
+    }
     c->in_flight = 0;
     rc = ctx_finish_enqueue(c, a, 2, r->l_out);
     if (rc) { c->dirty = 1; c->order_len = 0; return rc; }

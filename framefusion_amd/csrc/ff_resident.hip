@@ -48,11 +48,13 @@ static_assert(kResRows <= 62 && kResRV % 2 == 0 && kResRL % 2 == 0, "rows are ha
 
 // barrier state, 128-byte lines, zero between launches (the last arriver of every stage resets its word)
 struct ResBar {
-    unsigned cnt[8][32];
-    unsigned top[32];
-    unsigned gen[8][32];
+    // arrival words: arrivals in bits 0-11, and what the arrivers bring along - the number of their similarities in the threshold
+    // set (bits 12-31) and above IGNORE_TOKEN (bits 32-51): the release word hands the two totals to everybody
+    unsigned long long cnt[8][16];
+    unsigned long long top[16];
+    unsigned long long gen[8][16];       // release word: tag (24 bits, never 0) | threshold-set total (20) | above-ignore total (20)
     unsigned abort_tag[32];
-    unsigned long long mail_tag[16];     // outputs by mail, relayed into device memory by ONE wave: tag (= seq) ...
+    unsigned long long mail_tag[16];     // outputs by mail, relayed into device memory by ONE wave: 4 * seq + slot (3: none came) ...
     unsigned long long mail[16];         // ... and the words {., hidden_out, L_cap, n_aux, dst[4]}
 };
 static_assert(sizeof(ResBar) <= 4096, "ff_plan.hip reserves 4 KB of the workspace front");
@@ -137,21 +139,35 @@ __device__ inline unsigned add_agent(unsigned* p, unsigned v) { return __hip_ato
 // block is observed to run on - for speed only, nothing depends on it).  One thread per workgroup; every writing wave has drained
 // its write-through stores and the workgroup has passed __syncthreads().  Returns false if the launch was aborted: a workgroup
 // waited longer than ~2 ms (another barrier kernel holds CUs this one needs: two samples on two streams), everybody leaves.
-__device__ inline bool res_barrier(ResBar* gb, int bid, int nwg, unsigned tag) {
+__device__ inline unsigned long long ld_agent64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void st_agent64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline unsigned long long add_agent64(unsigned long long* p, unsigned long long v) {
+    return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Returns the release word's two totals (threshold set << 20 | above ignore), or -1 if the launch was aborted.
+__device__ inline long long res_barrier(ResBar* gb, int bid, int nwg, unsigned tag, int thr_n, int gt_n) {
     const int g = bid & 7;
     const unsigned gsize = (unsigned)((nwg + 7 - g) >> 3);
     const unsigned ngroups = (unsigned)(nwg < 8 ? nwg : 8);
-    if (add_agent(&gb->cnt[g][0], 1u) + 1 == gsize) {
-        st_agent(&gb->cnt[g][0], 0u);
-        if (add_agent(&gb->top[0], 1u) + 1 == ngroups) {
-            st_agent(&gb->top[0], 0u);
-            for (unsigned x = 0; x < ngroups; ++x) st_agent(&gb->gen[x][0], tag);
+    const unsigned long long tag24 = (unsigned long long)(tag % 0xffffffu) + 1ull;
+    const unsigned long long mine = 1ull | ((unsigned long long)thr_n << 12) | ((unsigned long long)gt_n << 32);
+    const unsigned long long now = add_agent64(&gb->cnt[g][0], mine) + mine;
+    if ((unsigned)(now & 0xfffull) == gsize) {
+        st_agent64(&gb->cnt[g][0], 0ull);
+        const unsigned long long up = (now & ~0xfffull) | 1ull;
+        const unsigned long long t = add_agent64(&gb->top[0], up) + up;
+        if ((unsigned)(t & 0xfffull) == ngroups) {
+            st_agent64(&gb->top[0], 0ull);
+            const unsigned long long word = (tag24 << 40) | (((t >> 12) & 0xfffffull) << 20) | ((t >> 32) & 0xfffffull);
+            for (unsigned x = 0; x < ngroups; ++x) st_agent64(&gb->gen[x][0], word);
         }
     }
     const long long t0 = wall_clock64();                                   // 100 MHz
     bool ok = true;
+    unsigned long long w = 0;
     for (unsigned spins = 0;; ++spins) {
-        if (ld_agent(&gb->gen[g][0]) == tag) break;
+        w = ld_agent64(&gb->gen[g][0]);
+        if ((w >> 40) == tag24) break;
         __builtin_amdgcn_s_sleep(2);
         if ((spins & 63u) == 63u) {
             if (ld_agent(&gb->abort_tag[0]) == tag) { ok = false; break; }
@@ -161,8 +177,16 @@ __device__ inline bool res_barrier(ResBar* gb, int bid, int nwg, unsigned tag) {
     // (no acquire fence: everything read across workgroups behind the barrier - the similarities, the error word - was stored
     // write-through / by an atomic and is loaded with agent-scope loads, which do not look at the CU's L1; an L1 invalidation
     // costs ~1.5 us per workgroup here)
-    return ok;
+    return ok ? (long long)(w & 0xffffffffffull) : -1ll;
 }
+
+// raw bits of a T value -> order-preserving 16-bit key (negative values inverted, the others get the sign bit; NaN -> 0xffff)
+__device__ inline uint32_t res_key16(uint32_t bits) {
+    uint32_t k = (bits & 0x8000u) ? (~bits & 0xffffu) : (bits | 0x8000u);
+    if ((bits & 0x7fffu) > 0x7f80u) k = 0xffffu;
+    return k;
+}
+constexpr uint32_t kResIgnoreKey = 0x3fffu;      // key of IGNORE_TOKEN = -2.0 (main.py:225-238) in bf16
 
 constexpr size_t kResPartBytes = (size_t)(kResRows + 2) * kResWaves * 8;          // float2 [rows + 2][waves]
 struct ResLds {
@@ -211,6 +235,16 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
     const unsigned tag = (unsigned)a.seq;
     // phase stamps of workgroup 0 (100 MHz wall clock, relative to its start): stats[FF_STAT_T_PLAN ..], diagnostics
     const long long stamp0 = wall_clock64();
+#ifdef FF_RES_WGSTAMPS
+    // (diagnostic build, tools/flow_stamps.py --wg: earliest / latest workgroup start and end on the device's 100 MHz clock, in the
+    // spare words of the barrier page)
+    unsigned long long* wgdbg = (unsigned long long*)a.bar + 384;
+    if (tid == 0) {
+        atomicMax(&wgdbg[0], ~0ull - (unsigned long long)stamp0);
+        atomicMax(&wgdbg[1], (unsigned long long)stamp0);
+        if (bid == 0) wgdbg[4] = (unsigned long long)stamp0;
+    }
+#endif
     long long stamp[7] = {0, 0, 0, 0, 0, 0, 0};
     long long sub[8] = {0, 0, 0, 0, 0, 0, 0, 0};               // finer stamps (stats[FF_STAT_T_ORDER ..])
     const int F = a.hint_frames, P = a.hint_patches, pre = a.hint_pre;
@@ -383,6 +417,8 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
     __syncthreads();
     stamp[0] = wall_clock64() - stamp0;                       // rows in, norms and dots done
     // ---- similarities of my slots (wave 0: lane <-> slot), published write-through
+    const PlanParams& pp = a.pp;
+    int my_thr = 0, my_gt = 0;
     if (wv == 0) {
         const bool mine = lane < n;
         float sv = -2.0f;                                   // IGNORE_TOKEN (main.py:225-238)
@@ -398,13 +434,23 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
         }
         const uint32_t bits = __float_as_uint(sv) >> 16;
         if (mine) __hip_atomic_store((uint16_t*)a.sim + (s0 + lane), (uint16_t)bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // what the barrier carries to everybody: how many of my similarities are in the threshold set (main.py:113) and how many
+        // are real ones (above IGNORE_TOKEN) - the two totals ARE the decision and the output length (below)
+        const uint32_t key = res_key16(bits);
+        my_thr = __popcll(__ballot(mine && (key - pp.thr_key) < (0xffffu - pp.thr_key)));
+        my_gt = __popcll(__ballot(mine && key > kResIgnoreKey));
     } else {
         // (the plan's histograms start from zero)
         for (int z = tid - kWave; z < 256 + 8 * 256 + 8; z += kResThreads - kWave) hist0[z] = 0;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) bcast[15] = res_barrier(a.bar, bid, G, tag) ? 1 : 0;
+    if (tid == 0) {
+        const long long totals = res_barrier(a.bar, bid, G, tag, my_thr, my_gt);
+        bcast[15] = totals >= 0 ? 1 : 0;
+        bcast[8] = (int)((totals >> 20) & 0xfffff);
+        bcast[9] = (int)(totals & 0xfffff);
+    }
     __syncthreads();
     if (!bcast[15]) {
         // aborted: the select tables and the barrier words are in no defined state - the host resets the workspace and
@@ -413,31 +459,9 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
         return;
     }
 
-    // ---- outputs by mail: ONE wave of the launch reads the host's words (a device read of host memory is a PCIe round trip,
-    // ~2.5 us, and the link takes only a few dozen of them at a time: every workgroup asking for itself cost 270 us) and relays
-    // them into device memory, where everybody picks them up behind the plan
-    if (a.mail && bid == G - 1 && wv == kResWaves - 1) {
-        int ok = 1;
-        if (lane == 0) {
-            for (unsigned spins = 0; __hip_atomic_load(&a.mail[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != (int64_t)a.seq; ++spins) {
-                __builtin_amdgcn_s_sleep(16);
-                if (spins > (1u << 17)) { ok = 0; break; }              // (~0.5 s: a dead host)
-            }
-        }
-        ok = __builtin_amdgcn_readfirstlane(ok);
-        unsigned long long w = 0;
-        if (lane < FF_MAIL_WORDS) w = (unsigned long long)__hip_atomic_load(&a.mail[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (lane == 1 && !ok) w = 0;                                     // (no outputs: the launch stops behind its plan)
-        if (lane == 3 && !ok) w = ~0ull;                                 // (... and says why)
-        if (lane < FF_MAIL_WORDS) __hip_atomic_store(&a.bar->mail[lane], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(&a.bar->mail_tag[0], (unsigned long long)a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-
     // ======================================================================================================================
     // B. plan (every workgroup for itself)
     stamp[1] = wall_clock64() - stamp0;                       // barrier passed
-    const PlanParams& pp = a.pp;
     // ---- my 32 similarities (bit e <-> slot 32 * tid + e) as order-preserving keys, two per word
     // (a 16-byte buffer access that crosses the end of the range is out of range as a WHOLE, so the range is rounded up to
     // whole words: the context's `sim` holds 4 bytes per token of capacity; what lies past nv is masked by `valid`)
@@ -447,6 +471,97 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
 #pragma unroll
     for (int x = 0; x < kResKeys / 8; ++x) kx[x] = buf_load16s<16>(sres_rsrc, (uint32_t)(t_base + x * 8) * 2u, 0u);      // (aux 16 = sc1: agent scope)
     const long long err_bits = (long long)__hip_atomic_load((unsigned long long*)(a.stats + FF_STAT_ERROR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ---- the decision (main.py:114-127) and the output length need nothing but the two totals the barrier brought: every wave
+    // works them out for itself (the same scalars from the same LDS words), and the result block leaves NOW - the host learns
+    // l_out ~13 us before the plan below is through and prepares what follows the call under it
+    const int count = uniform(bcast[8]), n_real = uniform(bcast[9]);
+    bool is_topk;
+    int k_sel;
+    {
+        long long k;
+        if (pp.k_given >= 0) {
+            is_topk = true;                               // fixed-sparsity policy (modeling_qwen2_baseline.py:920,1001)
+            k = pp.k_given > nv ? (long long)nv : pp.k_given;
+        } else {
+            // main.py:114-116 in double, as python: ratio = count / ftn ; ratio < sub ?
+            const double ratio = ftn > 0 ? (double)count / (double)ftn : 0.0;
+            is_topk = !(ratio < pp.sub);
+            k = 0;
+            if (is_topk) {
+                k = (long long)(pp.sub * (double)ftn);   // int(sub * ftn), main.py:122
+                if (k > nv) k = nv;
+                if (k < 0) k = 0;
+            }
+        }
+        k_sel = uniform((int)k);
+    }
+    const bool topk = is_topk && k_sel > 0;
+    // slot 0 never folds (it has no predecessor; its similarity is IGNORE_TOKEN, the FIRST of the ties at that value): it is in
+    // the top-k set iff k exceeds the real similarities, in the threshold set iff the threshold lies below IGNORE_TOKEN
+    const bool slot0_thr = (kResIgnoreKey - pp.thr_key) < (0xffffu - pp.thr_key);
+    const int members_e = topk ? k_sel - (k_sel > n_real ? 1 : 0) : (is_topk ? 0 : count - (slot0_thr ? 1 : 0));
+    const int l_out = L - members_e;
+    const long long tag_mail = (long long)a.seq * 4;          // + slot (1, 2): a mail of this call; + 3: none came in time
+    if (bid == 0 && wv == kResWaves - 1) {
+        // the result block leaves through the last wave of workgroup 0: one lane per word.  APPLIED = 2: the outputs come by mail
+        // and this launch waits for them behind its plan (ff_ctx_merge_apply confirms: word FF_STAT_ACK)
+        const long long e = err_bits;
+        if (lane < FF_STAT_T_ORDER && lane != FF_STAT_SEQ) {            // (the words behind are the host's: FF_MAIL_WORD)
+            long long vres = 0;
+            const double ratio = ftn > 0 ? (double)count / (double)ftn : 0.0;
+            switch (lane) {
+                case FF_STAT_NV: vres = nv; break;
+                case FF_STAT_FTN: vres = ftn; break;
+                case FF_STAT_COUNT: vres = count; break;
+                case FF_STAT_BRANCH: vres = is_topk ? 1 : 0; break;
+                case FF_STAT_K: vres = k_sel; break;
+                case FF_STAT_MERGED: vres = L - l_out; break;
+                case FF_STAT_LOUT: vres = l_out; break;
+                case FF_STAT_BELOW_LB: vres = (!is_topk && ratio < pp.ratio_lb) ? 1 : 0; break;
+                case FF_STAT_APPLIED: vres = l_out == L ? 1 : (a.mail ? 2 : ((a.out != nullptr && a.L_cap >= (long long)l_out) ? 1 : 0)); break;
+                default: break;
+            }
+            if (e) vres = 0;
+            if (lane == FF_STAT_ERROR) vres = e;
+            if (!e && lane != FF_STAT_ERROR && lane != FF_STAT_ACK) a.stats[lane] = vres;
+            if (lane == FF_STAT_ERROR) a.stats[lane] = 0;                       // reported: the next call starts clean
+            if (lane != FF_STAT_ACK) __hip_atomic_store(&a.host_mapped[lane], vres, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        if (lane == 0) __hip_atomic_store(&a.host_mapped[FF_STAT_SEQ], (int64_t)a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (err_bits) return;                                     // (the host resets the workspace and repeats the call)
+    sub[3] = wall_clock64() - stamp0;                         // result block on its way
+    // ---- outputs by mail: ONE wave of the launch reads the host's words (a device read of host memory is a PCIe round trip,
+    // ~2.5 us, and the link takes only a few dozen of them at a time: every workgroup asking for itself cost 270 us) and relays
+    // them into device memory, where everybody picks them up behind the plan.  Two slots, each written once per call (words,
+    // then its tag): the first for outputs allocated before the result was known (a guessed length), the second for outputs
+    // sized to the l_out published above.  The first mail that holds l_out rows is taken and acknowledged.
+    const bool wants_mail = a.mail != nullptr && l_out != L;
+    const bool relay_wave = wants_mail && bid == G - 1 && wv == kResWaves - 1;
+    // one look at the host's slots (0: nothing usable there, 1: relayed + acknowledged, 2: slot 1 is there and does not fit)
+    auto relay_try = [&](bool skip1) -> int {
+        long long t = 0;
+        if (lane < 2) t = __hip_atomic_load(&a.mail[lane * FF_MAIL_WORDS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const long long t1 = __shfl(t, 0), t2 = __shfl(t, 1);
+        const int slot = t2 == tag_mail + 2 ? 2 : ((t1 == tag_mail + 1 && !skip1) ? 1 : 0);
+        if (!slot) return 0;
+        long long w = 0;
+        if (lane < FF_MAIL_WORDS) w = __hip_atomic_load(&a.mail[(slot - 1) * FF_MAIL_WORDS + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const long long ptr = __shfl(w, 1), cap = __shfl(w, 2);
+        // slot 1 was written before the result was known: taken when it holds exactly l_out rows (a guessed length that came
+        // true) or a whole input; slot 2 is sized to the result
+        if (!ptr || (slot == 2 ? cap < (long long)l_out : (cap != (long long)l_out && cap < (long long)L))) return slot == 1 ? 2 : 0;
+        if (lane < FF_MAIL_WORDS) __hip_atomic_store(&a.bar->mail[lane], (unsigned long long)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            __hip_atomic_store(&a.bar->mail_tag[0], (unsigned long long)(tag_mail + slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.host_mapped[FF_STAT_ACK], (int64_t)(tag_mail + slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return 1;
+    };
+    int relay_state = 0;
+    if (relay_wave) relay_state = relay_try(false);                            // (one look now, under the plan; the patient ones behind it)
     const uint32_t valid = nv - t_base >= 32 ? 0xffffffffu : (nv - t_base <= 0 ? 0u : (1u << (nv - t_base)) - 1u);
     // raw bits -> keys, both halves of a word at once: negative values are inverted, the others get the sign bit; NaN -> 0xffff
     auto keys2 = [&](uint32_t w) -> uint32_t {
@@ -504,7 +619,6 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
         if (lane == 63) { atomicAdd(&hcnt[0], (int)r0); atomicAdd(&hcnt[1], (int)r1); atomicAdd(&hcnt[2], (int)r2); }
     }
     __syncthreads();                                         // #1
-    sub[7] = wall_clock64() - stamp0;                         // level-0 counts
     // pick: the bin of the rem-th largest entry of a 256-bin histogram (+ more copies of it), and the entries above it - by one wave
     auto pick = [&](const int* h, int copies, int rem, int& bin, int& above) {
         const int top = 255 - 4 * lane;
@@ -525,29 +639,6 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
         bin = __builtin_amdgcn_readlane(bsel, first);
         above = __builtin_amdgcn_readlane(ab, first);
     };
-    // ---- the decision, by every wave for itself (the same scalars from the same LDS words: no broadcast, no barrier)
-    const int count = uniform(hcnt[0]);
-    bool is_topk;
-    int k_sel;
-    {
-        long long k;
-        if (pp.k_given >= 0) {
-            is_topk = true;                               // fixed-sparsity policy (modeling_qwen2_baseline.py:920,1001)
-            k = pp.k_given > nv ? (long long)nv : pp.k_given;
-        } else {
-            // main.py:114-116 in double, as python: ratio = count / ftn ; ratio < sub ?
-            const double ratio = ftn > 0 ? (double)count / (double)ftn : 0.0;
-            is_topk = !(ratio < pp.sub);
-            k = 0;
-            if (is_topk) {
-                k = (long long)(pp.sub * (double)ftn);   // int(sub * ftn), main.py:122
-                if (k > nv) k = nv;
-                if (k < 0) k = 0;
-            }
-        }
-        k_sel = uniform((int)k);
-    }
-    const bool topk = is_topk && k_sel > 0;
     uint32_t kth = 0;
     int need = 0;
     uint32_t mm;
@@ -687,33 +778,55 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
     }
     __syncthreads();                                         // #7
     stamp[3] = wall_clock64() - stamp0;                       // member bits by slot and position, prefix sums
-    const int l_out = L - (members_total < 0 ? 0 : members_total);
-    const bool plan_bad = members_total < 0 || (err_bits != 0);
-    // ---- the outputs: in the launch arguments, or by mail - the host allocated them while the rows were read and wrote their
-    // addresses into pinned memory BEFORE it started to wait for the result block, so whoever waits here waits for a store that
-    // is already on its way (bounded all the same: a dead host must not hang the device)
+    // (the plan and the arithmetic of the published result must agree: an internal check - the result block has left, so a
+    // disagreement is reported through the device's error word, by the next call)
+    const bool plan_bad = members_total != members_e || uniform(hcnt[0]) != count;
+    if (plan_bad && bid == 0 && tid == 0) atomicOr((unsigned long long*)(a.stats + FF_STAT_ERROR), (unsigned long long)FF_ERR_BIT_RESIDENT);
+    // ---- the outputs: in the launch arguments, or by mail.  The host mailed them before it began to wait for the result block
+    // (a guessed length that came true, or input-length buffers) - then the relay wave has them already - or it sizes them to the
+    // l_out it has just read and mails them now: this is where the launch waits for that, rows in hand (the alternative is a
+    // second kernel that reads every row again).  Bounded: a host that does not answer within ~4 ms gets the plan only
+    // (FF_STAT_ACK = 4 seq + 3: ff_ctx_merge_apply follows with the merge kernel).
     char* out_ptr = a.out;
     long long out_cap = a.L_cap;
     int aux_n = a.aux.n;
     unsigned long long* auxdst = (unsigned long long*)sres;          // [FF_MAX_AUX] destinations of the auxiliary tensors (LDS)
     if (tid < FF_MAX_AUX) auxdst[tid] = (unsigned long long)(uintptr_t)a.aux.a[tid].dst;
-    if (a.mail) {
-        if (tid == 0) {
-            int ok = 1;
-            for (unsigned spins = 0; __hip_atomic_load(&a.bar->mail_tag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned long long)a.seq; ++spins) {
-                __builtin_amdgcn_s_sleep(2);
-                if (spins > (1u << 20)) { ok = 0; break; }
+    if (wants_mail) {
+        if (relay_wave && relay_state != 1) {
+            const long long t0 = wall_clock64();
+            while (true) {
+                const int got = relay_try(relay_state == 2);
+                if (got == 1) break;
+                if (got == 2) relay_state = 2;
+                if (wall_clock64() - t0 > 400000) {             // 4 ms
+                    if (lane == 0) {
+                        __hip_atomic_store(&a.bar->mail_tag[0], (unsigned long long)(tag_mail + 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&a.host_mapped[FF_STAT_ACK], (int64_t)(tag_mail + 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
             }
-            bcast[13] = ok;
+        }
+        if (tid == 0) {
+            int got = 3;
+            const long long t0 = wall_clock64();
+            for (unsigned spins = 0;; ++spins) {
+                const unsigned long long v = __hip_atomic_load(&a.bar->mail_tag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((long long)(v >> 2) == (long long)a.seq) { got = (int)(v & 3ull); break; }
+                __builtin_amdgcn_s_sleep(2);
+                if ((spins & 63u) == 63u && wall_clock64() - t0 > 1000000) break;       // (10 ms: the relay wave's bound and more)
+            }
+            bcast[13] = got;
         }
         if (tid >= kWave && tid < kWave + FF_MAIL_WORDS) sres[16 + tid - kWave] = 0;       // (slots of the relayed words)
         __syncthreads();
-        if (tid < FF_MAIL_WORDS && bcast[13])
+        const bool have = bcast[13] == 1 || bcast[13] == 2;
+        if (tid < FF_MAIL_WORDS && have)
             sres[16 + tid] = (long long)__hip_atomic_load(&a.bar->mail[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
-        const bool lost = !bcast[13] || sres[16 + 3] == -1ll;
-        if (lost) {
-            if (tid == 0) atomicOr((unsigned long long*)(a.stats + FF_STAT_ERROR), (unsigned long long)FF_ERR_BIT_RESIDENT);
+        if (!have) {
             out_ptr = nullptr;
             aux_n = 0;
         } else {
@@ -724,43 +837,32 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
             if (tid < FF_MAX_AUX) auxdst[tid] = (unsigned long long)sres[16 + 4 + tid];
         }
     }
+    if (tid == 0) {
+        // the (tensor, outer slice) pairs of the auxiliary rows: x << 8 | slice, with how a 16-lane group moves one row of the
+        // pair (<< 16; 2: 16 bytes per lane, 1: one 8-byte word, 0: copy_row)
+        int np = 0, slow = 0;
+        for (int x = 0; x < aux_n; ++x) {
+            const ff_aux_t& ax = a.aux.a[x];
+            const uintptr_t al = (uintptr_t)ax.src | (uintptr_t)auxdst[x] | (uintptr_t)ax.row_bytes | (uintptr_t)ax.src_outer_bytes;
+            const int f = (ax.row_bytes <= 256 && !(al & 15)) ? 2 : ((ax.row_bytes == 8 && !(al & 7)) ? 1 : 0);
+            for (int kq = 0; kq < (int)ax.outer; ++kq, ++np) {
+                if (np < 8) scratch[8 + np] = (f << 16) | (x << 8) | kq;
+                if (np >= 8 || f == 0) slow = 1;
+            }
+        }
+        scratch[29] = slow;                                  // some pair takes the general row copy
+        scratch[30] = np;
+        scratch[31] = 0;
+    }
     __syncthreads();
-    sub[3] = wall_clock64() - stamp0;                         // outputs known (mail read)
+    sub[7] = wall_clock64() - stamp0;                         // outputs known (mail read)
     const bool apply = !plan_bad && (l_out == L || (out_ptr != nullptr && out_cap >= (long long)l_out));
     auto members_before_pos = [&](int i) { return pospre[i >> 5] + __popc(posmask[i >> 5] & ((1u << (i & 31)) - 1u)); };
     auto members_before_slot = [&](int t) { return slotpre[t >> 5] + __popc(slotword(t >> 5) & ((1u << (t & 31)) - 1u)); };
-    if (bid == 0 && wv == kResWaves - 1) {
-        // the result block leaves through the last wave of workgroup 0 (the one that holds no rows when the rows have fewer than
-        // 8 tiles): one lane per word, no LDS, no workgroup barrier - the other waves are already folding
-        long long e = err_bits;
-        if (members_total < 0) e |= FF_ERR_BIT_RESIDENT;
-        if (lane < FF_STAT_T_ORDER && lane != FF_STAT_SEQ) {            // (the words behind are the host's: FF_MAIL_WORD)
-            long long vres = 0;
-            const double ratio = ftn > 0 ? (double)count / (double)ftn : 0.0;
-            switch (lane) {
-                case FF_STAT_NV: vres = nv; break;
-                case FF_STAT_FTN: vres = ftn; break;
-                case FF_STAT_COUNT: vres = count; break;
-                case FF_STAT_BRANCH: vres = is_topk ? 1 : 0; break;
-                case FF_STAT_K: vres = k_sel; break;
-                case FF_STAT_MERGED: vres = L - l_out; break;
-                case FF_STAT_LOUT: vres = l_out; break;
-                case FF_STAT_BELOW_LB: vres = (!is_topk && ratio < pp.ratio_lb) ? 1 : 0; break;
-                case FF_STAT_KTH_KEY: vres = kth; break;
-                case FF_STAT_TIES_TAKEN: vres = topk ? need : 0; break;
-                case FF_STAT_APPLIED: vres = apply ? 1 : 0; break;
-                default: break;
-            }
-            if (e) vres = 0;
-            if (lane == FF_STAT_ERROR) vres = e;
-            if (!e && lane != FF_STAT_ERROR && lane < FF_STAT_T_ORDER) a.stats[lane] = vres;
-            if (lane == FF_STAT_ERROR) a.stats[lane] = 0;                       // reported: the next call starts clean
-            __hip_atomic_store(&a.host_mapped[lane], vres, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-        if (lane == 0) __hip_atomic_store(&a.host_mapped[FF_STAT_SEQ], (int64_t)a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (bid == 0 && tid == 0) {                               // (debug words: device block only)
+        a.stats[FF_STAT_KTH_KEY] = kth;
+        a.stats[FF_STAT_TIES_TAKEN] = topk ? need : 0;
     }
-    if (plan_bad) return;                                   // (the host resets the workspace)
 
     const bool folded = l_out != L;
     const int b0 = (int)((long long)bid * L / G), b1 = (int)((long long)(bid + 1) * L / G);      // my slice of positions / slots
@@ -796,44 +898,80 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
         index_roles(tid, kResThreads);
         return;
     }
-    // ---- auxiliary rows (position tables, patch types) of the kept positions of my slice: one task = one row of one (tensor,
-    // outer slice), 16 lanes each, kBatch tasks per round with the loads ahead of the stores; by `ngrp` groups of 16 lanes
-    auto aux_roles = [&](int grp, int ngrp, int l16, auto batch) {
-        constexpr int kBatch = decltype(batch)::value;
-        if (!folded || aux_n <= 0) return;
-        int per = 0;
-        for (int x = 0; x < aux_n; ++x) per += (int)a.aux.a[x].outer;
-        const int T = (b1 - b0) * per;
-        struct Task { const char* sp; char* dq; int rbytes; int fast; };
-        auto task = [&](int t) -> Task {
-            Task k{nullptr, nullptr, 0, 0};
-            if (t < T) {
-                const int i = b0 + t / per;
-                int kq = t % per, x = 0;
-                while (kq >= (int)a.aux.a[x].outer) { kq -= (int)a.aux.a[x].outer; ++x; }
-                if (!((posmask[i >> 5] >> (i & 31)) & 1u)) {
-                    const ff_aux_t& ax = a.aux.a[x];
-                    k.sp = aux_src_row(ax, kq, i, L);
-                    k.dq = (char*)(uintptr_t)auxdst[x] + ((int64_t)kq * out_cap + (i - members_before_pos(i))) * ax.row_bytes;
-                    k.rbytes = (int)ax.row_bytes;
-                    k.fast = ax.row_bytes <= 256 && !(((uintptr_t)k.sp | (uintptr_t)k.dq | (uintptr_t)ax.row_bytes) & 15);
+    // ---- auxiliary rows (position tables, patch types) of the kept positions of my slice.  One position = one unit of work for a
+    // group of 16 lanes, handed out by an LDS counter: the wave that holds no rows starts at once, the others join when their
+    // fold is done.  Per position the loads of all (tensor, outer slice) pairs go out before the first store (the pairs' table:
+    // scratch[8..15], built by thread 0 above; a 16-lane group moves up to 256 bytes per pair at once).
+    // (one wave alone, descriptors looked up per task, took 35 us for the 53 positions of a 7B segment: 24 us behind the fold)
+    auto aux_rows = [&]() {
+        const int np = scratch[30];
+        if (!folded || np <= 0) return;
+        constexpr int U = 4;                                 // positions per turn of a group: U x np loads in flight
+        const int l16 = lane & 15, gl = lane & ~15, npos = b1 - b0;
+        // the pairs once: source of position 0, destination of output row 0, bytes per row, how to move one
+        const char* spz[8];
+        char* dpz[8];
+        int rbz[8], fz[8];
+#pragma unroll
+        for (int z = 0; z < 8; ++z) {
+            spz[z] = nullptr; dpz[z] = nullptr; rbz[z] = 0; fz[z] = 0;
+            if (z < np) {
+                const int e = scratch[8 + z], x = (e >> 8) & 0xff, kq = e & 0xff;
+                const ff_aux_t& ax = a.aux.a[x];
+                fz[z] = e >> 16;
+                rbz[z] = (int)ax.row_bytes;
+                spz[z] = aux_src_row(ax, kq, 0, L);
+                dpz[z] = (char*)(uintptr_t)auxdst[x] + (int64_t)kq * out_cap * ax.row_bytes;
+            }
+        }
+        while (true) {
+            int p = 0;
+            if (l16 == 0) p = atomicAdd(&scratch[31], U);
+            p = __shfl(p, gl);
+            if (p >= npos) break;
+            int iu[U];
+            int64_t ru[U];
+            uint4 u[U][8];
+#pragma unroll
+            for (int q = 0; q < U; ++q) {
+                const int i = b0 + p + q;
+                const bool kept = p + q < npos && !((posmask[i >> 5] >> (i & 31)) & 1u);
+                iu[q] = kept ? i : -1;
+                ru[q] = kept ? i - members_before_pos(i) : 0;
+#pragma unroll
+                for (int z = 0; z < 8; ++z) {
+                    u[q][z] = make_uint4(0, 0, 0, 0);
+                    if (z < np && kept) {
+                        const char* sp = spz[z] + (int64_t)i * rbz[z];
+                        if (fz[z] == 2) { if (l16 * 16 < rbz[z]) u[q][z] = *(const uint4*)(sp + l16 * 16); }
+                        else if (fz[z] == 1) { if (l16 == 0) { const uint2 w = *(const uint2*)sp; u[q][z].x = w.x; u[q][z].y = w.y; } }
+                    }
                 }
             }
-            return k;
-        };
-        for (int t0 = grp * kBatch; t0 < T; t0 += ngrp * kBatch) {
-            Task k[kBatch];
-            uint4 u[kBatch];
 #pragma unroll
-            for (int z = 0; z < kBatch; ++z) {
-                k[z] = task(t0 + z);
-                u[z] = make_uint4(0, 0, 0, 0);
-                if (k[z].fast && l16 * 16 < k[z].rbytes) u[z] = *(const uint4*)(k[z].sp + l16 * 16);
+            for (int q = 0; q < U; ++q) {
+#pragma unroll
+                for (int z = 0; z < 8; ++z) {
+                    if (z < np && iu[q] >= 0) {
+                        char* dq = dpz[z] + ru[q] * rbz[z];
+                        if (fz[z] == 2) { if (l16 * 16 < rbz[z]) *(uint4*)(dq + l16 * 16) = u[q][z]; }
+                        else if (fz[z] == 1) { if (l16 == 0) *(uint2*)dq = make_uint2(u[q][z].x, u[q][z].y); }
+                    }
+                }
             }
-#pragma unroll
-            for (int z = 0; z < kBatch; ++z) {
-                if (k[z].fast && l16 * 16 < k[z].rbytes) *(uint4*)(k[z].dq + l16 * 16) = u[z];
-                if (k[z].sp && !k[z].fast) copy_row(k[z].sp, k[z].dq, k[z].rbytes, l16, 16);       // (odd sizes, long rows)
+            if (scratch[29]) {
+                // pairs the table does not hold, odd sizes, long rows: one by one (ONE copy of the general row copy in the
+                // kernel's code: unrolled into the block above it made this path crawl through the instruction cache)
+                for (int q = 0; q < U; ++q) {
+                    if (iu[q] < 0) continue;
+                    int z = 0;
+                    for (int x = 0; x < aux_n; ++x) {
+                        const ff_aux_t& ax = a.aux.a[x];
+                        for (int kq = 0; kq < (int)ax.outer; ++kq, ++z)
+                            if (z >= 8 || (scratch[8 + z] >> 16) == 0)
+                                copy_row(aux_src_row(ax, kq, iu[q], L), (char*)(uintptr_t)auxdst[x] + ((int64_t)kq * out_cap + ru[q]) * ax.row_bytes, ax.row_bytes, l16, 16);
+                    }
+                }
             }
         }
     };
@@ -943,12 +1081,32 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
 #endif
     if (!spare_wave) {
         index_roles(tid, kResThreads);
-        aux_roles(tid >> 4, kResThreads / 16, tid & 15, std::integral_constant<int, 4>{});
+        aux_rows();
     } else if (wv == kResWaves - 1) {
+#ifdef FF_RES_WGSTAMPS
+        if (bid == 0 && lane == 0) wgdbg[6] = (unsigned long long)wall_clock64();
+#endif
         index_roles(lane, kWave);
-        aux_roles(lane >> 4, kWave / 16, lane & 15, std::integral_constant<int, 8>{});
+#ifdef FF_RES_WGSTAMPS
+        if (bid == 0 && lane == 0) wgdbg[7] = (unsigned long long)wall_clock64();
+#endif
+        aux_rows();
+#ifdef FF_RES_WGSTAMPS
+        if (bid == 0 && lane == 0) wgdbg[8] = (unsigned long long)wall_clock64();
+#endif
+    } else {
+        aux_rows();                                          // (a data wave behind its fold: what the spare wave has not taken yet)
     }
     stamp[5] = wall_clock64() - stamp0;                       // short roles done
+#ifdef FF_RES_WGSTAMPS
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long te = (unsigned long long)wall_clock64();
+        atomicMax(&wgdbg[2], ~0ull - te);
+        atomicMax(&wgdbg[3], te);
+        if (bid == 0) wgdbg[5] = te;
+    }
+#endif
     if (bid == 0 && tid == 0) {
         stamp[6] = wall_clock64() - stamp0;
         for (int x = 0; x < 7; ++x) a.stats[FF_STAT_T_PLAN + x] = stamp[x];

@@ -548,15 +548,19 @@ class FrameFusion(nn.Module):
             if rc:
                 _fail(rc, "merge")
         rc = lib.ff_ctx_merge_collect(sc.ctx_ptr, sc.call_ptr, sc.res_ptr)
-        if rc or sc.res.applied:
+        if rc or sc.res.applied == 1:
             return self._merge_complete(st, rc)
+        # applied = 2: the one-launch kernel published l_out right behind its grid barrier and now waits, rows in hand, for
+        # outputs that hold it - the mailed ones if the guess came true, else the ones allocated here (second mail slot, written
+        # by ff_ctx_merge_apply, which also reads the kernel's acknowledgement: no launch).  applied = 0: the three launches'
+        # blind merge kernel wrote nothing (the plan decided otherwise): ff_ctx_merge_apply repeats it into the right outputs.
         L_out = int(sc.res.l_out)
         if L_out == L:
             self._no_outputs(st, hidden=st["hidden"])       # nothing folds: the launch only clears the select tables
         elif st.get("L_cap") != L and st.get("L_cap") != L_out:
             self._merge_outputs(st, L_out)
-        rc = lib.ff_ctx_merge_apply(sc.ctx_ptr, sc.call_ptr, sc.res_ptr)
-        return self._merge_complete(st, rc)
+        # (the host's own bookkeeping of the call comes first: the kernel's answer to the mail is two PCIe round trips away)
+        return self._merge_complete(st, 0, confirm=lambda: lib.ff_ctx_merge_apply(sc.ctx_ptr, sc.call_ptr, sc.res_ptr))
 
     def _merge_sources(self, st):
         """The SOURCE half of the auxiliary entries (patch types + position tensors, destinations 0): no allocation."""
@@ -750,8 +754,9 @@ class FrameFusion(nn.Module):
             _lib.MASK_TRIPLE.pack_into(call, _lib.MERGE_CALL_MASK_OFFSET, 0, 0, 0)
         st.update(out=out, ptype_out=ptype_out, srcs=srcs, rebuild=rebuild, mask_cap=mask_cap, L_cap=L_cap)
 
-    def _merge_complete(self, st, rc):
-        """The result block -> the state machine of main.py:112-138 and the returned views."""
+    def _merge_complete(self, st, rc, confirm=None):
+        """The result block -> the state machine of main.py:112-138 and the returned views.  `confirm`: the crossing that finishes
+        the call on the device side (ff_ctx_merge_apply), made once the host's bookkeeping is done."""
         lib = _lib.load()
         sc, L, dtype, stream = st["sc"], st["L"], st["dtype"], st["stream"]
         hidden_states, position_embeddings, attention_mask, residual = (st["hidden_states"], st["position_embeddings"],
@@ -771,8 +776,18 @@ class FrameFusion(nn.Module):
             self._layout_hint = None
         if rc:
             _fail(rc, "merge", err)
-        sc.sync_views()
         assert nv > 0, "no visual tokens"                                          # main.py:240
+
+        def finish():
+            # (with `confirm` the library's bookkeeping of the call - the order swap - happens in that crossing)
+            if confirm is not None:
+                rc = confirm()
+                if rc:
+                    _fail(rc, "merge")
+            sc.sync_views()
+            # which mail the waiting one-launch kernel took (1: sent before the result was known, 2: sized to it; 3: none came
+            # in time and the merge kernel followed as a launch of its own); 0: no kernel waited
+            return int(sc.stats_host[_lib.STAT_ACK]) & 3 if _applied == 2 else 0
 
         above_k_ratio = count / ftn                                                 # main.py:114
         if branch == 0:                                                             # main.py:116-120
@@ -787,19 +802,22 @@ class FrameFusion(nn.Module):
             # nothing was folded (empty threshold set, main.py:264-266): the merge kernel saw that on
             # the device and wrote nothing - the reduced sequence is the input itself, and the order
             # in the scratch still describes the (unchanged) patch_type
+            mail_slot = finish()
             self.last_call = dict(kind="merge", L_in=L, L_out=L, nv=nv, ftn=ftn, count=count, branch=branch,
                                   k=k, scratch=sc, dtype=dtype, order=sc.order, wait_ns=wait_ns, unhinted=bool(unhinted),
-                                  one_launch=bool(st.get("one_launch")), applied=bool(_applied))
+                                  one_launch=bool(st.get("one_launch")), applied=int(_applied), mail_slot=mail_slot)
             sc.order_gen = self._ptype_gen
             if residual is not None:          # nothing folded, but the caller is owed the sum
                 return residual + hidden_states, position_embeddings, attention_mask
             return hidden_states, position_embeddings, attention_mask
 
+        hidden_out, ptype_new, pos_new = st["out"].narrow(1, 0, L_out), st["ptype_out"].narrow(1, 0, L_out), st["rebuild"](L_out)
+        mail_slot = finish()
         # order maintenance: the merge kernel also wrote the by-patch order of the compacted sequence
         # (now the context's current one), so the next merge call of this prefill skips K0
         self.last_call = dict(kind="merge", L_in=L, L_out=L_out, nv=nv, ftn=ftn, count=count, branch=branch,
                               k=k, scratch=sc, dtype=dtype, order=sc.order_next, wait_ns=wait_ns, unhinted=bool(unhinted),
-                              one_launch=bool(st.get("one_launch")), applied=bool(_applied))
+                              one_launch=bool(st.get("one_launch")), applied=int(_applied), mail_slot=mail_slot)
         mask_cap = st["mask_cap"]
         if mask_cap is not None:
             attention_mask = mask_cap[:, :, :L_out, :L_out]
@@ -812,7 +830,6 @@ class FrameFusion(nn.Module):
             if rc:
                 _fail(rc, "merge (attention mask)")
             attention_mask = mask_out
-        hidden_out, ptype_new, pos_new = st["out"].narrow(1, 0, L_out), st["ptype_out"].narrow(1, 0, L_out), st["rebuild"](L_out)
         self.patch_type = ptype_new                                                 # main.py:132
         sc.order_gen = self._ptype_gen
         return hidden_out, pos_new, attention_mask

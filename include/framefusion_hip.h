@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FF_ABI_VERSION 10
+#define FF_ABI_VERSION 11
 
 enum { FF_F32 = 0, FF_BF16 = 1, FF_F16 = 2 };
 
@@ -56,7 +56,9 @@ enum {
     FF_STAT_TIES_TAKEN = 9,/* debug: entries equal to the k-th value that were selected                   */
     FF_STAT_SEQ = 10,      /* sequence number of the call, written LAST (what the host polls)             */
     FF_STAT_ERROR = 11,    /* FF_ERR_BIT_* of the device-side checks; cleared once published              */
-    FF_STAT_APPLIED = 12,  /* one-launch call: 1 = outputs written (or nothing folds), 0 = the plan only  */
+    FF_STAT_APPLIED = 12,  /* one-launch call: 1 = outputs written (or nothing folds), 0 = the plan only, */
+                           /* 2 = the kernel waits for outputs of LOUT rows by mail                       */
+    FF_STAT_ACK = 13,      /* pinned block only: 4 * seq + the mail slot the kernel took (3: none in time) */
     FF_STAT_T_ORDER = 16,  /* device block: 8 diagnostic words.  PINNED block: words 16..23 are the host's */
     FF_STAT_T_PLAN = 24,   /* 7 diagnostic words (phase stamps of the plan / the one-launch kernel)       */
     FF_STAT_WORDS = 32
@@ -294,7 +296,7 @@ int ff_ctx_merge_wait(ff_ctx_t* ctx, const ff_merge_call_t* call, ff_merge_resul
 int ff_ctx_merge_apply(ff_ctx_t* ctx, const ff_merge_call_t* call, const ff_merge_result_t* result);
 int ff_ctx_merge_submit(ff_ctx_t* ctx, const ff_merge_call_t* call);
 int ff_ctx_merge_collect(ff_ctx_t* ctx, const ff_merge_call_t* call, ff_merge_result_t* result);
-enum { FF_MAIL_WORD = 16, FF_MAIL_WORDS = 8 };
+enum { FF_MAIL_WORD = 16, FF_MAIL_WORDS = 8, FF_MAIL_SLOTS = 2 };   /* pinned words 16..31 */
 int ff_ctx_merge_mail(ff_ctx_t* ctx, const ff_merge_call_t* call);
 /* 1 if ff_ctx_merge_submit(ctx, call) would go out as the one-launch kernel now (input half of `call` only) */
 int ff_ctx_merge_one_launch(const ff_ctx_t* ctx, const ff_merge_call_t* call);

@@ -47,7 +47,7 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(_lib.LIB_PATH)
     for name in declared_functions():
         assert hasattr(lib, name), name
-    assert _lib.load().ff_abi_version() == _lib.ABI_VERSION == 10
+    assert _lib.load().ff_abi_version() == _lib.ABI_VERSION == 11
 
 
 def test_stat_enum_matches_binding():
@@ -270,3 +270,11 @@ def test_every_illegal_transition_is_refused_and_changes_nothing():
             refused += 1
             assert lib.ff_ctx_reset(a(ctx), None) == 0 and ctx.in_flight == 0      # ... and the way out works from anywhere
     assert refused == sum(len(states) - len(v) for v in _MERGE_ENTRIES.values())
+    # state 3 has one sub-state: a one-launch kernel that published its result and waits for outputs by mail (collect returned
+    # applied = 2; ctx->res_active = 3).  There - and only there - a mail is legal in state 3: both slots once, then no more.
+    ctx, call, res, pc, lq, host = fresh(3)
+    ctx.res_active = 3
+    call.hidden_out, call.L_cap = 4096, 100
+    assert lib.ff_ctx_merge_mail(a(ctx), a(call)) == 0 and host[_lib.MAIL_WORD] == 7 * 4 + 1 and host[_lib.MAIL_WORD + 2] == 100
+    assert lib.ff_ctx_merge_mail(a(ctx), a(call)) == 0 and host[_lib.MAIL_WORD + _lib.MAIL_WORDS] == 7 * 4 + 2
+    assert lib.ff_ctx_merge_mail(a(ctx), a(call)) == _lib.ERR_STATE

@@ -114,8 +114,9 @@ def test_gaussian_rows_give_the_same_bits_too():
 
 
 def test_outputs_sized_for_the_other_branch_and_no_outputs_at_all():
-    """Exactly sized outputs are allocated for the top-k branch's length; when the plan takes the threshold branch the launch stops
-    behind its plan (`applied` = 0) and the merge kernel follows alone - likewise when no length can be guessed."""
+    """Exactly sized outputs are allocated for the top-k branch's length; when the plan takes the threshold branch the kernel - which
+    published l_out right behind its grid barrier - waits, rows in hand, for outputs of that length in the second mail slot (no
+    second launch); likewise when no length can be guessed."""
     F, P, d, pre, post = 64, 195, 3584, 15, 12
     h, pt = video_tokens(F, P, d, p_change=0.5, sigma=0.3, sigma_hi=1.8, seed=77, pre=pre, post=post, grid=0.125)
     L = h.shape[1]
@@ -124,7 +125,7 @@ def test_outputs_sized_for_the_other_branch_and_no_outputs_at_all():
         prepare(ff, dev(pt), P, pre, F * P, L)
     pe = dev(rotary_tables(L, 128, torch.bfloat16, mrope=True))
     same_call(fa, fb, dev(h), pe)
-    assert fa.last_call["branch"] == 0 and not fa.last_call["applied"]          # guessed the top-k length, got the threshold set
+    assert fa.last_call["branch"] == 0 and fa.last_call["applied"] == 2 and fa.last_call["mail_slot"] == 2    # guessed the top-k length, got the threshold set
     # no guess: prepare() scalars that do not describe whole frames -> K0 path for the first call (three launches), the second
     # call is order-maintained and goes out as one launch without a length to allocate for
     fa, fb = pair()
@@ -134,6 +135,38 @@ def test_outputs_sized_for_the_other_branch_and_no_outputs_at_all():
     o2 = dev(harness.layer_stub(o.cpu(), 0))
     same_call(fa, fb, o2, q)
     assert fa.last_call["one_launch"]
+    assert fa.last_call["L_out"] == o2.shape[1] or fa.last_call["mail_slot"] == 2
+
+
+def test_a_host_that_answers_too_late_gets_the_merge_kernel_as_a_launch_of_its_own(monkeypatch):
+    """The waiting kernel gives up after ~4 ms (FF_STAT_ACK = 4 seq + 3), ff_ctx_merge_apply sees that and enqueues the merge kernel
+    behind it: same bits, one launch more."""
+    import time
+    F, P, d, pre, post = 64, 195, 3584, 15, 12
+    h, pt = video_tokens(F, P, d, p_change=0.5, sigma=0.3, sigma_hi=1.8, seed=77, pre=pre, post=post, grid=0.125)
+    L = h.shape[1]
+    fa, fb = pair()
+    for ff in (fa, fb):
+        prepare(ff, dev(pt), P, pre, F * P, L)
+    pe = dev(rotary_tables(L, 128, torch.bfloat16, mrope=True))
+    real = ffa.FrameFusion._merge_outputs
+    calls = []
+
+    def slow(self, st, L_cap=None):
+        calls.append(L_cap)
+        if len(calls) == 2 and self is fa:                   # (the allocation BEHIND the result: the kernel is waiting)
+            time.sleep(0.012)
+        return real(self, st, L_cap)
+    monkeypatch.setattr(ffa.FrameFusion, "_merge_outputs", slow)
+    same_call(fa, fb, dev(h), pe)
+    assert fa.last_call["applied"] == 2 and fa.last_call["mail_slot"] == 3
+    monkeypatch.setattr(ffa.FrameFusion, "_merge_outputs", real)
+    # ... and the context goes on as if nothing had happened
+    h2, _ = video_tokens(F, P, d, p_change=0.2, sigma=0.3, seed=5, pre=pre, post=post, grid=0.125)
+    for ff in (fa, fb):
+        prepare(ff, dev(pt), P, pre, F * P, L)
+    same_call(fa, fb, dev(h2), pe)
+    assert fa.last_call["one_launch"] and fa.last_call["mail_slot"] in (1, 2)
 
 
 def test_top_k_guess_holds_and_the_call_is_one_kernel():
@@ -145,7 +178,7 @@ def test_top_k_guess_holds_and_the_call_is_one_kernel():
         prepare(ff, dev(pt), P, pre, F * P, L)
     pe = dev(rotary_tables(L, 128, torch.bfloat16))
     out, _ = same_call(fa, fb, dev(h), pe)
-    assert fa.last_call["branch"] == 1 and fa.last_call["applied"]
+    assert fa.last_call["branch"] == 1 and fa.last_call["applied"] == 2 and fa.last_call["mail_slot"] == 1    # the guessed outputs were taken
     assert out.untyped_storage().nbytes() == out.numel() * out.element_size()    # exactly sized, no capacity buffer behind it
 
 

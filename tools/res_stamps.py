@@ -19,7 +19,7 @@ L = h.shape[1]
 h, pt = h.to(dev), pt.to(dev)
 pe = [t.to(dev) for t in rotary_tables(L, 128, torch.bfloat16)]
 ff = ffa.FrameFusion(compact_outputs=not a.views)
-subs = ["keymasks", "tieslot", "poswords", "mail", "ldsrows", "vgprrows", "contin", "hist0"]
+subs = ["keymasks", "tieslot", "poswords", "published", "ldsrows", "vgprrows", "contin", "outputs"]
 names = ["rows+sims", "barrier", "decision", "plan", "fold", "roles", "end"]
 for it in range(6):
     ff.prepare(pt, a.P, a.pre, a.pre + a.F * a.P, a.F * a.P, L)
@@ -28,7 +28,7 @@ for it in range(6):
     torch.cuda.synchronize()
     sc = ff.last_call["scratch"]
     st = sc.stats.cpu().tolist()
-    print(f"call {it}: one_launch={ff.last_call['one_launch']} applied={ff.last_call['applied']} {L}->{out.shape[1]}  " +
+    print(f"call {it}: one_launch={ff.last_call['one_launch']} applied={ff.last_call['applied']} wait_us={ff.last_call['wait_ns'] / 1e3:.1f} {L}->{out.shape[1]}  " +
           "  ".join(f"{n} {st[_lib.STAT_T_PLAN + x] / 100:.1f}" for x, n in enumerate(names)) + "\n        " +
           "  ".join(f"{n} {st[_lib.STAT_T_ORDER + x] / 100:.1f}" for x, n in enumerate(subs)))
-print("res_off", int(sc.ctx.res_off), "mail words", sc.stats_host[16:24].tolist(), "seq", int(sc.ctx.seq))
+print("mail slot taken by the last call:", ff.last_call["mail_slot"])
