@@ -9,21 +9,34 @@
 //      into VGPRs, 4 per row per wave) and STAY there.  |x|^2 and the T-rounded pair dots are summed per lane as the rows arrive
 //      (recipe of ff_similarity.hip), per wave on the DPP network, across the waves through LDS; the segment's similarities are
 //      published write-through.
-//   -- ONE XCD-hierarchical grid barrier (static groups blockIdx & 7; bounded; abort flag) --
+//   -- ONE XCD-hierarchical grid barrier (static groups blockIdx & 7; bounded; abort flag).  Its arrival words also CARRY two
+//      counts per workgroup - similarities in the threshold set (main.py:113), similarities above IGNORE_TOKEN - and the release
+//      word hands the two totals to everybody: they ARE the decision (main.py:114-127) and the output length, so the RESULT
+//      BLOCK LEAVES HERE (~22 us after the kernel's start at the 7B layout, ~12 us before the plan is through) --
 //   B  plan, by every workgroup for itself (nothing else crosses workgroups; the select tables of the three-launch path are not
-//      touched): all similarities 32 per thread in registers, two 256-bin histograms in LDS (top byte, then low byte of the
-//      k-th key's bin), decision and ties with ff_plan_fast.h's arithmetic; member bits by slot; the member bitmap by POSITION
-//      (closed form of the frame-major layout, or inv[]); two prefix scans.  Workgroup 0 publishes the result block.
-//   C  fold + compaction FROM THE RESIDENT ROWS: a wave walks its rows in order, a non-member opens an output row, a member folds
-//      into it (rounding after every add, main.py:304-317); a run that continues into the next workgroup's segment is finished
-//      by its anchor's workgroup, which fetches those rows (L2 / Infinity Cache) - the only rows read twice.  Then the short
-//      roles: non-visual rows, auxiliary rows (position tables, patch types), member / keep / dst, next order + inverse.
+//      touched): all similarities 32 per thread in registers, level 0 speculated (counts above / at the guessed top byte), one
+//      256-bin histogram in LDS for the low byte, ties with ff_plan_fast.h's arithmetic; member bits by slot; the member bitmap
+//      by POSITION (closed form of the frame-major layout, or inv[]); two prefix scans.  The plan's member count is checked
+//      against the published length (an internal assertion: device error word).
+//   C  outputs + fold + compaction FROM THE RESIDENT ROWS.  The outputs come in the launch arguments or BY MAIL (two slots in the
+//      pinned block, relayed into device memory by one wave): slot 1 is written by the host while the rows are being read
+//      (input-length buffers, or a guessed length), slot 2 after it has read the result block (exactly l_out rows) - the kernel
+//      waits for whichever holds the result, rows in hand, and acknowledges it (FF_STAT_ACK); a host that does not answer within
+//      ~4 ms gets the plan only and follows with the merge kernel (ff_ctx_merge_apply).  Then a wave walks its rows in order, a
+//      non-member opens an output row, a member folds into it (rounding after every add, main.py:304-317); a run that continues
+//      into the next workgroup's segment is finished by its anchor's workgroup, which fetches those rows (L2 / Infinity Cache) -
+//      the only rows read twice.  The short roles: non-visual rows, auxiliary rows (position tables, patch types: before the
+//      fold when there are at most three (tensor, slice) pairs, else handed out by an LDS counter, the wave without rows first),
+//      member / keep / dst, next order + inverse.
 //
-// When the output buffers are too short for the result (L_cap < l_out: exactly sized outputs allocated for the top-k branch's
-// length while the plan took the threshold branch) or absent, the launch stops after B with member / keep / dst in place:
-// stats[FF_STAT_APPLIED] = 0 and the host follows with the merge kernel alone (ff_ctx_merge_apply).
+// Measured (tools/flow_stamps.py --wg on a library built with EXTRA=-DFF_RES_WGSTAMPS: first workgroup start -> last workgroup
+// end on the device clock; rocprofv3's kernel duration includes the wait for the host's mail, and its tracing slows the host):
+// 53-61 us at the 7B layout (13 474 -> 4 066) against 57.7 us for the three launches; the host sees the result 22 us after
+// the kernel's start instead of 31 us, and a call whose guessed output length was wrong costs no second launch.
+// History of a mismeasurement: until the per-workgroup stamps existed the kernel was timed by workgroup 0's FIRST wave
+// ("48 us"); the wave without rows did all auxiliary rows alone and took until 75 us.
 //
-// Measured on the bare pattern first (tools/resprobe, profiles/r06_resident_probe.txt): 31-33 us against 57.7 us for the three
+// The bare pattern was measured first (tools/resprobe, profiles/r06_resident_probe.txt): 31-33 us against 57.7 us for the three
 // launches at the 7B layout.  Lesson of the probe: all loads first, arithmetic behind them, starts the arithmetic 9-12 us late -
 // a CU holds far fewer requests than 8 waves x 55 KiB, so the load INSTRUCTIONS queue; hence the software pipeline.
 #include <atomic>
@@ -903,17 +916,18 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
     // fold is done.  Per position the loads of all (tensor, outer slice) pairs go out before the first store (the pairs' table:
     // scratch[8..15], built by thread 0 above; a 16-lane group moves up to 256 bytes per pair at once).
     // (one wave alone, descriptors looked up per task, took 35 us for the 53 positions of a 7B segment: 24 us behind the fold)
-    auto aux_rows = [&]() {
+    auto aux_rows = [&](auto np_c, auto u_c) {
+        constexpr int NP = decltype(np_c)::value;            // pairs held in registers (the table's first NP)
+        constexpr int U = decltype(u_c)::value;              // positions per turn of a group: U x NP loads in flight
         const int np = scratch[30];
         if (!folded || np <= 0) return;
-        constexpr int U = 4;                                 // positions per turn of a group: U x np loads in flight
         const int l16 = lane & 15, gl = lane & ~15, npos = b1 - b0;
         // the pairs once: source of position 0, destination of output row 0, bytes per row, how to move one
-        const char* spz[8];
-        char* dpz[8];
-        int rbz[8], fz[8];
+        const char* spz[NP];
+        char* dpz[NP];
+        int rbz[NP], fz[NP];
 #pragma unroll
-        for (int z = 0; z < 8; ++z) {
+        for (int z = 0; z < NP; ++z) {
             spz[z] = nullptr; dpz[z] = nullptr; rbz[z] = 0; fz[z] = 0;
             if (z < np) {
                 const int e = scratch[8 + z], x = (e >> 8) & 0xff, kq = e & 0xff;
@@ -931,7 +945,7 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
             if (p >= npos) break;
             int iu[U];
             int64_t ru[U];
-            uint4 u[U][8];
+            uint4 u[U][NP];
 #pragma unroll
             for (int q = 0; q < U; ++q) {
                 const int i = b0 + p + q;
@@ -939,7 +953,7 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
                 iu[q] = kept ? i : -1;
                 ru[q] = kept ? i - members_before_pos(i) : 0;
 #pragma unroll
-                for (int z = 0; z < 8; ++z) {
+                for (int z = 0; z < NP; ++z) {
                     u[q][z] = make_uint4(0, 0, 0, 0);
                     if (z < np && kept) {
                         const char* sp = spz[z] + (int64_t)i * rbz[z];
@@ -951,7 +965,7 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
 #pragma unroll
             for (int q = 0; q < U; ++q) {
 #pragma unroll
-                for (int z = 0; z < 8; ++z) {
+                for (int z = 0; z < NP; ++z) {
                     if (z < np && iu[q] >= 0) {
                         char* dq = dpz[z] + ru[q] * rbz[z];
                         if (fz[z] == 2) { if (l16 * 16 < rbz[z]) *(uint4*)(dq + l16 * 16) = u[q][z]; }
@@ -959,7 +973,7 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
                     }
                 }
             }
-            if (scratch[29]) {
+            if (scratch[29] || np > NP) {
                 // pairs the table does not hold, odd sizes, long rows: one by one (ONE copy of the general row copy in the
                 // kernel's code: unrolled into the block above it made this path crawl through the instruction cache)
                 for (int q = 0; q < U; ++q) {
@@ -968,7 +982,7 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
                     for (int x = 0; x < aux_n; ++x) {
                         const ff_aux_t& ax = a.aux.a[x];
                         for (int kq = 0; kq < (int)ax.outer; ++kq, ++z)
-                            if (z >= 8 || (scratch[8 + z] >> 16) == 0)
+                            if (z >= NP || (scratch[8 + z] >> 16) == 0)
                                 copy_row(aux_src_row(ax, kq, iu[q], L), (char*)(uintptr_t)auxdst[x] + ((int64_t)kq * out_cap + ru[q]) * ax.row_bytes, ax.row_bytes, l16, 16);
                     }
                 }
@@ -978,6 +992,11 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
     // a wave that holds no rows (rows of fewer than 8 tiles) does the short roles while the others fold: it walks past the fold
     // below at once
     const bool spare_wave = nt < kResWaves;
+    // Up to three pairs (patch types + two [1, L, .] position tables: every model but the M-RoPE ones) go BEFORE the fold, by
+    // every wave, two positions per 16-lane group: the memory system is quiet here and one turn is one load latency (~2 us);
+    // behind the fold's stores the same turn took 5 us, and the wave without rows, started early, 14 us for its share.
+    const bool aux_first = scratch[30] <= 3;
+    if (aux_first) aux_rows(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{});
 
     // ======================================================================================================================
     // C. fold + compaction from the resident rows
@@ -1081,8 +1100,10 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
 #endif
     if (!spare_wave) {
         index_roles(tid, kResThreads);
-        aux_rows();
+        if (!aux_first) aux_rows(std::integral_constant<int, 8>{}, std::integral_constant<int, 4>{});
     } else if (wv == kResWaves - 1) {
+        // (first in line at its SIMD's issue port: the wave it shares the SIMD with is folding, VALU-bound)
+        __builtin_amdgcn_s_setprio(3);
 #ifdef FF_RES_WGSTAMPS
         if (bid == 0 && lane == 0) wgdbg[6] = (unsigned long long)wall_clock64();
 #endif
@@ -1090,12 +1111,13 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
 #ifdef FF_RES_WGSTAMPS
         if (bid == 0 && lane == 0) wgdbg[7] = (unsigned long long)wall_clock64();
 #endif
-        aux_rows();
+        // (more than three pairs - M-RoPE: the wave without rows starts on them at once, the others join behind their fold)
+        if (!aux_first) aux_rows(std::integral_constant<int, 8>{}, std::integral_constant<int, 5>{});
 #ifdef FF_RES_WGSTAMPS
         if (bid == 0 && lane == 0) wgdbg[8] = (unsigned long long)wall_clock64();
 #endif
     } else {
-        aux_rows();                                          // (a data wave behind its fold: what the spare wave has not taken yet)
+        if (!aux_first) aux_rows(std::integral_constant<int, 8>{}, std::integral_constant<int, 4>{});      // (a data wave behind its fold: what the spare wave has not taken yet)
     }
     stamp[5] = wall_clock64() - stamp0;                       // short roles done
 #ifdef FF_RES_WGSTAMPS

@@ -513,8 +513,10 @@ class FrameFusion(nn.Module):
         """Outputs first, then ONE crossing that enqueues the whole call (ff_ctx_merge_submit: the one-launch kernel, or K1 + plan +
         merge kernel), then the wait (ff_ctx_merge_collect).  Exactly sized outputs (the default) are allocated for the length the
         top-k branch gives (main.py:122, host arithmetic) and the merge kernel / phase goes out BLIND into them, guarded on the
-        device: if the plan decides otherwise - or no length can be guessed - nothing is written (`applied` = 0) and the merge
-        kernel follows alone, into outputs of the length the result block names (ff_ctx_merge_apply)."""
+        device: if the plan decides otherwise - or no length can be guessed - the three launches write nothing (`applied` = 0) and
+        the merge kernel follows alone, into outputs of the length the result block names; the one-launch kernel, which publishes
+        that length before its plan is through, waits for them rows in hand (`applied` = 2; second mail slot) - no second launch
+        (ff_ctx_merge_apply either way)."""
         lib = _lib.load()
         sc, L = st["sc"], st["L"]
 
@@ -531,8 +533,8 @@ class FrameFusion(nn.Module):
         _PACK_I64.pack_into(sc.call, _lib.MERGE_CALL_LATE_OFFSET, late)
         if late:
             # the one-launch kernel needs its outputs ~35 us after it starts: launch first (the auxiliary SOURCES go with the
-            # launch), allocate under it, hand the addresses over in pinned memory (ff_ctx_merge_mail: plain stores, written
-            # before the wait below begins)
+            # launch), allocate under it, hand the addresses over in pinned memory (ff_ctx_merge_mail, slot 1: plain stores,
+            # written before the wait below begins)
             self._no_outputs(st)
             self._merge_sources(st)
             rc = lib.ff_ctx_merge_submit(sc.ctx_ptr, sc.call_ptr)

@@ -220,7 +220,7 @@ typedef struct ff_ctx {
     int64_t cur_nv;        /* visual / non-text tokens of the sequence `order` describes (0: unknown to  */
     int64_t cur_ftn;       /* the host): makes a later merge call eligible for the one-launch kernel     */
     int64_t res_active;    /* the submitted call went out as 1: the one-launch kernel, 2: three launches with a
-                              blind, guarded merge kernel                                                */
+                              blind, guarded merge kernel; 3: state 3* (a one-launch kernel waits for mail) */
     int64_t res_off;       /* > 0: merge calls left for which the one-launch kernel is not tried (it gave up recently;
                               an owner that keeps two samples in flight on two streams keeps this > 1)   */
 } ff_ctx_t;
@@ -255,7 +255,8 @@ typedef struct ff_merge_result {
     int64_t unhinted;    /* 1: the layout hint was wrong; the call was repeated through K0 (stop hinting) */
     int64_t wait_ns;     /* time spent polling for the result block (diagnostics)                       */
     int64_t applied;     /* 1: the merge kernel of the call is enqueued (or ran); 0: the plan only - state 3,
-                            ff_ctx_merge_apply must follow                                              */
+                            ff_ctx_merge_apply must follow; 2: a one-launch kernel waits for outputs of l_out rows
+                            by mail - state 3*, ff_ctx_merge_apply hands them over / confirms them (no launch) */
 } ff_merge_result_t;
 
 /* STATE DIAGRAM of a context (ctx->in_flight).  Every other transition returns FF_ERR_STATE and changes nothing;
@@ -266,7 +267,10 @@ typedef struct ff_merge_result {
  *      |                      '------begin (restart: the workspace is reset)--> 1
  *      '--------submit (K1 + plan + K4, or ONE kernel)----> 4 submitted --[mail]--> 4
  *                                                              '--collect (waits)--> 0   (result->applied = 1)
- *                                                                              '---> 3   (result->applied = 0) --apply--> 0
+ *                                                                              '---> 3   (result->applied = 0) --apply (K4)--> 0
+ *                                                                              '---> 3*  (result->applied = 2) --[mail]--> 3*
+ *                                                                                        --apply (mail if none holds l_out rows, then the
+ *                                                                                          kernel's acknowledgement; no launch)--> 0
  *   prune / prune_from_qk / last_query_importance / gather_mask: state 0 only, stay in 0.
  *
  * begin:   (reset if dirty) + K0 unless order_valid / hinted + K1.  Enqueues only; no output field is looked at.
@@ -286,10 +290,18 @@ typedef struct ff_merge_result {
  *          kernel that reads every row ONCE (csrc/ff_resident.hip); same results bit for bit; hidden_out = NULL = plan only.
  *          Two such kernels side by side wait for each other's CUs until one gives up (~2 ms, repeated as three launches):
  *          an owner with two samples in flight sets ctx->res_off > 1 on both contexts.
- * mail:    outputs of a late_outputs submit: plain stores of {seq, hidden_out, L_cap, n_aux, aux[].dst} into the pinned block
- *          (words FF_MAIL_WORD..), no HIP call; the kernel needs them ~35 us after its launch, one of its waves relays them.
- *          Must be called before collect (the kernel waits for it).
- * collect: the wait + bookkeeping of a submitted call (layout retry, give-up retry, mask gather, order swap). */
+ * mail:    outputs of a late_outputs submit: plain stores of {4 seq + slot, hidden_out, L_cap, n_aux, aux[].dst} into the pinned
+ *          block (two slots of FF_MAIL_WORDS words from FF_MAIL_WORD on; each written once per call), no HIP call; one wave of
+ *          the kernel relays them into device memory.  Slot 1 = outputs that exist before the result does (L rows, or a guessed
+ *          length): mailed between submit and collect, taken if they hold exactly l_out rows or a whole input.  Slot 2 = outputs
+ *          sized to the result (state 3*, ctx->res_active == 3).
+ * collect: the wait + bookkeeping of a submitted call (layout retry, give-up retry, mask gather, order swap).  The one-launch
+ *          kernel publishes the result block right behind its grid barrier (the barrier carries the two counts that decide
+ *          the branch and l_out), ~12 us before its plan is through, and then WAITS for outputs by mail, rows in hand:
+ *          applied = 2.  The caller sizes its outputs to l_out (unless slot 1 holds them already) and calls apply, which mails
+ *          what is not mailed yet and reads the kernel's acknowledgement (FF_STAT_ACK; two PCIe round trips) - the call block
+ *          must name the buffers of the mail that was taken.  A kernel that waited ~4 ms in vain leaves with the plan only; apply
+ *          sees that (ACK = 4 seq + 3) and enqueues the merge kernel as in state 3. */
 int ff_ctx_merge_begin(ff_ctx_t* ctx, const ff_merge_call_t* call);
 int ff_ctx_merge_finish(ff_ctx_t* ctx, const ff_merge_call_t* call, ff_merge_result_t* result);
 int ff_ctx_merge_wait(ff_ctx_t* ctx, const ff_merge_call_t* call, ff_merge_result_t* result);
