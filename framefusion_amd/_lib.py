@@ -30,7 +30,7 @@ ERR_BIT_BARRIER, ERR_BIT_LAYOUT, ERR_BIT_RESIDENT = 1, 2, 4
 STAT_APPLIED = 12
 STAT_WORDS = 32
 STAT_ACK = 13               # pinned block: 4 * seq + the mail slot the one-launch kernel took (3: none in time)
-MAIL_WORD, MAIL_WORDS, MAIL_SLOTS = 16, 8, 2       # pinned words 16..31: the two mail slots of a late_outputs call
+MAIL_WORD, MAIL_WORDS, MAIL_SLOTS, HOST_WORDS = 16, 24, 2, 64       # pinned words 16..63: the two mail slots of a late_outputs call
 MAX_AUX = 4
 ABI_VERSION = 11
 ERR_DEVICE, ERR_STATE = -5, -6

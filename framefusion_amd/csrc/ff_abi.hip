@@ -511,8 +511,8 @@ extern "C" int ff_ctx_merge_submit(ff_ctx_t* c, const ff_merge_call_t* a) {
     }
     if (a->mask && !a->mask_out && a->hidden_out) return FF_ERR_ARG;
     const bool late = a->late_outputs != 0;
-    for (int x = 0; x < ((a->hidden_out || late) ? (int)a->n_aux : 0); ++x)
-        if (!a->aux[x].src || (!late && !a->aux[x].dst) || a->aux[x].row_bytes < 1 || a->aux[x].outer < 1 || a->aux[x].src_outer_bytes < 0) return FF_ERR_ARG;
+    for (int x = 0; x < ((a->hidden_out && !late) ? (int)a->n_aux : 0); ++x)
+        if (!a->aux[x].src || !a->aux[x].dst || a->aux[x].row_bytes < 1 || a->aux[x].outer < 1 || a->aux[x].src_outer_bytes < 0) return FF_ERR_ARG;
     hipStream_t st = (hipStream_t)a->stream;
     rc = ctx_clean(c, st);
     if (rc) return rc;
@@ -536,7 +536,7 @@ extern "C" int ff_ctx_merge_submit(ff_ctx_t* c, const ff_merge_call_t* a) {
         m[FF_MAIL_WORDS] = 0;
         c->stats_host[FF_STAT_ACK] = 0;
         p.mail = c->stats_host + FF_MAIL_WORD;
-        p.hidden_out = nullptr; p.L_cap = 0;
+        p.hidden_out = nullptr; p.L_cap = 0; p.n_aux = 0;
     }
     rc = ff::launch_merge_resident(p, st);
     if (rc) { c->order_len = 0; return rc; }
@@ -550,7 +550,8 @@ static int ctx_mail(ff_ctx_t* c, const ff_merge_call_t* a) {
     if (a->n_aux < 0 || a->n_aux > FF_MAX_AUX) return FF_ERR_ARG;
     if ((uintptr_t)a->hidden_out & 15) return FF_ERR_ALIGN;
     for (int x = 0; x < (a->hidden_out ? (int)a->n_aux : 0); ++x)
-        if (!a->aux[x].dst) return FF_ERR_ARG;
+        if (!a->aux[x].src || !a->aux[x].dst || a->aux[x].row_bytes < 1 || a->aux[x].outer < 1 || a->aux[x].src_outer_bytes < 0) return FF_ERR_ARG;
+    static_assert(sizeof(ff_aux_t) == 40 && FF_MAIL_WORDS == 4 + 5 * FF_MAX_AUX, "a mail slot holds the auxiliary entries whole");
     int64_t* m = c->stats_host + FF_MAIL_WORD;
     int slot = 1;
     if (m[0] == c->seq * 4 + 1) {
@@ -561,7 +562,16 @@ static int ctx_mail(ff_ctx_t* c, const ff_merge_call_t* a) {
     m[1] = (int64_t)(uintptr_t)a->hidden_out;
     m[2] = a->hidden_out ? a->L_cap : 0;
     m[3] = a->hidden_out ? a->n_aux : 0;
-    for (int x = 0; x < FF_MAX_AUX; ++x) m[4 + x] = x < a->n_aux ? (int64_t)(uintptr_t)a->aux[x].dst : 0;
+    const bool any = a->hidden_out != nullptr;
+    for (int x = 0; x < FF_MAX_AUX; ++x) {
+        const bool on = any && x < a->n_aux;
+        int64_t* e = m + 4 + 5 * x;
+        e[0] = on ? (int64_t)(uintptr_t)a->aux[x].src : 0;
+        e[1] = on ? (int64_t)(uintptr_t)a->aux[x].dst : 0;
+        e[2] = on ? a->aux[x].row_bytes : 0;
+        e[3] = on ? a->aux[x].outer : 0;
+        e[4] = on ? a->aux[x].src_outer_bytes : 0;
+    }
     __atomic_store_n(&m[0], c->seq * 4 + slot, __ATOMIC_RELEASE);
     return FF_OK;
 }

@@ -23,7 +23,7 @@ struct PlanParams {
 // store instruction crosses PCIe once), a system fence, then the sequence word the host polls.
 __device__ inline void publish(int64_t* __restrict__ stats, int64_t* host_mapped, int64_t seq) {
     const int lane = threadIdx.x;          // called by wave 0
-    if (lane < FF_STAT_WORDS && lane != FF_STAT_SEQ)
+    if (lane < FF_STAT_T_ORDER && lane != FF_STAT_SEQ)       // (the pinned words behind are the host's: FF_MAIL_WORD)
         __hip_atomic_store(&host_mapped[lane], stats[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (lane == FF_STAT_ERROR) stats[lane] = 0;     // reported; the next call starts clean
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");

@@ -68,7 +68,7 @@ struct ResBar {
     unsigned long long gen[8][16];       // release word: tag (24 bits, never 0) | threshold-set total (20) | above-ignore total (20)
     unsigned abort_tag[32];
     unsigned long long mail_tag[16];     // outputs by mail, relayed into device memory by ONE wave: 4 * seq + slot (3: none came) ...
-    unsigned long long mail[16];         // ... and the words {., hidden_out, L_cap, n_aux, dst[4]}
+    unsigned long long mail[32];         // ... and the slot's FF_MAIL_WORDS words {., hidden_out, L_cap, n_aux, aux[4]}
 };
 static_assert(sizeof(ResBar) <= 4096, "ff_plan.hip reserves 4 KB of the workspace front");
 
@@ -96,7 +96,7 @@ struct ResArgs {
     long long seq;
     AuxPack aux;
     ResBar* bar;
-    const int64_t* mail;          // != NULL: the outputs come by mail (pinned host words {seq, hidden_out, L_cap, n_aux, dst[4]})
+    const int64_t* mail;          // != NULL: the outputs + auxiliary tensors come by mail (two slots of FF_MAIL_WORDS pinned host words)
 };
 
 // sum of four floats over the wave at once (each total in lane 63): four independent DPP chains interleaved, so that no
@@ -803,8 +803,20 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
     char* out_ptr = a.out;
     long long out_cap = a.L_cap;
     int aux_n = a.aux.n;
-    unsigned long long* auxdst = (unsigned long long*)sres;          // [FF_MAX_AUX] destinations of the auxiliary tensors (LDS)
-    if (tid < FF_MAX_AUX) auxdst[tid] = (unsigned long long)(uintptr_t)a.aux.a[tid].dst;
+    // the auxiliary tensors as the rest of the kernel reads them: LDS copies of the ff_aux_t entries (a mail slot's layout)
+    static_assert(sizeof(ff_aux_t) == 40 && FF_MAIL_WORDS == 4 + 5 * FF_MAX_AUX && FF_MAIL_WORDS <= 32, "slot layout");
+    const ff_aux_t* auxe = (const ff_aux_t*)(sres + 4);
+    if (!a.mail && tid == 0) {
+#pragma unroll
+        for (int x = 0; x < FF_MAX_AUX; ++x) {
+            sres[4 + 5 * x] = (long long)(uintptr_t)a.aux.a[x].src;
+            sres[5 + 5 * x] = (long long)(uintptr_t)a.aux.a[x].dst;
+            sres[6 + 5 * x] = a.aux.a[x].row_bytes;
+            sres[7 + 5 * x] = a.aux.a[x].outer;
+            sres[8 + 5 * x] = a.aux.a[x].src_outer_bytes;
+        }
+    }
+    if (a.mail && !wants_mail) aux_n = 0;
     if (wants_mail) {
         if (relay_wave && relay_state != 1) {
             const long long t0 = wall_clock64();
@@ -833,21 +845,18 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
             }
             bcast[13] = got;
         }
-        if (tid >= kWave && tid < kWave + FF_MAIL_WORDS) sres[16 + tid - kWave] = 0;       // (slots of the relayed words)
         __syncthreads();
         const bool have = bcast[13] == 1 || bcast[13] == 2;
-        if (tid < FF_MAIL_WORDS && have)
-            sres[16 + tid] = (long long)__hip_atomic_load(&a.bar->mail[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < FF_MAIL_WORDS) sres[tid] = have ? (long long)__hip_atomic_load(&a.bar->mail[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ll;
         __syncthreads();
         if (!have) {
             out_ptr = nullptr;
             aux_n = 0;
         } else {
-            out_ptr = (char*)(uintptr_t)sres[16 + 1];
-            out_cap = sres[16 + 2];
-            const int n_mail = (int)sres[16 + 3];
-            aux_n = out_ptr ? (n_mail < FF_MAX_AUX ? n_mail : FF_MAX_AUX) : 0;
-            if (tid < FF_MAX_AUX) auxdst[tid] = (unsigned long long)sres[16 + 4 + tid];
+            out_ptr = (char*)(uintptr_t)sres[1];
+            out_cap = sres[2];
+            const int n_mail = (int)sres[3];
+            aux_n = out_ptr ? (n_mail < FF_MAX_AUX ? (n_mail < 0 ? 0 : n_mail) : FF_MAX_AUX) : 0;
         }
     }
     if (tid == 0) {
@@ -855,8 +864,8 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
         // pair (<< 16; 2: 16 bytes per lane, 1: one 8-byte word, 0: copy_row)
         int np = 0, slow = 0;
         for (int x = 0; x < aux_n; ++x) {
-            const ff_aux_t& ax = a.aux.a[x];
-            const uintptr_t al = (uintptr_t)ax.src | (uintptr_t)auxdst[x] | (uintptr_t)ax.row_bytes | (uintptr_t)ax.src_outer_bytes;
+            const ff_aux_t& ax = auxe[x];
+            const uintptr_t al = (uintptr_t)ax.src | (uintptr_t)ax.dst | (uintptr_t)ax.row_bytes | (uintptr_t)ax.src_outer_bytes;
             const int f = (ax.row_bytes <= 256 && !(al & 15)) ? 2 : ((ax.row_bytes == 8 && !(al & 7)) ? 1 : 0);
             for (int kq = 0; kq < (int)ax.outer; ++kq, ++np) {
                 if (np < 8) scratch[8 + np] = (f << 16) | (x << 8) | kq;
@@ -931,11 +940,11 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
             spz[z] = nullptr; dpz[z] = nullptr; rbz[z] = 0; fz[z] = 0;
             if (z < np) {
                 const int e = scratch[8 + z], x = (e >> 8) & 0xff, kq = e & 0xff;
-                const ff_aux_t& ax = a.aux.a[x];
+                const ff_aux_t& ax = auxe[x];
                 fz[z] = e >> 16;
                 rbz[z] = (int)ax.row_bytes;
                 spz[z] = aux_src_row(ax, kq, 0, L);
-                dpz[z] = (char*)(uintptr_t)auxdst[x] + (int64_t)kq * out_cap * ax.row_bytes;
+                dpz[z] = (char*)ax.dst + (int64_t)kq * out_cap * ax.row_bytes;
             }
         }
         while (true) {
@@ -980,10 +989,10 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
                     if (iu[q] < 0) continue;
                     int z = 0;
                     for (int x = 0; x < aux_n; ++x) {
-                        const ff_aux_t& ax = a.aux.a[x];
+                        const ff_aux_t& ax = auxe[x];
                         for (int kq = 0; kq < (int)ax.outer; ++kq, ++z)
                             if (z >= NP || (scratch[8 + z] >> 16) == 0)
-                                copy_row(aux_src_row(ax, kq, iu[q], L), (char*)(uintptr_t)auxdst[x] + ((int64_t)kq * out_cap + ru[q]) * ax.row_bytes, ax.row_bytes, l16, 16);
+                                copy_row(aux_src_row(ax, kq, iu[q], L), (char*)ax.dst + ((int64_t)kq * out_cap + ru[q]) * ax.row_bytes, ax.row_bytes, l16, 16);
                     }
                 }
             }
@@ -1211,7 +1220,7 @@ int launch_merge_resident(const ResLaunch& p, hipStream_t st) {
     a.member = p.member; a.keep = p.keep; a.dst = p.dst;
     a.order_next = p.order_next; a.inv_next = p.inv_next;
     a.stats = p.stats; a.host_mapped = p.host_mapped; a.seq = p.seq;
-    a.aux.n = (p.hidden_out || p.mail) ? p.n_aux : 0;
+    a.aux.n = (p.hidden_out && !p.mail) ? p.n_aux : 0;
     for (int x = 0; x < FF_MAX_AUX; ++x) a.aux.a[x] = x < a.aux.n ? p.aux[x] : ff_aux_t{nullptr, nullptr, 0, 0, 0};
     a.bar = ws_resbar(p.ws);
     a.mail = p.mail;

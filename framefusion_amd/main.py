@@ -107,11 +107,11 @@ class _Scratch:
             if getattr(self, "stats_host_ptr", None):
                 pass                                             # (one block per scratch: its size does not depend on the capacity)
             else:
-                self.stats_host_ptr = _lib.load().ff_host_alloc(_lib.STAT_WORDS * 8)
+                self.stats_host_ptr = _lib.load().ff_host_alloc(_lib.HOST_WORDS * 8)
                 if not self.stats_host_ptr:
                     raise FrameFusionHipError("ff_host_alloc failed (pinned, coherent host memory for the result block)")
                 import numpy as np
-                self.stats_np = np.ctypeslib.as_array((C.c_int64 * _lib.STAT_WORDS).from_address(self.stats_host_ptr))
+                self.stats_np = np.ctypeslib.as_array((C.c_int64 * _lib.HOST_WORDS).from_address(self.stats_host_ptr))
                 self.stats_host = torch.from_numpy(self.stats_np)
             c = self.ctx
             c.cap = cap
@@ -532,11 +532,10 @@ class FrameFusion(nn.Module):
         late = 1 if st.get("one_launch") else 0
         _PACK_I64.pack_into(sc.call, _lib.MERGE_CALL_LATE_OFFSET, late)
         if late:
-            # the one-launch kernel needs its outputs ~35 us after it starts: launch first (the auxiliary SOURCES go with the
-            # launch), allocate under it, hand the addresses over in pinned memory (ff_ctx_merge_mail, slot 1: plain stores,
-            # written before the wait below begins)
+            # the one-launch kernel needs its outputs - and the position tables / patch types that are gathered with them -
+            # ~35 us after it starts: launch first, describe and allocate under it, hand the lot over in pinned memory
+            # (ff_ctx_merge_mail, slot 1: plain stores, written before the wait below begins)
             self._no_outputs(st)
-            self._merge_sources(st)
             rc = lib.ff_ctx_merge_submit(sc.ctx_ptr, sc.call_ptr)
             if rc:
                 _fail(rc, "merge")
@@ -563,28 +562,6 @@ class FrameFusion(nn.Module):
             self._merge_outputs(st, L_out)
         # (the host's own bookkeeping of the call comes first: the kernel's answer to the mail is two PCIe round trips away)
         return self._merge_complete(st, 0, confirm=lambda: lib.ff_ctx_merge_apply(sc.ctx_ptr, sc.call_ptr, sc.res_ptr))
-
-    def _merge_sources(self, st):
-        """The SOURCE half of the auxiliary entries (patch types + position tensors, destinations 0): no allocation."""
-        sc, L, call = st["sc"], st["L"], st["sc"].call
-        pe = st["position_embeddings"]
-        if type(pe) == list:
-            assert len(pe) == 2
-            for t in pe:
-                if t.ndim not in (3, 4) or t.shape[-2] != L:
-                    raise FrameFusionHipError(f"position embedding of shape {tuple(t.shape)} does not have "
-                                              f"{L} tokens on its second-to-last axis")
-            srcs = [_token_dense(pe[0]), _token_dense(pe[1])]
-        elif type(pe) == torch.Tensor:
-            if pe.ndim != 2:
-                raise NotImplementedError("Only support 2D position embeddings")
-            srcs = [pe.contiguous()]
-        else:
-            raise NotImplementedError("Only support list or tensor for position embeddings")
-        st["late_srcs"] = srcs                               # (kept alive until the call is over)
-        _lib.AUX_ENTRY.pack_into(call, _lib.MERGE_CALL_AUX_OFFSET, st["ptype"].data_ptr(), 0, 8, 1, 0)
-        n_aux = 1 + sc.put_aux(call, _lib.MERGE_CALL_AUX_OFFSET + _lib.AUX_ENTRY.size, ((s, None) for s in srcs), L, room=_lib.MAX_AUX - 1)
-        _PACK_I64.pack_into(call, _lib.MERGE_CALL_AUX_OFFSET - 8, n_aux)
 
     def _no_outputs(self, st, hidden=None):
         """The output half of the call block, empty: a plan-only submit (hidden = None) / an apply that writes nothing."""

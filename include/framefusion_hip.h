@@ -59,7 +59,7 @@ enum {
     FF_STAT_APPLIED = 12,  /* one-launch call: 1 = outputs written (or nothing folds), 0 = the plan only, */
                            /* 2 = the kernel waits for outputs of LOUT rows by mail                       */
     FF_STAT_ACK = 13,      /* pinned block only: 4 * seq + the mail slot the kernel took (3: none in time) */
-    FF_STAT_T_ORDER = 16,  /* device block: 8 diagnostic words.  PINNED block: words 16..23 are the host's */
+    FF_STAT_T_ORDER = 16,  /* device block: 8 diagnostic words.  PINNED block: words 16.. are the host's   */
     FF_STAT_T_PLAN = 24,   /* 7 diagnostic words (phase stamps of the plan / the one-launch kernel)       */
     FF_STAT_WORDS = 32
 };
@@ -205,7 +205,7 @@ typedef struct ff_ctx {
     int32_t* dst;          /* [cap]                                                                     */
     uint8_t* keep;         /* [cap]                                                                     */
     int64_t* stats;        /* [FF_STAT_WORDS] device, zero-initialised                                  */
-    int64_t* stats_host;   /* [FF_STAT_WORDS] pinned host memory the DEVICE can write; for outputs by mail it must be
+    int64_t* stats_host;   /* [FF_HOST_WORDS] pinned host memory the DEVICE can write; for outputs by mail it must be
                               COHERENT while a kernel runs (ff_host_alloc): words FF_MAIL_WORD.. are the host's  */
     void* ws;              /* ff_workspace_bytes(cap, .) bytes, zero-initialised                        */
     size_t ws_bytes;
@@ -245,8 +245,8 @@ typedef struct ff_merge_call {
     const void* mask;            /* optional [L, L] attention mask of mask_elem_bytes per element       */
     void* mask_out;              /* [L_cap, L_cap]: written ONLY when the call folded something         */
     int64_t mask_elem_bytes;
-    int64_t late_outputs;        /* ff_ctx_merge_submit of a one-launch call: != 0 = the outputs follow by
-                                    ff_ctx_merge_mail (aux[].src / row_bytes / outer are set, the dst are not) */
+    int64_t late_outputs;        /* ff_ctx_merge_submit of a one-launch call: != 0 = the outputs AND the auxiliary
+                                    tensors follow by ff_ctx_merge_mail (n_aux / aux[] are not looked at by submit) */
 } ff_merge_call_t;
 
 typedef struct ff_merge_result {
@@ -290,9 +290,10 @@ typedef struct ff_merge_result {
  *          kernel that reads every row ONCE (csrc/ff_resident.hip); same results bit for bit; hidden_out = NULL = plan only.
  *          Two such kernels side by side wait for each other's CUs until one gives up (~2 ms, repeated as three launches):
  *          an owner with two samples in flight sets ctx->res_off > 1 on both contexts.
- * mail:    outputs of a late_outputs submit: plain stores of {4 seq + slot, hidden_out, L_cap, n_aux, aux[].dst} into the pinned
+ * mail:    outputs of a late_outputs submit: plain stores of {4 seq + slot, hidden_out, L_cap, n_aux, aux[]} into the pinned
  *          block (two slots of FF_MAIL_WORDS words from FF_MAIL_WORD on; each written once per call), no HIP call; one wave of
- *          the kernel relays them into device memory.  Slot 1 = outputs that exist before the result does (L rows, or a guessed
+ *          the kernel relays them into device memory.  The auxiliary tensors travel whole (sources too): the kernel needs them
+ *          only behind its plan, so the host describes them AFTER the launch.  Slot 1 = outputs that exist before the result does (L rows, or a guessed
  *          length): mailed between submit and collect, taken if they hold exactly l_out rows or a whole input.  Slot 2 = outputs
  *          sized to the result (state 3*, ctx->res_active == 3).
  * collect: the wait + bookkeeping of a submitted call (layout retry, give-up retry, mask gather, order swap).  The one-launch
@@ -308,7 +309,9 @@ int ff_ctx_merge_wait(ff_ctx_t* ctx, const ff_merge_call_t* call, ff_merge_resul
 int ff_ctx_merge_apply(ff_ctx_t* ctx, const ff_merge_call_t* call, const ff_merge_result_t* result);
 int ff_ctx_merge_submit(ff_ctx_t* ctx, const ff_merge_call_t* call);
 int ff_ctx_merge_collect(ff_ctx_t* ctx, const ff_merge_call_t* call, ff_merge_result_t* result);
-enum { FF_MAIL_WORD = 16, FF_MAIL_WORDS = 8, FF_MAIL_SLOTS = 2 };   /* pinned words 16..31 */
+/* pinned block: FF_STAT_WORDS words the device writes + two mail slots of FF_MAIL_WORDS words the host writes:
+ * {4 seq + slot, hidden_out, L_cap, n_aux, aux[FF_MAX_AUX] as ff_aux_t} */
+enum { FF_MAIL_WORD = 16, FF_MAIL_WORDS = 24, FF_MAIL_SLOTS = 2, FF_HOST_WORDS = 64 };
 int ff_ctx_merge_mail(ff_ctx_t* ctx, const ff_merge_call_t* call);
 /* 1 if ff_ctx_merge_submit(ctx, call) would go out as the one-launch kernel now (input half of `call` only) */
 int ff_ctx_merge_one_launch(const ff_ctx_t* ctx, const ff_merge_call_t* call);

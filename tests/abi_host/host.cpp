@@ -72,8 +72,8 @@ static int full_mode(int F, int P, int d, int pre, int L, const std::vector<uint
     CK(hipMalloc(&dorder, L * 4)); CK(hipMalloc(&dorder_next, L * 4)); CK(hipMalloc(&dinv, L * 4)); CK(hipMalloc(&dinv_next, L * 4));
     CK(hipMalloc(&dsim, L * 4)); CK(hipMalloc(&dmember, L)); CK(hipMalloc(&ddst, L * 4)); CK(hipMalloc(&dkeep, L));
     CK(hipMalloc(&dstats, FF_STAT_WORDS * 8)); CK(hipMalloc(&dws, wsb));
-    CK(hipHostMalloc((void**)&stats_host, FF_STAT_WORDS * 8, hipHostMallocDefault));
-    memset(stats_host, 0, FF_STAT_WORDS * 8);
+    CK(hipHostMalloc((void**)&stats_host, FF_HOST_WORDS * 8, hipHostMallocDefault));
+    memset(stats_host, 0, FF_HOST_WORDS * 8);
     CK(hipMemcpy(dbase, base.data(), hb, hipMemcpyHostToDevice)); CK(hipMemcpy(dadd, add.data(), hb, hipMemcpyHostToDevice));
     CK(hipMemcpy(dpt, pt.data(), L * 8, hipMemcpyHostToDevice));
     for (int w = 0; w < 2; ++w) CK(hipMemcpy(dtab[w], tab[w].data(), tb, hipMemcpyHostToDevice));
@@ -155,8 +155,8 @@ static int full_mode(int F, int P, int d, int pre, int L, const std::vector<uint
         CK(hipMalloc(&bsim, L * 4)); CK(hipMalloc(&bmember, L)); CK(hipMalloc(&bdst, L * 4)); CK(hipMalloc(&bkeep, L));
         CK(hipMalloc(&bstats, FF_STAT_WORDS * 8)); CK(hipMalloc(&bws, wsb)); CK(hipMalloc(&bout, hb)); CK(hipMalloc(&bpt_out, L * 8));
         for (int w = 0; w < 2; ++w) CK(hipMalloc(&btab_out[w], tb));
-        CK(hipHostMalloc((void**)&bstats_host, FF_STAT_WORDS * 8, hipHostMallocDefault));
-        memset(bstats_host, 0, FF_STAT_WORDS * 8);
+        CK(hipHostMalloc((void**)&bstats_host, FF_HOST_WORDS * 8, hipHostMallocDefault));
+        memset(bstats_host, 0, FF_HOST_WORDS * 8);
         CK(hipMemset(bstats, 0, FF_STAT_WORDS * 8)); CK(hipMemset(bws, 0, wsb));
         hipStream_t st_b; CK(hipStreamCreateWithFlags(&st_b, hipStreamNonBlocking));
         ff_ctx_t ctx_b; memset(&ctx_b, 0, sizeof ctx_b);

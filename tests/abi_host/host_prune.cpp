@@ -62,7 +62,7 @@ struct Scratch {
         CK(hipMemset(p, 0, FF_STAT_WORDS * 8));
         CK(hipMalloc(&p, wsb)); ctx.ws = p; ctx.ws_bytes = wsb;
         CK(hipMemset(p, 0, wsb));
-        ctx.stats_host = (int64_t*)ff_host_alloc(FF_STAT_WORDS * 8);         // coherent: outputs may go by mail
+        ctx.stats_host = (int64_t*)ff_host_alloc(FF_HOST_WORDS * 8);         // coherent: outputs may go by mail
         return ctx.stats_host ? 0 : 2;
     }
 };

@@ -227,7 +227,7 @@ def test_every_illegal_transition_is_refused_and_changes_nothing():
         ctx, call, res, pc, lq = _lib.FFCtx(), _lib.FFMergeCall(), _lib.FFMergeResult(), _lib.FFPruneCall(), _lib.FFLqArgs()
         for f in ("order", "order_next", "inv", "inv_next", "sim", "member", "dst", "keep", "stats", "ws"):
             setattr(ctx, f, 4096)
-        host = (C.c_int64 * _lib.STAT_WORDS)()
+        host = (C.c_int64 * _lib.HOST_WORDS)()
         ctx.stats_host = C.addressof(host)
         ctx.cap = 1024
         ctx.ws_bytes = lib.ff_workspace_bytes(1024, 1)

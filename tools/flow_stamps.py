@@ -95,7 +95,7 @@ def main():
     # stamped loop
     real = _lib.load()
     _lib._lib = LibProxy(real)
-    for m in ("prepare", "_merge_prepare", "_merge_outputs", "_merge_sources", "_no_outputs", "_merge_complete", "_scratch_for",
+    for m in ("prepare", "_merge_prepare", "_merge_outputs", "_no_outputs", "_merge_complete", "_scratch_for",
               "_merge_submitted"):
         wrap_method(ffa.FrameFusion, m)
     for _ in range(20):

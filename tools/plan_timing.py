@@ -24,11 +24,12 @@ for it in range(60):
     out, _, _ = ff(h2 if it & 1 else h, [cos, sin], None)
     torch.cuda.synchronize()
     sc = ff.last_call["scratch"]
-    acc.append(np.concatenate((np.array(sc.stats_np[_lib.STAT_T_PLAN:_lib.STAT_T_PLAN + 7], dtype=np.float64),
-                               np.array(sc.stats_np[_lib.STAT_T_ORDER:_lib.STAT_T_ORDER + 3], dtype=np.float64))) / 100.0)
+    dstats = sc.stats.cpu().numpy()        # (the diagnostic words stay on the device: the pinned words behind 15 are the host's)
+    acc.append(np.concatenate((np.array(dstats[_lib.STAT_T_PLAN:_lib.STAT_T_PLAN + 7], dtype=np.float64),
+                               np.array(dstats[_lib.STAT_T_ORDER:_lib.STAT_T_ORDER + 3], dtype=np.float64))) / 100.0)
 a = np.stack(acc[10:])
 names = ["loads issued + LDS filled", "first barrier", "level 0", "level 1 + t*", "classified", "exchanged", "end", "[last wave started", "first wave ready", "last wave ready]"]
-pk = int(sc.stats_np[_lib.STAT_T_ORDER + 3])
+pk = int(dstats[_lib.STAT_T_ORDER + 3])
 print("per-wave ready (x0.4 us):", [(pk >> (4 * x)) & 15 for x in range(16)])
 print(f"L={L} -> {out.shape[1]}; plan kernel phase stamps (us since entry, last workgroup): " +
       ", ".join(f"{n} {v:.2f}" for n, v in zip(names, a.mean(0))))
