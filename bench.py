@@ -543,6 +543,9 @@ def profiled_kernel_us(cfg):
     if m is None or m.group(1) != _lib.source_hash():
         src["stale"] = "the kernel sources changed since this timeline was taken: kernel_us withheld"
         return None, src
+    if "k_merge_resident" in text:
+        src["note"] = ("the one-launch kernel waits inside the kernel for the host's mail: its traced duration contains the host's "
+                       "reaction time (lengthened by the tracer); profiles/*_resident_stamps.txt has its device time")
     m = re.search(r"kernel_us ([0-9.]+)", text)
     return (float(m.group(1)) if m else None), src
 
@@ -555,6 +558,7 @@ def two_samples_per_gpu(ffa, dev, F, P, d, p_change, seed, steps, warmup):
     Whole-GPU throughput of `steps` steps per sample; NOT the headline (one sample per GPU per step)."""
     import threading
     from framefusion_amd.synth import video_tokens, rotary_tables
+    from framefusion_amd import pair as pair_mod
     work = []
     for t in range(2):
         h, pt = video_tokens(F, P, d, p_change=p_change, sigma=SIGMA, seed=seed + 100 + t, dtype=torch.bfloat16, device=str(dev))
@@ -635,6 +639,7 @@ def two_samples_per_gpu(ffa, dev, F, P, d, p_change, seed, steps, warmup):
                                      "how": "framefusion_amd.FrameFusionPair (ff_ctx_merge_submit / _collect), two HIP streams, no threads"},
             "two_threads": {**best["two_threads"], "all_us": [r["us_per_pair_of_steps"] for r in runs["two_threads"]]},
             "one_host_thread_pair_exact_outputs": exact,
+            "pair_streams": sorted(set(pair_mod.STREAM_SOURCE.values())),
             "us_per_pair_of_steps": best["one_host_thread_pair"]["us_per_pair_of_steps"],
             "tokens_reduced_per_s": best["one_host_thread_pair"]["tokens_reduced_per_s"]}
 

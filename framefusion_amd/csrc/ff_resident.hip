@@ -329,13 +329,8 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
         uint32_t prev_off;
         if constexpr (kHint) prev_off = (uint32_t)pos_hint(s0 > 0 ? s0 - 1 : 0) * rb;
         else prev_off = (uint32_t)__builtin_amdgcn_readlane(ordw, 0) * rb;
-#ifdef FF_RES_NO_UNCOUNTED
-        const uint4 prev_c = buf_load16s(hres, vcol, prev_off);
-        u32x4 prevv; prevv.x = prev_c.x; prevv.y = prev_c.y; prevv.z = prev_c.z; prevv.w = prev_c.w;
-#else
         u32x4 prevv;
         buf_load16_uncounted(prevv, hraw, vcol, prev_off);
-#endif
         // every wave issues exactly 1 + RL + RV requests (rows past n: an out-of-range offset, answered with zeros without
         // traffic), so that the hand-counted waits below hold for every segment length
 #pragma unroll
@@ -374,11 +369,7 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
             if (i + 1 < RV) { if (RL + i + 1 < n) v[i + 1] = buf_load16s(hres, vcol, row_off(RL + i + 1)); else v[i + 1] = buf_load16s(hres, kDead, 0u); }
             if (i == 0) {
                 // (the row before my first slot was requested first: it is there when rows 0 and 1 are)
-#ifdef FF_RES_WAIT_ALL
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(prevv) :: "memory");
-#else
                 asm volatile("s_waitcnt vmcnt(%1)" : "+v"(prevv) : "n"(RL) : "memory");
-#endif
                 const uint4 prev = make_uint4(prevv.x, prevv.y, prevv.z, prevv.w);
                 if constexpr (DT == FF_BF16) A::unpack(prev, lastf);
                 else lastw = prev;
@@ -386,9 +377,7 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
                 wave_sum4_dpp63(q0, z0, z1, z2);
                 if (lane == 63) part[wv] = make_float2(q0, 0.f);
             } else {
-#ifndef FF_RES_WAIT_ALL
                 asm volatile("s_waitcnt vmcnt(%0)" :: "n"(RL) : "memory");
-#endif
             }
             if (i < n) two(*lrow(i), *lrow(i + 1), i);
         }
@@ -1009,6 +998,9 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
 
     // ======================================================================================================================
     // C. fold + compaction from the resident rows
+#ifdef FF_RES_WGSTAMPS
+    long long wg_waited = 0;
+#endif
     if (folded && data_wave) {
         const __amdgpu_buffer_rsrc_t ores = make_rsrc(out_ptr, (uint32_t)(out_cap * (long long)rb));
         // member bits of my slots and of the 64 behind them; output row of every anchor (by lane)
@@ -1055,13 +1047,43 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
         for (int i = 0; i < RL; ++i)
             if (i < n) take(*lrow(i), i);
         sub[4] = wall_clock64() - stamp0;                     // LDS rows folded
+        // The last run of my segment may go on in the following segments.  Those rows sit in other workgroups' registers; this
+        // one fetches them again (L2 / Infinity Cache: the only rows read twice).  The first kResRL of them are requested NOW, by
+        // LDS-DMA into the LDS rows just folded, and arrive under the fold of the VGPR rows: fetched behind the fold, two per
+        // round trip, they were the kernel's tail (up to 10 us at the 7B layout).
+        int pre_run = 0;
+        {
+            const int tt = s1 + lane;
+            const bool mb = tt < nv && slotbit(tt);
+            const unsigned long long mw = __ballot(mb);
+            const int run = mw == ~0ull ? kWave : __ffsll((long long)~mw) - 1;      // leading members behind my segment
+            pre_run = run < RL ? run : RL;
+            int iw = 0;
+            if (lane < pre_run) {
+                if constexpr (kHint) iw = pos_hint(tt);
+                else iw = a.order[tt];
+            }
+            for (int u = 0; u < pre_run; ++u)
+                buf_load16_lds(hraw, vcol, (uint32_t)__builtin_amdgcn_readlane(iw, u) * rb, (uint32_t)(uintptr_t)(lrows + ((size_t)u * nt + wv) * 1024));
+        }
 #pragma unroll
         for (int i = 0; i < RV; ++i)
             if (RL + i < n) take(v[i], RL + i);
         sub[5] = wall_clock64() - stamp0;                     // VGPR rows folded
-        // the open run may go on in the following segments: those rows come from L2 / the Infinity Cache
+        if (pre_run > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the LDS-DMA rows: not the compiler's to count)
+#ifdef FF_RES_WGSTAMPS
+        wg_waited = wall_clock64() - stamp0;
+#endif
         if (open_r >= 0) {
-            for (int t = s1; t < nv;) {
+            for (int u = 0; u < pre_run; ++u) {
+                float y[E];
+                A::unpack(*lrow(u), y);
+#pragma unroll
+                for (int e = 0; e < E; ++e) acc[e] = A::rnd(acc[e] + y[e]);
+                ++open_n;
+            }
+            // (a run of more than kResRL rows behind my segment: the rest eight at a time)
+            for (int t = s1 + pre_run; pre_run == RL && t < nv;) {
                 const int tt = t + lane;
                 const bool mb = tt < nv && slotbit(tt);
                 const unsigned long long mw = __ballot(mb);
@@ -1071,13 +1093,14 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
                     if constexpr (kHint) iw = pos_hint(tt);
                     else iw = a.order[tt];
                 }
-                for (int u = 0; u < run; u += 2) {
-                    uint4 x[2];
+                constexpr int kB = 8;                        // rows in flight (the VGPR rows are folded: their registers are free)
+                for (int u = 0; u < run; u += kB) {
+                    uint4 x[kB];
 #pragma unroll
-                    for (int z = 0; z < 2; ++z)
+                    for (int z = 0; z < kB; ++z)
                         if (u + z < run) x[z] = buf_load16s(hres, vcol, (uint32_t)__builtin_amdgcn_readlane(iw, u + z) * rb);
 #pragma unroll
-                    for (int z = 0; z < 2; ++z) {
+                    for (int z = 0; z < kB; ++z) {
                         if (u + z < run) {
                             float y[E];
                             A::unpack(x[z], y);
@@ -1104,8 +1127,13 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
         }
     }
     stamp[4] = wall_clock64() - stamp0;                       // my rows folded and written (this wave)
-#ifdef FF_RES_SYNCROLES
-    __syncthreads();
+#ifdef FF_RES_WGSTAMPS
+    if (tid == 0) {                                          // (latest first wave of the launch, relative to its workgroup's start;
+        // one atomic per workgroup and word: same-address device atomics cost ~10 ns EACH - three per wave made the kernel 114 us)
+        atomicMax(&wgdbg[9], (unsigned long long)(wg_waited - sub[5]));     // longest wait for the prefetched continuation rows
+        atomicMax(&wgdbg[10], (unsigned long long)(sub[6] - sub[5]));      // longest continuation into the next segments
+        atomicMax(&wgdbg[11], (unsigned long long)stamp[4]);               // fold + non-visual rows done
+    }
 #endif
     if (!spare_wave) {
         index_roles(tid, kResThreads);

@@ -185,6 +185,36 @@ static int layout_mode(int argc, char** argv) {
     printf("L %d ONE_LAUNCH %d APPLIED %lld LOUT %lld BRANCH %lld COUNT %lld UNHINTED %lld\n", L, one, (long long)res.applied, (long long)res.l_out,
            (long long)res.branch, (long long)res.count, (long long)res.unhinted);
     printf("PTYPE_FNV %016llx\nHIDDEN_FNV %016llx\nPTYPE_OUT_FNV %016llx\n", (unsigned long long)fnv64(pt), (unsigned long long)fnv16(o), (unsigned long long)fnv64(po));
+    // the same call once more with the outputs BY MAIL (what the Python host does for exactly sized outputs): launch without any
+    // output, mail buffers of a wrong length (slot 1: refused), read l_out from the result block the kernel publishes behind its
+    // barrier, hand over buffers of exactly l_out rows (ff_ctx_merge_apply mails slot 2 and reads the acknowledgement: no launch)
+    FF(ff_ctx_reset(&sc.ctx, st));
+    void *dout2, *dpt_out2;
+    CK(hipMalloc(&dout2, h.size() * 2)); CK(hipMalloc(&dpt_out2, L * 8));
+    CK(hipMemset(dout2, 0, h.size() * 2)); CK(hipMemset(dpt_out2, 0, L * 8));
+    ff_merge_call_t late = call;
+    ff_merge_result_t res2;
+    late.late_outputs = 1; late.hidden_out = nullptr; late.L_cap = 0; late.n_aux = 0;
+    const int one2 = ff_ctx_merge_one_launch(&sc.ctx, &late);
+    int slot = 0;
+    if (one2) {
+        FF(ff_ctx_merge_submit(&sc.ctx, &late));
+        late.hidden_out = dout2; late.L_cap = res.l_out + 1; late.n_aux = 1;
+        late.aux[0] = ff_aux_t{dpt, dpt_out2, 8, 1, 0};
+        FF(ff_ctx_merge_mail(&sc.ctx, &late));                 // a guess that does not come true
+        FF(ff_ctx_merge_collect(&sc.ctx, &late, &res2));
+        if (res2.applied != 2 || res2.l_out != res.l_out) { fprintf(stderr, "late collect: applied %lld l_out %lld\n", (long long)res2.applied, (long long)res2.l_out); return 7; }
+        late.L_cap = res2.l_out;
+        FF(ff_ctx_merge_apply(&sc.ctx, &late, &res2));
+        slot = (int)(sc.ctx.stats_host[FF_STAT_ACK] & 3);
+        CK(hipStreamSynchronize(st));
+        std::vector<uint16_t> o2((size_t)res2.l_out * d);
+        std::vector<int64_t> po2(res2.l_out);
+        CK(hipMemcpy(o2.data(), dout2, o2.size() * 2, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(po2.data(), dpt_out2, res2.l_out * 8, hipMemcpyDeviceToHost));
+        printf("LATE_HIDDEN_FNV %016llx\nLATE_PTYPE_OUT_FNV %016llx\n", (unsigned long long)fnv16(o2), (unsigned long long)fnv64(po2));
+    }
+    printf("LATE_ONE_LAUNCH %d\nLATE_MAIL_SLOT %d\n", one2, slot);
     return 0;
 }
 

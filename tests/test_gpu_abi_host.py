@@ -245,3 +245,6 @@ def test_cpp_host_layout_entry_points_feed_a_merge_call(tmp_path):
     f.prepare(pt.to(DEV), P, pre, pre + F * P - 1, F * P, L)
     hg, _, _ = f(h.to(DEV), torch.arange(L, device=DEV)[None], None)
     assert int(out["HIDDEN_FNV"], 16) == wsum16(hg.cpu())
+    # the same call with its outputs by mail: first slot refused (wrong length), second taken - no second launch, same bits
+    assert int(out["LATE_ONE_LAUNCH"]) == 1 and int(out["LATE_MAIL_SLOT"]) == 2
+    assert out["LATE_HIDDEN_FNV"] == out["HIDDEN_FNV"] and out["LATE_PTYPE_OUT_FNV"] == out["PTYPE_OUT_FNV"]

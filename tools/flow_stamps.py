@@ -78,7 +78,7 @@ def main():
         # a library built with EXTRA=-DFF_RES_WGSTAMPS: earliest / latest workgroup start and end of the kernels of a back-to-back
         # loop (device clock, 100 MHz), and the host's clock around the launch
         sc = ff.last_call["scratch"]
-        dbg = sc.ws[20800 + 3072: 20800 + 3072 + 72].view(torch.int64)
+        dbg = sc.ws[20800 + 3072: 20800 + 3072 + 96].view(torch.int64)
         M = (1 << 64) - 1
         rows = []
         for _ in range(12):
@@ -89,9 +89,9 @@ def main():
             torch.cuda.synchronize()
             v = [x & M for x in dbg.tolist()]
             s_min, s_max, e_min, e_max, s0, e0 = M - v[0], v[1], M - v[2], v[3], v[4], v[5]
-            rows.append(((s_max - s_min) / 100, (e_min - s_min) / 100, (e_max - s_min) / 100, (s0 - s_min) / 100, (e0 - s_min) / 100, (v[6] - s_min) / 100, (v[7] - s_min) / 100, (v[8] - s_min) / 100))
+            rows.append(((s_max - s_min) / 100, (e_min - s_min) / 100, (e_max - s_min) / 100, (s0 - s_min) / 100, (e0 - s_min) / 100, (v[6] - s_min) / 100, (v[7] - s_min) / 100, (v[8] - s_min) / 100, v[9] / 100, v[10] / 100, v[11] / 100))
         for r in rows:
-            print("  workgroup starts spread over %.1f us; first end %.1f, last end %.1f us after the first start; workgroup 0: start %.1f end %.1f; its spare wave: roles from %.1f, index roles done %.1f, auxiliary rows done %.1f" % r)
+            print("  workgroup starts spread over %.1f us; first end %.1f, last end %.1f us after the first start; workgroup 0: start %.1f end %.1f; its spare wave: roles from %.1f, index roles done %.1f, auxiliary rows done %.1f; latest wave of the launch: longest wait for the prefetched rows %.1f, longest continuation %.1f, fold done %.1f" % r)
     # stamped loop
     real = _lib.load()
     _lib._lib = LibProxy(real)

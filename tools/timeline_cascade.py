@@ -39,3 +39,7 @@ span = sum(c[-1][2] - c[0][1] for c in same) / len(same) / 1e3
 between = [same[i + 1][0][1] - same[i][-1][2] for i in range(len(same) - 1) if casc.index(same[i + 1]) == casc.index(same[i]) + 1]
 print(f"per cascade: kernels {tot_k:.1f} us + gaps inside {tot_g:.1f} us = span {span:.1f} us; idle between consecutive cascades "
       f"{(sum(between) / len(between) / 1e3) if between else 0.0:.1f} us; kernel_us {tot_k:.1f}")
+if any("k_merge_resident" in nm for nm in names):
+    print("# note: k_merge_resident waits INSIDE the kernel for the host's mail (outputs allocated after the launch; on the threshold "
+          "branch after the result block): its duration here contains the host's reaction time, which the tracer lengthens. Device "
+          "time without the wait: tools/flow_stamps.py --wg (first workgroup start -> last workgroup end).")
