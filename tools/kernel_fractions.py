@@ -33,9 +33,16 @@ for cfg in ("c2", "7b", "c3", "c5", "c5topk", "c2thr"):
     q = 0
     nv = vis
     for kind, a, b in calls:
-        if kind == "merge":
-            per = [("k_pair_similarity", nv * row), ("k_plan", 0),
-                   ("k_merge_compact", 0 if a == b else (a + b) * row + (a + b) * pe_row + 8 * (a + b))]
+        if kind == "merge" and kern[q][0].startswith("k_merge_resident"):
+            # the one-launch kernel: every row read ONCE, l_out rows written (an identity call: the visual rows read)
+            per = [("k_merge_resident", nv * row if a == b else a * row + b * row + (a + b) * pe_row + 8 * (a + b))]
+            nv -= a - b
+        elif kind == "merge":
+            fold_bytes = 0 if a == b else (a + b) * row + (a + b) * pe_row + 8 * (a + b)
+            per = [("k_pair_similarity", nv * row), ("k_plan", 0), ("k_merge_compact", fold_bytes)]
+            if a != b and q + 3 < len(kern) and kern[q + 2][0].startswith("k_merge_compact") and kern[q + 3][0].startswith("k_merge_compact"):
+                # exactly sized outputs guessed for the other branch: the guarded merge kernel wrote nothing, the real one follows
+                per = [("k_pair_similarity", nv * row), ("k_plan", 0), ("k_merge_compact", 0), ("k_merge_compact", fold_bytes)]
             nv -= a - b
         else:
             per = [("k_lq", 0), ("k_lq", c["kv_heads"] * a * DH * ELT), ("k_plan", 0), ("k_prune_gather", 2 * b * (row + pe_row))]
@@ -56,4 +63,6 @@ for cfg in ("c2", "7b", "c3", "c5", "c5topk", "c2thr"):
             else:
                 print(f"  {kind:5s} {a:6d} -> {b:6d}  {name:34s} {us:7.1f} us  (latency)")
     print()
+print("# k_merge_resident: its traced duration contains the wait for the host's mail (see the note in the timelines); device time without it:")
+print("# <tag>_resident_stamps.txt.")
 print(f"# largest fraction: {worst:.2f} (nothing above the 8 TB/s peak, nothing above the chip's ~6.3 TB/s copy rate = 0.79)")
