@@ -246,12 +246,13 @@ class FrameFusion(nn.Module):
         self.similarity_lower_bound = similarity_lower_bound
         self.ratio_lower_bound = ratio_lower_bound
         # compact_outputs = True (the default since round 5): exactly sized outputs, what the reference returns
-        # (main.py:132-138).  The host waits for the plan's result block, sizes the outputs to l_out and only then enqueues
-        # the merge kernel (ff_ctx_merge_wait / _apply): the GPU idles for the host's reaction time between the two
-        # kernels (~10-20 us), nothing is over-allocated, nothing is copied.  False: the merge kernel is enqueued blind, right
-        # behind the plan, into buffers of the INPUT length, and narrow() views of them are returned (a view keeps its whole
-        # buffer alive: 302 MB for a 91 MB result at 64 x 576 x 4096) - the opt-in fast path: no idle gap.  End to end the two
-        # differ by less than +-0.35 % (profiles/r05_e2e_prefill.json).  INTEGRATION.md, "Output buffers".
+        # (main.py:132-138).  They are allocated for the length the top-k branch gives (host arithmetic) while the kernels run
+        # and the merge kernel goes out blind into them, guarded on the device; if the plan decides otherwise the host sizes
+        # them to the l_out it reads from the result block (the one-launch kernel waits for that with the rows in registers,
+        # the three launches repeat the merge kernel).  Nothing is over-allocated, nothing is copied.  False: buffers of the
+        # INPUT length, narrow() views of them are returned (a view keeps its whole buffer alive: 302 MB for a 91 MB result
+        # at 64 x 576 x 4096): never a repeat.  End to end the two differ by less than +-0.35 %
+        # (profiles/r05_e2e_prefill.json).  INTEGRATION.md, "Output buffers".
         self.compact_outputs = compact_outputs
         self._scratch = {}
         self._ptype_gen = 0       # bumped whenever patch_type is (re)assigned: keys the cached by-patch order
@@ -285,6 +286,7 @@ class FrameFusion(nn.Module):
         state["last_call"] = None
         state["_ticket"] = None
         state["_bad_hints"] = dict(self.__dict__.get("_bad_hints", {}))
+        state["_guess_held"] = dict(self.__dict__.get("_guess_held", {}))
         return state
 
     def __deepcopy__(self, memo):
@@ -479,10 +481,17 @@ class FrameFusion(nn.Module):
         sc = st["sc"]
         one = bool(self.one_launch and lib.ff_ctx_merge_one_launch(sc.ctx_ptr, sc.call_ptr))
         guess = st.get("L_guess")
-        if one or (self.compact_outputs and guess is not None and 0 < guess < st["L"]):
+        # Does the guessed length (the top-k branch's) usually come true for THIS call of a prefill?  The threshold branch runs
+        # for every merge call of a prefill but the last, and a blind merge kernel that finds its buffers too short costs a
+        # wasted launch (7.5 us at 37 k tokens) on top of the repeat: a call index whose guess failed in the previous prefill goes
+        # plan -> wait -> outputs -> merge kernel instead (no wasted launch).  The one-launch kernel does not care (second mail).
+        st["guess_idx"] = idx = len(self.sparsity_list)
+        trust = self.__dict__.get("_guess_held", {}).get(idx, True)
+        if one or (self.compact_outputs and guess is not None and 0 < guess < st["L"] and trust):
             # everything goes out in ONE crossing: the one-launch kernel when the activation fits on the chip; else the three
             # launches with the merge kernel blind into outputs of the guessed length (no plan -> host -> merge kernel bubble)
             st["one_launch"] = one
+            st["flow"] = "submit"
             return self._merge_submitted(st)
         rc = lib.ff_ctx_merge_begin(sc.ctx_ptr, sc.call_ptr)
         if rc:
@@ -491,7 +500,9 @@ class FrameFusion(nn.Module):
             # exactly sized outputs (the default) and no length to guess: the plan goes out behind K1, the host waits for l_out,
             # sizes the outputs to it and only then enqueues the merge kernel - no input-length buffers, no copy; the GPU idles
             # for the host's reaction time between the two kernels instead
+            st["flow"] = "wait"
             return self._merge_exact_tail(st)
+        st["flow"] = "finish"
         self._merge_outputs(st)
         # The one device->host hand-off of the call: the plan kernel stores the result block into pinned
         # host memory (sequence word last) BEFORE the merge kernel runs, so the host learns L_out while the
@@ -560,6 +571,12 @@ class FrameFusion(nn.Module):
             self._no_outputs(st, hidden=st["hidden"])       # nothing folds: the launch only clears the select tables
         elif st.get("L_cap") != L and st.get("L_cap") != L_out:
             self._merge_outputs(st, L_out)
+            if sc.res.applied == 2:
+                # the kernel is waiting for exactly these: second mail slot, NOW - every microsecond until it is written is one
+                # the whole chip spends spinning (ff_ctx_merge_apply below would mail them too, after the bookkeeping)
+                rc = lib.ff_ctx_merge_mail(sc.ctx_ptr, sc.call_ptr)
+                if rc:
+                    _fail(rc, "merge")
         # (the host's own bookkeeping of the call comes first: the kernel's answer to the mail is two PCIe round trips away)
         return self._merge_complete(st, 0, confirm=lambda: lib.ff_ctx_merge_apply(sc.ctx_ptr, sc.call_ptr, sc.res_ptr))
 
@@ -756,6 +773,8 @@ class FrameFusion(nn.Module):
         if rc:
             _fail(rc, "merge", err)
         assert nv > 0, "no visual tokens"                                          # main.py:240
+        if st.get("L_guess") is not None and "guess_idx" in st:
+            self.__dict__.setdefault("_guess_held", {})[st["guess_idx"]] = (L_out == st["L_guess"])
 
         def finish():
             # (with `confirm` the library's bookkeeping of the call - the order swap - happens in that crossing)
@@ -784,7 +803,7 @@ class FrameFusion(nn.Module):
             mail_slot = finish()
             self.last_call = dict(kind="merge", L_in=L, L_out=L, nv=nv, ftn=ftn, count=count, branch=branch,
                                   k=k, scratch=sc, dtype=dtype, order=sc.order, wait_ns=wait_ns, unhinted=bool(unhinted),
-                                  one_launch=bool(st.get("one_launch")), applied=int(_applied), mail_slot=mail_slot)
+                                  one_launch=bool(st.get("one_launch")), applied=int(_applied), mail_slot=mail_slot, flow=st.get("flow"))
             sc.order_gen = self._ptype_gen
             if residual is not None:          # nothing folded, but the caller is owed the sum
                 return residual + hidden_states, position_embeddings, attention_mask
@@ -796,7 +815,7 @@ class FrameFusion(nn.Module):
         # (now the context's current one), so the next merge call of this prefill skips K0
         self.last_call = dict(kind="merge", L_in=L, L_out=L_out, nv=nv, ftn=ftn, count=count, branch=branch,
                               k=k, scratch=sc, dtype=dtype, order=sc.order_next, wait_ns=wait_ns, unhinted=bool(unhinted),
-                              one_launch=bool(st.get("one_launch")), applied=int(_applied), mail_slot=mail_slot)
+                              one_launch=bool(st.get("one_launch")), applied=int(_applied), mail_slot=mail_slot, flow=st.get("flow"))
         mask_cap = st["mask_cap"]
         if mask_cap is not None:
             attention_mask = mask_cap[:, :, :L_out, :L_out]

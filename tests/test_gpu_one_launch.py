@@ -120,12 +120,14 @@ def test_outputs_sized_for_the_other_branch_and_no_outputs_at_all():
     F, P, d, pre, post = 64, 195, 3584, 15, 12
     h, pt = video_tokens(F, P, d, p_change=0.5, sigma=0.3, sigma_hi=1.8, seed=77, pre=pre, post=post, grid=0.125)
     L = h.shape[1]
-    fa, fb = pair()
-    for ff in (fa, fb):
-        prepare(ff, dev(pt), P, pre, F * P, L)
     pe = dev(rotary_tables(L, 128, torch.bfloat16, mrope=True))
-    same_call(fa, fb, dev(h), pe)
-    assert fa.last_call["branch"] == 0 and fa.last_call["applied"] == 2 and fa.last_call["mail_slot"] == 2    # guessed the top-k length, got the threshold set
+    for rep in range(2):            # (the first pass may find the caching allocator cold: a hipMalloc of 46 MB behind the result
+        fa, fb = pair()             #  block can take longer than the kernel waits - it then gets the merge kernel instead, slot 3)
+        for ff in (fa, fb):
+            prepare(ff, dev(pt), P, pre, F * P, L)
+        same_call(fa, fb, dev(h), pe)
+        assert fa.last_call["branch"] == 0 and fa.last_call["applied"] == 2 and fa.last_call["mail_slot"] in (2, 3)
+    assert fa.last_call["branch"] == 0 and fa.last_call["applied"] == 2 and fa.last_call["mail_slot"] == 2, {k: fa.last_call[k] for k in ("branch", "applied", "mail_slot", "flow", "wait_ns")}    # guessed the top-k length, got the threshold set
     # no guess: prepare() scalars that do not describe whole frames -> K0 path for the first call (three launches), the second
     # call is order-maintained and goes out as one launch without a length to allocate for
     fa, fb = pair()
@@ -271,3 +273,32 @@ def test_barrier_words_survive_many_calls_of_changing_size():
             prepare(ff, dev(pt), P, pre, F * P, L)
         same_call(fa, fb, dev(h), dev(torch.arange(L)[None]))
     assert not fa.last_call["scratch"].dirty
+
+
+def test_a_guess_that_failed_for_a_call_index_is_not_repeated_in_the_next_prefill():
+    """Three launches, exactly sized outputs, threshold branch: the first prefill guesses the top-k length for its first merge call,
+    the blind merge kernel writes nothing (applied = 0) and is repeated; the next prefill of the instance sends the same call index
+    through plan -> wait -> outputs -> merge kernel (no wasted launch) - same bits either way, and a call whose guess held keeps
+    guessing."""
+    F, P, d, pre, post = 16, 48, 512, 3, 5
+    h, pt = video_tokens(F, P, d, p_change=0.5, sigma=0.3, sigma_hi=1.8, seed=9, pre=pre, post=post, grid=0.125, dtype=torch.float16)
+    L = h.shape[1]
+    ff = ffa.FrameFusion()
+    pe = dev(rotary_tables(L, 64, torch.float16))
+    outs = []
+    for rep in range(3):
+        prepare(ff, dev(pt), P, pre, F * P, L)
+        o, _, _ = ff(dev(h), [t.clone() for t in pe], None)
+        assert not ff.last_call["one_launch"] and ff.last_call["branch"] == 0 and ff.last_call["L_out"] < L
+        assert ff.last_call["flow"] == ("submit" if rep == 0 else "wait"), (rep, ff.last_call["flow"])
+        outs.append(o.cpu())
+    assert same_bits(outs[0], outs[1]) and same_bits(outs[0], outs[2])
+    # the top-k branch on the same instance: index 0 is distrusted once, found right, trusted again
+    h2, _ = video_tokens(F, P, d, p_change=0.1, sigma=0.3, seed=10, pre=pre, post=post, grid=0.125, dtype=torch.float16)
+    flows = []
+    for rep in range(3):
+        prepare(ff, dev(pt), P, pre, F * P, L)
+        ff(dev(h2), [t.clone() for t in pe], None)
+        assert ff.last_call["branch"] == 1
+        flows.append(ff.last_call["flow"])
+    assert flows == ["wait", "submit", "submit"], flows
