@@ -302,3 +302,49 @@ def test_a_guess_that_failed_for_a_call_index_is_not_repeated_in_the_next_prefil
         assert ff.last_call["branch"] == 1
         flows.append(ff.last_call["flow"])
     assert flows == ["wait", "submit", "submit"], flows
+
+
+@pytest.mark.parametrize("case", ["k_exceeds_the_real_similarities", "threshold_below_ignore_token", "all_rows_equal", "nan_rows"])
+def test_edge_cases_of_the_early_result(case):
+    """The result block leaves before the plan has run: l_out = L - k + [k > real similarities] on the top-k branch (slot 0, the first
+    of the IGNORE_TOKEN ties, never folds), L - count - [threshold below IGNORE_TOKEN] on the threshold branch.  The corners of that
+    arithmetic, against the three launches (which count the members they actually take) - a disagreement would also trip the
+    kernel's own assertion (FF_ERR_BIT_RESIDENT on the next call)."""
+    cost, thr = 0.3, 0.6
+    if case == "k_exceeds_the_real_similarities":
+        F, P, d = 2, 64, 256                     # 64 real similarities, k = int(0.7 * 128) = 89: 25 IGNORE_TOKEN slots are taken
+        h, pt = video_tokens(F, P, d, p_change=0.0, sigma=0.05, seed=4, pre=2, post=3, grid=0.125)
+    elif case == "threshold_below_ignore_token":
+        F, P, d = 6, 48, 256
+        cost, thr = 0.9, -3.0                    # every slot is in the threshold set; budget large enough for the threshold branch
+        h, pt = video_tokens(F, P, d, p_change=0.5, sigma=0.3, seed=5, pre=1, post=1, grid=0.125)
+    elif case == "all_rows_equal":
+        F, P, d = 8, 40, 256                     # every real similarity is exactly 1: one tie class, cut by position
+        h, pt = video_tokens(F, P, d, p_change=0.0, sigma=0.0, seed=6, pre=0, post=0, grid=0.125)
+        h[:] = h[:, :1]
+    else:
+        F, P, d = 8, 40, 256
+        h, pt = video_tokens(F, P, d, p_change=0.3, sigma=0.3, seed=7, pre=3, post=2, grid=0.125)
+        h[0, 3 + 5 * P + 7, 11] = float("nan")   # two similarities become NaN (largest key: taken first by top-k, never by threshold)
+    L = h.shape[1]
+    fa, fb = pair(cost, thr, 0.1)
+    for ff in (fa, fb):
+        prepare(ff, dev(pt), P, int((pt[0] == -1).long().argmin()), F * P, L)
+    pe = dev(rotary_tables(L, 32, torch.bfloat16))
+    pa, pb = [t.clone() for t in pe], [t.clone() for t in pe]
+    oa, _, _ = fa(dev(h), pa, None)
+    ob, _, _ = fb(dev(h), pb, None)
+    assert fa.last_call["one_launch"] and not fb.last_call["one_launch"]
+    for key in ("L_out", "count", "branch", "k", "nv", "ftn"):
+        assert fa.last_call[key] == fb.last_call[key], (case, key, fa.last_call[key], fb.last_call[key])
+    assert oa.shape == ob.shape
+    if case != "nan_rows":
+        assert same_bits(oa.cpu(), ob.cpu())
+    else:
+        a, b = oa.cpu().view(torch.int16), ob.cpu().view(torch.int16)
+        nan = torch.isnan(oa.cpu().float()) | torch.isnan(ob.cpu().float())
+        assert torch.equal(a[~nan], b[~nan]) and torch.equal(torch.isnan(oa.cpu().float()), torch.isnan(ob.cpu().float()))
+    assert torch.equal(fa.patch_type, fb.patch_type)
+    # ... and the kernel's own assertion stayed quiet: the next call of the instance goes through
+    prepare(fa, dev(pt), P, int((pt[0] == -1).long().argmin()), F * P, L)
+    fa(dev(h), [t.clone() for t in pe], None)
