@@ -293,9 +293,9 @@ typedef struct ff_merge_result {
  * mail:    outputs of a late_outputs submit: plain stores of {4 seq + slot, hidden_out, L_cap, n_aux, aux[]} into the pinned
  *          block (two slots of FF_MAIL_WORDS words from FF_MAIL_WORD on; each written once per call), no HIP call; one wave of
  *          the kernel relays them into device memory.  The auxiliary tensors travel whole (sources too): the kernel needs them
- *          only behind its plan, so the host describes them AFTER the launch.  Slot 1 = outputs that exist before the result does (L rows, or a guessed
- *          length): mailed between submit and collect, taken if they hold exactly l_out rows or a whole input.  Slot 2 = outputs
- *          sized to the result (state 3*, ctx->res_active == 3).
+ *          only behind its plan, so the host describes them AFTER the launch.  Slot 1 = outputs that exist before the result
+ *          does (L rows, or a guessed length): mailed between submit and collect, taken if they hold exactly l_out rows or a
+ *          whole input.  Slot 2 = outputs sized to the result (state 3*, ctx->res_active == 3).
  * collect: the wait + bookkeeping of a submitted call (layout retry, give-up retry, mask gather, order swap).  The one-launch
  *          kernel publishes the result block right behind its grid barrier (the barrier carries the two counts that decide
  *          the branch and l_out), ~12 us before its plan is through, and then WAITS for outputs by mail, rows in hand:
@@ -309,7 +309,8 @@ int ff_ctx_merge_wait(ff_ctx_t* ctx, const ff_merge_call_t* call, ff_merge_resul
 int ff_ctx_merge_apply(ff_ctx_t* ctx, const ff_merge_call_t* call, const ff_merge_result_t* result);
 int ff_ctx_merge_submit(ff_ctx_t* ctx, const ff_merge_call_t* call);
 int ff_ctx_merge_collect(ff_ctx_t* ctx, const ff_merge_call_t* call, ff_merge_result_t* result);
-/* pinned block: FF_STAT_WORDS words the device writes + two mail slots of FF_MAIL_WORDS words the host writes:
+/* pinned block (ctx->stats_host, FF_HOST_WORDS words): the first FF_MAIL_WORD words are the device's (result block,
+ * FF_STAT_ACK), then two mail slots of FF_MAIL_WORDS words the host writes:
  * {4 seq + slot, hidden_out, L_cap, n_aux, aux[FF_MAX_AUX] as ff_aux_t} */
 enum { FF_MAIL_WORD = 16, FF_MAIL_WORDS = 24, FF_MAIL_SLOTS = 2, FF_HOST_WORDS = 64 };
 int ff_ctx_merge_mail(ff_ctx_t* ctx, const ff_merge_call_t* call);
