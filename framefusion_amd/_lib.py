@@ -33,6 +33,7 @@ STAT_ACK = 13               # pinned block: 4 * seq + the mail slot the one-laun
 MAIL_WORD, MAIL_WORDS, MAIL_SLOTS, HOST_WORDS = 16, 24, 2, 64       # pinned words 16..63: the two mail slots of a late_outputs call
 MAX_AUX = 4
 ABI_VERSION = 11
+ERR_ARG = -1
 ERR_DEVICE, ERR_STATE = -5, -6
 
 

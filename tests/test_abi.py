@@ -278,3 +278,68 @@ def test_every_illegal_transition_is_refused_and_changes_nothing():
     assert lib.ff_ctx_merge_mail(a(ctx), a(call)) == 0 and host[_lib.MAIL_WORD] == 7 * 4 + 1 and host[_lib.MAIL_WORD + 2] == 100
     assert lib.ff_ctx_merge_mail(a(ctx), a(call)) == 0 and host[_lib.MAIL_WORD + _lib.MAIL_WORDS] == 7 * 4 + 2
     assert lib.ff_ctx_merge_mail(a(ctx), a(call)) == _lib.ERR_STATE
+
+
+def test_apply_in_the_waiting_kernel_state_mails_and_confirms_without_a_device():
+    """State 3* (collect returned applied = 2: a one-launch kernel waits for outputs by mail).  ff_ctx_merge_apply is pure host work
+    until the kernel's acknowledgement is in: which slot it writes, which mail counts as sent (slot 1 only if it holds EXACTLY l_out
+    rows or a whole input), that the call block must name the mailed buffers - checked here with the acknowledgement pre-written
+    into the pinned block, so no HIP call is ever made."""
+    lib = _lib.load()
+    a = C.addressof
+    L, l_out, seq = 512, 100, 7
+
+    def fresh():
+        ctx, call, res = _lib.FFCtx(), _lib.FFMergeCall(), _lib.FFMergeResult()
+        for f in ("order", "order_next", "inv", "inv_next", "sim", "member", "dst", "keep", "stats", "ws"):
+            setattr(ctx, f, 4096 + 64 * len(f))
+        host = (C.c_int64 * _lib.HOST_WORDS)()
+        ctx.stats_host = C.addressof(host)
+        ctx.cap, ctx.ws_bytes = 1024, lib.ff_workspace_bytes(1024, 1)
+        ctx.in_flight, ctx.res_active, ctx.seq, ctx.dirty = 3, 3, seq, 1
+        host[_lib.STAT_LOUT] = l_out
+        call.L, call.d, call.dtype, call.patch_num, call.fold, call.force_k = L, 64, _lib.FF_BF16, 8, _lib.FOLD_SEQUENTIAL, -1
+        call.hidden = call.patch_type = 4096
+        res.l_out, res.nv, res.ftn = l_out, 400, 400
+        return ctx, call, res, host
+
+    M, W = _lib.MAIL_WORD, _lib.MAIL_WORDS
+    # nothing mailed yet: apply writes slot 1 itself and takes the kernel's word for it
+    ctx, call, res, host = fresh()
+    call.hidden_out, call.L_cap = 0x10000, l_out
+    host[_lib.STAT_ACK] = seq * 4 + 1
+    order, order_next = ctx.order, ctx.order_next
+    assert lib.ff_ctx_merge_apply(a(ctx), a(call), a(res)) == 0
+    assert host[M] == seq * 4 + 1 and host[M + 1] == 0x10000 and host[M + 2] == l_out
+    assert (ctx.in_flight, ctx.res_active, ctx.dirty, ctx.order_len) == (0, 0, 0, l_out)
+    assert (ctx.order, ctx.order_next) == (order_next, order)               # the order swap of a call that folded
+    assert (ctx.cur_nv, ctx.cur_ftn) == (400 - (L - l_out), 400 - (L - l_out))
+    # a guess of another length sits in slot 1: it does not count, the exact outputs go into slot 2
+    ctx, call, res, host = fresh()
+    call.hidden_out, call.L_cap = 0x20000, l_out + 30
+    assert lib.ff_ctx_merge_mail(a(ctx), a(call)) == 0 and host[M] == seq * 4 + 1
+    call.hidden_out, call.L_cap = 0x30000, l_out
+    host[_lib.STAT_ACK] = seq * 4 + 2
+    assert lib.ff_ctx_merge_apply(a(ctx), a(call), a(res)) == 0
+    assert host[M + W] == seq * 4 + 2 and host[M + W + 1] == 0x30000 and host[M + W + 2] == l_out and ctx.in_flight == 0
+    # the guess came true (slot 1 holds exactly l_out rows): nothing more is mailed, but the call block must name THOSE buffers
+    ctx, call, res, host = fresh()
+    call.hidden_out, call.L_cap = 0x20000, l_out
+    assert lib.ff_ctx_merge_mail(a(ctx), a(call)) == 0
+    call.hidden_out = 0x50000
+    assert lib.ff_ctx_merge_apply(a(ctx), a(call), a(res)) == _lib.ERR_ARG and ctx.in_flight == 3 and host[M + W] == 0
+    call.hidden_out = 0x20000
+    host[_lib.STAT_ACK] = seq * 4 + 1
+    assert lib.ff_ctx_merge_apply(a(ctx), a(call), a(res)) == 0 and host[M + W] == 0 and ctx.in_flight == 0
+    # input-length buffers in slot 1 (the view form) hold any result
+    ctx, call, res, host = fresh()
+    call.hidden_out, call.L_cap = 0x20000, L
+    assert lib.ff_ctx_merge_mail(a(ctx), a(call)) == 0
+    host[_lib.STAT_ACK] = seq * 4 + 1
+    assert lib.ff_ctx_merge_apply(a(ctx), a(call), a(res)) == 0 and host[M + W] == 0
+    # outputs that do not hold the result, or a result that is not this call's: refused, nothing changes
+    ctx, call, res, host = fresh()
+    call.hidden_out, call.L_cap = 0x20000, l_out - 1
+    assert lib.ff_ctx_merge_apply(a(ctx), a(call), a(res)) == _lib.ERR_ARG and ctx.in_flight == 3 and host[M] == 0
+    call.L_cap, res.l_out = l_out, l_out + 1
+    assert lib.ff_ctx_merge_apply(a(ctx), a(call), a(res)) == _lib.ERR_ARG and ctx.in_flight == 3
