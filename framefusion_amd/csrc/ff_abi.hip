@@ -469,7 +469,8 @@ static bool ctx_resident(const ff_ctx_t* c, const ff_merge_call_t* a, int64_t* n
     *hinted = hint;
     if (a->fold != FF_FOLD_SEQUENTIAL || a->n_aux < 0 || a->n_aux > FF_MAX_AUX) return false;
     if (((uintptr_t)a->hidden & 15) || ((uintptr_t)a->hidden_out & 15) || !a->hidden || !a->patch_type) return false;
-    return ff::merge_resident_fits((int)a->dtype, a->L, a->d, *nv, a->addend != nullptr, (int)a->fold);
+    if ((uintptr_t)a->addend & 15) return false;
+    return ff::merge_resident_fits((int)a->dtype, a->L, a->d, *nv, a->addend != nullptr, hint, (int)a->fold);
 }
 
 extern "C" int ff_ctx_merge_one_launch(const ff_ctx_t* c, const ff_merge_call_t* a) {
@@ -521,7 +522,7 @@ extern "C" int ff_ctx_merge_submit(ff_ctx_t* c, const ff_merge_call_t* a) {
     c->seq += 1;
     c->dirty = 1;                // until the kernel is known to have cleared the select tables (collect) / the merge kernel is enqueued (apply)
     ff::ResLaunch p;
-    p.hidden = a->hidden; p.hidden_out = a->hidden_out; p.dtype = (int)a->dtype; p.L = a->L; p.d = a->d; p.L_cap = a->L_cap;
+    p.hidden = a->hidden; p.addend = a->addend; p.hidden_out = a->hidden_out; p.dtype = (int)a->dtype; p.L = a->L; p.d = a->d; p.L_cap = a->L_cap;
     p.nv = nv; p.ftn = ftn; p.ptype = a->patch_type; p.order = c->order; p.inv = c->inv;
     p.hint_pre = a->hint_pre; p.hint_patches = a->patch_num; p.hint_frames = order_valid ? 0 : a->hint_frames;
     p.sim = c->sim; p.member = c->member; p.keep = c->keep; p.dst = c->dst; p.order_next = c->order_next; p.inv_next = c->inv_next;

@@ -7,6 +7,7 @@ namespace ff {
 
 struct ResLaunch {
     const void* hidden;
+    const void* addend;           // optional: the rows are T(hidden + addend); only with a maintained order (no layout hint)
     void* hidden_out;             // NULL: plan only
     int dtype;
     int64_t L, d, L_cap;
@@ -34,7 +35,7 @@ struct ResLaunch {
 };
 
 // Does a merge call of this shape run as the one-launch kernel?  `nv`: visual tokens as the host knows them (<= 0: unknown).
-bool merge_resident_fits(int dtype, int64_t L, int64_t d, int64_t nv, bool addend, int fold);
+bool merge_resident_fits(int dtype, int64_t L, int64_t d, int64_t nv, bool addend, bool hinted, int fold);
 int launch_merge_resident(const ResLaunch& p, hipStream_t st);
 
 }  // namespace ff

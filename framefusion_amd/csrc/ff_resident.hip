@@ -74,6 +74,7 @@ static_assert(sizeof(ResBar) <= 4096, "ff_plan.hip reserves 4 KB of the workspac
 
 struct ResArgs {
     const char* hidden;
+    const char* addend;           // kAdd: the rows are T(hidden + addend) (the decoder's residual add, modeling_qwen2.py:64-67)
     char* out;                    // NULL: plan only
     uint32_t row_bytes;
     int nt;                       // 1 KiB column tiles per row = data waves
@@ -219,8 +220,9 @@ struct ResLds {
 };
 __host__ __device__ constexpr size_t res_lds_bytes(int nt) { return ResLds::rows + (size_t)kResRL * nt * 1024; }
 
-template <int DT, bool kHint>
+template <int DT, bool kHint, bool kAdd>
 __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a) {
+    static_assert(!(kHint && kAdd), "rows that are sums (a fused residual add) come with a maintained order: call B follows call A");
     using A = Act<DT>;
     static_assert(A::kBytes == 2, "16-bit activations");
     constexpr int E = 8, RV = kResRV, RL = kResRL;
@@ -330,14 +332,16 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
         if constexpr (kHint) prev_off = (uint32_t)pos_hint(s0 > 0 ? s0 - 1 : 0) * rb;
         else prev_off = (uint32_t)__builtin_amdgcn_readlane(ordw, 0) * rb;
         u32x4 prevv;
-        buf_load16_uncounted(prevv, hraw, vcol, prev_off);
+        if constexpr (!kAdd) buf_load16_uncounted(prevv, hraw, vcol, prev_off);
         // every wave issues exactly 1 + RL + RV requests (rows past n: an out-of-range offset, answered with zeros without
         // traffic), so that the hand-counted waits below hold for every segment length
+        if constexpr (!kAdd) {
 #pragma unroll
-        for (int i = 0; i < RL; ++i) {
-            const uint32_t lds = (uint32_t)(uintptr_t)(lrows + ((size_t)i * nt + wv) * 1024);
-            if (i < n) buf_load16_lds(hraw, vcol, row_off(i), lds);
-            else buf_load16_lds(hraw, kDead, 0u, lds);
+            for (int i = 0; i < RL; ++i) {
+                const uint32_t lds = (uint32_t)(uintptr_t)(lrows + ((size_t)i * nt + wv) * 1024);
+                if (i < n) buf_load16_lds(hraw, vcol, row_off(i), lds);
+                else buf_load16_lds(hraw, kDead, 0u, lds);
+            }
         }
         float lastf[E];                                      // bf16: the previous row, unpacked
         uint4 lastw = make_uint4(0, 0, 0, 0);                // fp16: the previous row, raw (packed multiply)
@@ -361,6 +365,49 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
             wave_sum4_dpp63(qa, da, qb, db);
             if (lane == 63) { part[(i + 1) * kResWaves + wv] = make_float2(qa, da); part[(i + 2) * kResWaves + wv] = make_float2(qb, db); }
         };
+        if constexpr (kAdd) {
+            // Rows that are SUMS, T(hidden + addend): two requests per row, kW rows in flight, everything through registers
+            // the compiler counts (no LDS-DMA: the raw halves would have to meet in LDS).  The addend halves wait in ta[], the
+            // hidden halves of the rows whose home is LDS in th[] - those of the VGPR rows arrive in their home registers, which
+            // are free until then; a row's sum goes home (LDS / its registers) and into the norms and dots at once.
+            constexpr int kW = 8;
+            static_assert(kW <= RL && RL % kW == 0, "the first window is LDS-home rows only");
+            const __amdgpu_buffer_rsrc_t ares = make_rsrc(a.addend, (uint32_t)L * rb);
+            uint4 th[kW], ta[kW];
+            const uint4 ph = buf_load16s(hres, vcol, prev_off), pa = buf_load16s(ares, vcol, prev_off);
+#pragma unroll
+            for (int w = 0; w < kW; ++w) {
+                const uint32_t vo = w < n ? vcol : kDead, so = w < n ? row_off(w) : 0u;
+                th[w] = buf_load16s(hres, vo, so);
+                ta[w] = buf_load16s(ares, vo, so);
+            }
+            {
+                const uint4 prev = add16<DT>(ph, pa);
+                if constexpr (DT == FF_BF16) A::unpack(prev, lastf);
+                else lastw = prev;
+                float q0 = A::sumsq(prev, 0.f), z0 = 0.f, z1 = 0.f, z2 = 0.f;
+                wave_sum4_dpp63(q0, z0, z1, z2);
+                if (lane == 63) part[wv] = make_float2(q0, 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < RL + RV; i += 2) {
+                uint4 x[2];
+#pragma unroll
+                for (int z = 0; z < 2; ++z) {
+                    const int r = i + z;
+                    if (r < RL) { x[z] = add16<DT>(th[r % kW], ta[r % kW]); *lrow(r) = x[z]; }
+                    else { v[r - RL] = add16<DT>(v[r - RL], ta[r % kW]); x[z] = v[r - RL]; }
+                    const int q = r + kW;                    // the row that takes the places just freed
+                    if (q < RL + RV) {
+                        const uint32_t vo = q < n ? vcol : kDead, so = q < n ? row_off(q) : 0u;
+                        if (q < RL) th[q % kW] = buf_load16s(hres, vo, so);
+                        else v[q - RL] = buf_load16s(hres, vo, so);
+                        ta[q % kW] = buf_load16s(ares, vo, so);
+                    }
+                }
+                if (i < n) two(x[0], x[1], i);
+            }
+        } else {
         // LDS rows i, i + 1: first request the VGPR rows that take their place in the window, then wait until at most RL
         // requests are outstanding - the LDS-DMA rows behind these two plus the VGPR rows requested so far
 #pragma unroll
@@ -386,6 +433,7 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
             if (i + RL < RV) { if (RL + i + RL < n) v[i + RL] = buf_load16s(hres, vcol, row_off(RL + i + RL)); else v[i + RL] = buf_load16s(hres, kDead, 0u); }
             if (i + RL + 1 < RV) { if (RL + i + RL + 1 < n) v[i + RL + 1] = buf_load16s(hres, vcol, row_off(RL + i + RL + 1)); else v[i + RL + 1] = buf_load16s(hres, kDead, 0u); }
             if (RL + i < n) two(v[i], v[i + 1], RL + i);
+        }
         }
         __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0): every row is on chip (and the compiler knows it)
     }
@@ -1052,7 +1100,7 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
         // LDS-DMA into the LDS rows just folded, and arrive under the fold of the VGPR rows: fetched behind the fold, two per
         // round trip, they were the kernel's tail (up to 10 us at the 7B layout).
         int pre_run = 0;
-        {
+        if constexpr (!kAdd) {                               // (sums: both halves through registers, in the loop further down)
             const int tt = s1 + lane;
             const bool mb = tt < nv && slotbit(tt);
             const unsigned long long mw = __ballot(mb);
@@ -1083,7 +1131,7 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
                 ++open_n;
             }
             // (a run of more than kResRL rows behind my segment: the rest eight at a time)
-            for (int t = s1 + pre_run; pre_run == RL && t < nv;) {
+            for (int t = s1 + pre_run; (kAdd || pre_run == RL) && t < nv;) {
                 const int tt = t + lane;
                 const bool mb = tt < nv && slotbit(tt);
                 const unsigned long long mw = __ballot(mb);
@@ -1095,14 +1143,20 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
                 }
                 constexpr int kB = 8;                        // rows in flight (the VGPR rows are folded: their registers are free)
                 for (int u = 0; u < run; u += kB) {
-                    uint4 x[kB];
+                    uint4 x[kB], xa[kAdd ? kB : 1];
 #pragma unroll
-                    for (int z = 0; z < kB; ++z)
-                        if (u + z < run) x[z] = buf_load16s(hres, vcol, (uint32_t)__builtin_amdgcn_readlane(iw, u + z) * rb);
+                    for (int z = 0; z < kB; ++z) {
+                        if (u + z < run) {
+                            const uint32_t so = (uint32_t)__builtin_amdgcn_readlane(iw, u + z) * rb;
+                            x[z] = buf_load16s(hres, vcol, so);
+                            if constexpr (kAdd) xa[z] = buf_load16s(make_rsrc(a.addend, (uint32_t)L * rb), vcol, so);
+                        }
+                    }
 #pragma unroll
                     for (int z = 0; z < kB; ++z) {
                         if (u + z < run) {
                             float y[E];
+                            if constexpr (kAdd) x[z] = add16<DT>(x[z], xa[z]);
                             A::unpack(x[z], y);
 #pragma unroll
                             for (int e = 0; e < E; ++e) acc[e] = A::rnd(acc[e] + y[e]);
@@ -1122,7 +1176,8 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
             int i;
             if constexpr (kHint) i = qq < pre ? qq : qq + nv;
             else i = a.order[nv + qq];
-            const uint4 x = buf_load16s<2>(hres, vcol, (uint32_t)i * rb);
+            uint4 x = buf_load16s<2>(hres, vcol, (uint32_t)i * rb);
+            if constexpr (kAdd) x = add16<DT>(x, buf_load16s<2>(make_rsrc(a.addend, (uint32_t)L * rb), vcol, (uint32_t)i * rb));
             buf_store16s<2>(ores, vcol, (uint32_t)(i - members_before_pos(i)) * rb, x);
         }
     }
@@ -1194,10 +1249,11 @@ static int res_cus() {
 }
 
 // Does a merge call of this shape run as the one-launch kernel?  `nv`: visual tokens as the host knows them (<= 0: unknown).
-bool merge_resident_fits(int dtype, int64_t L, int64_t d, int64_t nv, bool addend, int fold) {
+bool merge_resident_fits(int dtype, int64_t L, int64_t d, int64_t nv, bool addend, bool hinted, int fold) {
     // (bf16 only: the fp16 fold keeps its eight IEEE divisions per flush - ff_merge_body.h - and does not fit next to 160 pinned VGPRs)
     if (dtype != FF_BF16) return false;
-    if (addend || fold != FF_FOLD_SEQUENTIAL) return false;
+    // (rows that are sums - the fused residual add of call B - come with a maintained order: call B follows call A)
+    if ((addend && hinted) || fold != FF_FOLD_SEQUENTIAL) return false;
     const int64_t rb = d * 2;
     if (rb < 16 || rb > 8 * 1024 || (rb & 15)) return false;
     if (nv < 1 || nv > kResMaxNv || nv > L || L > kResMaxL) return false;
@@ -1211,18 +1267,18 @@ ResBar* ws_resbar(void* ws);
 
 PlanParams merge_plan_params(int dtype, double thr, double sub, double ratio_lb, long long force_k);
 
-template <int DT, bool kHint>
+template <int DT, bool kHint, bool kAdd>
 static int launch_res(const ResArgs& a, int cus, hipStream_t st) {
     static std::atomic<bool> attr_set[kMaxDevices];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = -1;
     if (dev < 0 || !attr_set[dev].load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_merge_resident<DT, kHint>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute((const void*)k_merge_resident<DT, kHint, kAdd>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)res_lds_bytes(8));
         if (e != hipSuccess) return (int)e;
         if (dev >= 0) attr_set[dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((k_merge_resident<DT, kHint>), dim3((unsigned)cus), dim3(kResThreads), res_lds_bytes(a.nt), st, a);
+    hipLaunchKernelGGL((k_merge_resident<DT, kHint, kAdd>), dim3((unsigned)cus), dim3(kResThreads), res_lds_bytes(a.nt), st, a);
     return (int)hipGetLastError();
 }
 
@@ -1231,6 +1287,7 @@ int launch_merge_resident(const ResLaunch& p, hipStream_t st) {
     if (cus < 8) return FF_ERR_UNSUPPORTED;
     ResArgs a;
     a.hidden = (const char*)p.hidden;
+    a.addend = (const char*)p.addend;
     a.out = (char*)p.hidden_out;
     a.row_bytes = (uint32_t)(p.d * 2);
     a.nt = (int)((p.d * 2 + 1023) / 1024);
@@ -1253,7 +1310,8 @@ int launch_merge_resident(const ResLaunch& p, hipStream_t st) {
     a.bar = ws_resbar(p.ws);
     a.mail = p.mail;
     const bool hint = p.hint_frames > 0;
-    return hint ? launch_res<FF_BF16, true>(a, cus, st) : launch_res<FF_BF16, false>(a, cus, st);
+    if (hint) return p.addend ? FF_ERR_UNSUPPORTED : launch_res<FF_BF16, true, false>(a, cus, st);
+    return p.addend ? launch_res<FF_BF16, false, true>(a, cus, st) : launch_res<FF_BF16, false, false>(a, cus, st);
 }
 
 }  // namespace ff

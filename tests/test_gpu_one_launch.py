@@ -33,12 +33,13 @@ def prepare(ff, pt, P, pre, nvis, L):
     ff.prepare(pt, P, pre, pre + nvis, nvis, L)
 
 
-def same_call(fa, fb, h, pe, expect_one_launch=True):
-    """One forward call through both instances; compares everything the call leaves behind."""
+def same_call(fa, fb, h, pe, expect_one_launch=True, residual=None):
+    """One forward call through both instances; compares everything the call leaves behind.  `residual`: call B of a decoder
+    layer with the add fused in (the rows are T(h + residual))."""
     pa = [t.clone() for t in pe] if isinstance(pe, list) else pe.clone()
     pb = [t.clone() for t in pe] if isinstance(pe, list) else pe.clone()
-    oa, qa, _ = fa(h, pa, None)
-    ob, qb, _ = fb(h, pb, None)
+    oa, qa, _ = fa(h, pa, None, None, residual=residual)
+    ob, qb, _ = fb(h, pb, None, None, residual=residual)
     assert fa.last_call["one_launch"] == expect_one_launch and not fb.last_call["one_launch"]
     assert oa.shape == ob.shape and same_bits(oa.cpu(), ob.cpu())
     if isinstance(qa, list):
@@ -348,3 +349,32 @@ def test_edge_cases_of_the_early_result(case):
     # ... and the kernel's own assertion stayed quiet: the next call of the instance goes through
     prepare(fa, dev(pt), P, int((pt[0] == -1).long().argmin()), F * P, L)
     fa(dev(h), [t.clone() for t in pe], None)
+
+
+@pytest.mark.parametrize("shape", [(64, 210, 3584, 14, 20, 0.5), (64, 195, 3584, 15, 12, 0.6), (24, 576, 4096, 3, 5, 0.5), (40, 130, 3000, 300, 500, 0.5),
+                                   (64, 224, 1024, 0, 0, 0.6)],
+                         ids=lambda s: f"{s[0]}x{s[1]}x{s[2]}")
+@pytest.mark.parametrize("mrope", [False, True])
+def test_call_b_with_the_residual_add_fused_in(shape, mrope):
+    """Call A (no residual, layout hint) and then call B of every layer with the decoder's residual add fused in (rows = T(hidden +
+    residual), modeling_qwen2.py:64-67): call B comes with the order call A left behind and goes out as the one-launch kernel whose
+    rows are sums - two requests per row, through registers - against the three launches, bit for bit."""
+    F, P, d, pre, post, p_change = shape
+    h, pt = video_tokens(F, P, d, p_change=p_change, sigma=0.3, sigma_hi=1.6, seed=F + P + d, pre=pre, post=post, grid=0.125)
+    L = h.shape[1]
+    fa, fb = pair(0.3, 0.6, 0.02)
+    for ff in (fa, fb):
+        prepare(ff, dev(pt), P, pre, F * P, L)
+    hd, pe = dev(h), dev(rotary_tables(L, 64, torch.bfloat16, mrope=mrope))
+    hd, pe = same_call(fa, fb, hd, pe)                                   # call A
+    layer, fused = 0, 0
+    gen = torch.Generator().manual_seed(11)
+    while not fa.finish_merging and layer < 5:
+        attn_out = dev((torch.randint(-8, 9, tuple(hd.shape), generator=gen).float() * 0.125).to(torch.bfloat16))
+        before = hd.shape[1]
+        hd, pe = same_call(fa, fb, attn_out, pe, residual=hd)            # call B: T(attn_out + residual)
+        fused += 1
+        assert fa.last_call["L_in"] == before
+        hd = dev(harness.layer_stub(hd.cpu(), layer))
+        layer += 1
+    assert fused >= 1
