@@ -29,6 +29,9 @@
 //      fold when there are at most three (tensor, slice) pairs, else handed out by an LDS counter, the wave without rows first),
 //      member / keep / dst, next order + inverse.
 //
+// A third instance (kAdd) takes call B of a decoder layer with the residual add fused in: its rows are the sums T(hidden + addend),
+// two requests per row through registers the compiler counts (phase A below); everything behind phase A sees resident sums.
+//
 // Measured (tools/flow_stamps.py --wg on a library built with EXTRA=-DFF_RES_WGSTAMPS: first workgroup start -> last workgroup
 // end on the device clock; rocprofv3's kernel duration includes the wait for the host's mail, and its tracing slows the host):
 // 53-61 us at the 7B layout (13 474 -> 4 066) against 57.7 us for the three launches; the host sees the result 22 us after

@@ -286,8 +286,9 @@ typedef struct ff_merge_result {
  *          device and writes nothing unless the plan's l_out is exactly L_cap - collect then reports applied = 0 and apply
  *          repeats it into buffers of l_out rows.  When the activation fits into the chip's registers + LDS
  *          (ff_ctx_merge_one_launch: bf16, rows <= 8 KiB, <= 56 visual tokens per CU, by-patch order known to the host from
- *          the hint or the previous call - the LLaVA-Video-7B / Qwen2-VL-7B prefills of 90-96 MB) "the whole call" is ONE
- *          kernel that reads every row ONCE (csrc/ff_resident.hip); same results bit for bit; hidden_out = NULL = plan only.
+ *          the hint or the previous call, an `addend` only with the previous call's order - the LLaVA-Video-7B / Qwen2-VL-7B
+ *          prefills of 90-96 MB) "the whole call" is ONE kernel that reads every row ONCE (csrc/ff_resident.hip); same results
+ *          bit for bit; hidden_out = NULL = plan only.
  *          Two such kernels side by side wait for each other's CUs until one gives up (~2 ms, repeated as three launches):
  *          an owner with two samples in flight sets ctx->res_off > 1 on both contexts.
  * mail:    outputs of a late_outputs submit: plain stores of {4 seq + slot, hidden_out, L_cap, n_aux, aux[]} into the pinned

@@ -24,6 +24,10 @@ python tools/kernel_fractions.py "$tag" > "$out/${tag}_kernel_fractions.txt" 2> 
   echo
   echo "# the same through the three launches"
   python tools/flow_stamps.py --three 2>&1 | grep -v amdgpu.ids
+  echo
+  echo "# tools/flow_residual.py: call A + call B (the decoder's residual add fused in) of one prefill, back to back"
+  python tools/flow_residual.py --config 7b 2>&1 | grep -v amdgpu.ids
+  python tools/flow_residual.py --config c3 2>&1 | grep -v amdgpu.ids
 } > "$out/${tag}_flow.txt"
 # device time of the one-launch kernel without the tracer: per-workgroup stamps (a library built with -DFF_RES_WGSTAMPS, then the
 # product build again)
