@@ -296,6 +296,7 @@ def main():
             assert step().shape[1] == L_out and step().untyped_storage().nbytes() == L_out * d * hidden.element_size()
             result["extra"] = {"packer_scalars_step_us": step_spread(step_packer, 40), "exact_outputs_step_us": spread,
                                "view_outputs_step_us": views, "configs": extra_configs(dev)}
+            result["extra"]["call_a_plus_call_b"] = call_a_plus_call_b(ffa, dev)
             torch.cuda.empty_cache()        # (the cascades above leave a zoo of cached block sizes behind)
             result["extra"]["two_samples_per_gpu"] = two_samples_per_gpu(ffa, dev, F, P, d, args.p_change, args.seed,
                                                                          max(20, min(args.steps, 100)), 10)
@@ -711,6 +712,52 @@ def cascade(ffa, dev, F, P, d, p_change, thr, pre, post, heads, kv_heads, num, m
                                       "merge Nv rows read; prune K + 2 x L_out rows",
             "hbm_frac": bytes_alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
             "hbm_frac_back_to_back": bytes_alg / (us_b2b * 1e-6) / 1e9 / HBM_PEAK_GBS}
+
+
+def call_a_plus_call_b(ffa, dev, reps=100, rounds=2):
+    """What the adapters in framefusion_amd/models issue at layer 0 of a prefill in the threshold regime: call A (merge), then call B
+    with the decoder's residual add fused in (rows = T(attn_out + residual), modeling_qwen2.py:64-67) - LLaVA-Video-7B layout,
+    prefills back to back, host included; the one-launch kernel (call B through its sums instance) against the three launches,
+    same process, alternating."""
+    from framefusion_amd.synth import video_tokens, rotary_tables
+    F, P, d, pre, post = 64, 210, 3584, 14, 20
+    h0, pt = video_tokens(F, P, d, p_change=0.5, sigma=SIGMA, sigma_hi=1.6, seed=1234, pre=pre, post=post, dtype=torch.bfloat16, device=str(dev))
+    L = h0.shape[1]
+    pe0 = rotary_tables(L, HEAD_DIM, torch.bfloat16, device=str(dev))
+    ff = ffa.FrameFusion(COST, THRESHOLD, 0.02)
+    attn, calls = {}, []
+
+    def prefill():
+        ff.prepare(pt, P, pre, pre + F * P - 1, F * P, L)
+        h, pe, _ = ff(h0, list(pe0), None)
+        calls[:] = [f"A:{L}->{h.shape[1]}" + ("*" if ff.last_call["one_launch"] else "")]
+        n = h.shape[1]
+        if n not in attn:
+            attn[n] = torch.randn(1, n, d, device=dev, dtype=torch.bfloat16) * 0.1
+        out, _, _ = ff(attn[n], pe, None, None, residual=h)
+        calls.append(f"B:{n}->{out.shape[1]}" + ("*" if ff.last_call["one_launch"] else ""))
+    us = {True: [], False: []}
+    seen = {}
+    was = ffa.FrameFusion.one_launch
+    try:
+        for _ in range(rounds):
+            for one in (True, False):
+                ffa.FrameFusion.one_launch = one
+                for _ in range(20):
+                    prefill()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    prefill()
+                torch.cuda.synchronize()
+                us[one].append((time.perf_counter() - t0) / reps * 1e6)
+                seen[one] = list(calls)
+    finally:
+        ffa.FrameFusion.one_launch = was
+    return {"workload": "LLaVA-Video-7B layout [1, 14+64x210+20, 3584] bf16, p_change=0.5: call A, then call B with residual=, per prefill, "
+                        "back to back (* = went out as the one-launch kernel)",
+            "calls_default": seen[True], "calls_three_launches": seen[False],
+            "us_per_prefill_default": us[True], "us_per_prefill_three_launches": us[False]}
 
 
 def extra_configs(dev):
