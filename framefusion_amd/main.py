@@ -426,18 +426,12 @@ class FrameFusion(nn.Module):
         return s, ptr
 
     @staticmethod
-    def _aux_for_positions(position_embeddings, L: int, L_cap: int):
-        """Describe the position container for K4 (main.py:142-178): returns
-        (sources, outputs, rebuild(L_out) -> new container)."""
+    def _position_outputs(position_embeddings, L_cap: int):
+        """The OUTPUT half of `_aux_for_positions`: (outputs, rebuild(L_out) -> new container) for a container that has been
+        looked at already (a merge call whose outputs are sized a second time, to the l_out of the result block)."""
         if type(position_embeddings) == list:
-            assert len(position_embeddings) == 2
             a, b = position_embeddings
             shape = a.shape
-            for t in (a, b):
-                if t.ndim not in (3, 4) or t.shape[-2] != L:
-                    raise FrameFusionHipError(f"position embedding of shape {tuple(t.shape)} does not have "
-                                              f"{L} tokens on its second-to-last axis")
-            src_a, src_b = _token_dense(a), _token_dense(b)       # (tensors, or _Strided wrappers of a and b themselves)
             out_shape = shape[:-2] + (L_cap, shape[-1])
             if b.shape == shape and b.dtype == a.dtype:
                 both = torch.empty((2,) + out_shape, dtype=a.dtype, device=a.device)     # cos and sin: one allocation
@@ -451,13 +445,30 @@ class FrameFusion(nn.Module):
                 for x in (0, 1):
                     position_embeddings[x] = outs[x].narrow(ax, 0, L_out)
                 return position_embeddings
+            return outs, rebuild
+        t = position_embeddings
+        out = torch.empty(t.shape[0], L_cap, dtype=t.dtype, device=t.device)
+        return [out], (lambda L_out: out.narrow(1, 0, L_out))
+
+    @staticmethod
+    def _aux_for_positions(position_embeddings, L: int, L_cap: int):
+        """Describe the position container for K4 (main.py:142-178): returns
+        (sources, outputs, rebuild(L_out) -> new container)."""
+        if type(position_embeddings) == list:
+            assert len(position_embeddings) == 2
+            a, b = position_embeddings
+            for t in (a, b):
+                if t.ndim not in (3, 4) or t.shape[-2] != L:
+                    raise FrameFusionHipError(f"position embedding of shape {tuple(t.shape)} does not have "
+                                              f"{L} tokens on its second-to-last axis")
+            src_a, src_b = _token_dense(a), _token_dense(b)       # (tensors, or _Strided wrappers of a and b themselves)
+            outs, rebuild = FrameFusion._position_outputs(position_embeddings, L_cap)
             return [src_a, src_b], outs, rebuild
         if type(position_embeddings) == torch.Tensor:
             if position_embeddings.ndim != 2:
                 raise NotImplementedError("Only support 2D position embeddings")
-            t = position_embeddings.contiguous()
-            out = torch.empty(t.shape[0], L_cap, dtype=t.dtype, device=t.device)
-            return [t], [out], (lambda L_out: out.narrow(1, 0, L_out))
+            outs, rebuild = FrameFusion._position_outputs(position_embeddings, L_cap)
+            return [position_embeddings.contiguous()], outs, rebuild
         raise NotImplementedError("Only support list or tensor for position embeddings")
 
     @staticmethod
@@ -733,6 +744,18 @@ class FrameFusion(nn.Module):
         _PACK_I64.pack_into(call, 56, L_cap)                           # ff_merge_call_t.L_cap
         out = torch.empty((1, L_cap, d), dtype=dtype, device=device)
         ptype_out = torch.empty((1, L_cap), dtype=torch.int64, device=device)
+        if st.get("n_aux") and st.get("mask_cap") is None:
+            # sized a second time (the guessed length did not come true, and somebody - the GPU, idle, or a kernel with the rows
+            # in its registers - is waiting): the sources are described in the call block already; new destinations only
+            outs, rebuild = self._position_outputs(st["position_embeddings"], L_cap)
+            size, at = _lib.AUX_ENTRY.size, _lib.MERGE_CALL_AUX_OFFSET + 8
+            _PACK_PTR.pack_into(call, at, ptype_out.data_ptr())
+            for x, o in enumerate(outs):
+                _PACK_PTR.pack_into(call, at + size * (x + 1), o.data_ptr())
+            _PACK_PTR.pack_into(call, 16, out.data_ptr())
+            _PACK_I64.pack_into(call, _lib.MERGE_CALL_AUX_OFFSET - 8, st["n_aux"])
+            st.update(out=out, ptype_out=ptype_out, rebuild=rebuild, L_cap=L_cap)
+            return
         srcs, outs, rebuild = self._aux_for_positions(st["position_embeddings"], L, L_cap)
         _lib.AUX_ENTRY.pack_into(call, _lib.MERGE_CALL_AUX_OFFSET, ptype.data_ptr(), ptype_out.data_ptr(), 8, 1, 0)    # patch types
         n_aux = 1 + sc.put_aux(call, _lib.MERGE_CALL_AUX_OFFSET + _lib.AUX_ENTRY.size, zip(srcs, outs), L, room=_lib.MAX_AUX - 1)
@@ -748,7 +771,7 @@ class FrameFusion(nn.Module):
             _lib.MASK_TRIPLE.pack_into(call, _lib.MERGE_CALL_MASK_OFFSET, mask_in.data_ptr(), mask_cap.data_ptr(), mask_in.element_size())
         else:
             _lib.MASK_TRIPLE.pack_into(call, _lib.MERGE_CALL_MASK_OFFSET, 0, 0, 0)
-        st.update(out=out, ptype_out=ptype_out, srcs=srcs, rebuild=rebuild, mask_cap=mask_cap, L_cap=L_cap)
+        st.update(out=out, ptype_out=ptype_out, srcs=srcs, rebuild=rebuild, mask_cap=mask_cap, L_cap=L_cap, n_aux=n_aux)
 
     def _merge_complete(self, st, rc, confirm=None):
         """The result block -> the state machine of main.py:112-138 and the returned views.  `confirm`: the crossing that finishes
