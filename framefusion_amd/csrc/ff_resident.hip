@@ -29,6 +29,9 @@
 //      fold when there are at most three (tensor, slice) pairs, else handed out by an LDS counter, the wave without rows first),
 //      member / keep / dst, next order + inverse.
 //
+// Fold while waiting: a data wave that finds no mail with the result at the end of the plan does the fold's arithmetic at once (pass 1:
+// finished rows parked in the home of each run's last row) and only stores when the outputs are known (pass 2); see C. below.
+//
 // A third instance (kAdd) takes call B of a decoder layer with the residual add fused in: its rows are the sums T(hidden + addend),
 // two requests per row through registers the compiler counts (phase A below); everything behind phase A sees resident sums.
 //
@@ -829,6 +832,11 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
         members_total = total >> 16;
         if (members_total != (total & 0xffff)) members_total = -1;          // (the two views of the member set disagree: reported)
     }
+    // (is a mail that holds the result in already?  one look, answered by the time the barrier below is passed: see C.)
+    if (tid == 0) {
+        const unsigned long long v = wants_mail ? __hip_atomic_load(&a.bar->mail_tag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        bcast[12] = (long long)(v >> 2) == (long long)a.seq ? (int)(v & 3ull) : 0;
+    }
     __syncthreads();                                         // #7
     stamp[3] = wall_clock64() - stamp0;                       // member bits by slot and position, prefix sums
     // (the plan and the arithmetic of the published result must agree: an internal check - the result block has left, so a
@@ -857,6 +865,90 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
         }
     }
     if (a.mail && !wants_mail) aux_n = 0;
+    // ---- The outputs are not there yet (a threshold-branch call with exactly sized outputs: the host is allocating l_out rows
+    // right now, ~20 us): the fold's ARITHMETIC does not need them.  Pass 1 walks the rows as the fold proper does and parks the
+    // finished row of every run in the home of the run's LAST row (a static place: the row before the one that opens the next
+    // run); the run that is open at the end of the segment - with the rows it continues with in the next segments - ends in
+    // tail_x.  Pass 2, once the outputs are known, only stores.  (The wave that relays the mail keeps its hands free.)
+    // (not in the instance whose rows are sums: its register file is full)
+    const bool two_pass = !kAdd && wants_mail && bcast[12] == 0 && data_wave && !relay_wave && n > 0;
+    uint4 tail_x = make_uint4(0, 0, 0, 0);
+    int tail_lane = -1;                                      // lane (= row of my segment) of the open run's anchor; -1: none
+    if constexpr (!kAdd) if (two_pass) {
+        const bool mbit = lane < n && slotbit(s0 + lane);
+        const unsigned long long memw = __ballot(mbit);
+        float acc[E];
+        int open_n = 0;
+        auto finished = [&]() -> uint4 {                     // (as flush() below, without the store)
+            if (open_n > 0) {
+                float o[E];
+                const float r = 1.0f / A::rnd((float)(open_n + 1));
+#pragma unroll
+                for (int e = 0; e < E; ++e) o[e] = acc[e] * r;
+                return A::pack_rne(o);
+            }
+            return A::pack(acc);
+        };
+        auto home = [&](int r) -> uint4& { return r < RL ? *lrow(r) : v[r - RL]; };       // r: static
+#pragma unroll
+        for (int r = 0; r < RL + RV; ++r) {
+            if (r < n) {
+                if (!((memw >> r) & 1ull)) {
+                    if (tail_lane >= 0 && open_n > 0) { if (r > 0) home(r > 0 ? r - 1 : 0) = finished(); }
+                    tail_lane = r;
+                    open_n = 0;
+                    A::unpack(home(r), acc);
+                } else if (tail_lane >= 0) {                 // (leading members belong to the previous workgroup's run)
+                    float y[E];
+                    A::unpack(home(r), y);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) acc[e] = A::rnd(acc[e] + y[e]);
+                    ++open_n;
+                }
+            }
+        }
+        if (tail_lane >= 0) {
+            // the open run goes on in the following segments: those rows come from L2 / the Infinity Cache, a few at a time (the
+            // VGPR rows are all alive here - they hold parked results - and the wait for the host hides the round trips)
+            for (int t = s1; t < nv;) {
+                const int tt = t + lane;
+                const bool mb = tt < nv && slotbit(tt);
+                const unsigned long long mw = __ballot(mb);
+                const int run = mw == ~0ull ? kWave : __ffsll((long long)~mw) - 1;
+                int iw = 0;
+                if (lane < run) {
+                    if constexpr (kHint) iw = pos_hint(tt);
+                    else iw = a.order[tt];
+                }
+                constexpr int kB = kAdd ? 2 : 4;
+                for (int u = 0; u < run; u += kB) {
+                    uint4 x[kB], xa[kAdd ? kB : 1];
+#pragma unroll
+                    for (int z = 0; z < kB; ++z) {
+                        if (u + z < run) {
+                            const uint32_t so = (uint32_t)__builtin_amdgcn_readlane(iw, u + z) * rb;
+                            x[z] = buf_load16s(hres, vcol, so);
+                            if constexpr (kAdd) xa[z] = buf_load16s(make_rsrc(a.addend, (uint32_t)L * rb), vcol, so);
+                        }
+                    }
+#pragma unroll
+                    for (int z = 0; z < kB; ++z) {
+                        if (u + z < run) {
+                            float y[E];
+                            if constexpr (kAdd) x[z] = add16<DT>(x[z], xa[z]);
+                            A::unpack(x[z], y);
+#pragma unroll
+                            for (int e = 0; e < E; ++e) acc[e] = A::rnd(acc[e] + y[e]);
+                            ++open_n;
+                        }
+                    }
+                }
+                if (run < kWave) break;
+                t += kWave;
+            }
+            tail_x = finished();
+        }
+    }
     if (wants_mail) {
         if (relay_wave && relay_state != 1) {
             const long long t0 = wall_clock64();
@@ -1052,7 +1144,40 @@ __global__ __launch_bounds__(kResThreads) void k_merge_resident(const ResArgs a)
 #ifdef FF_RES_WGSTAMPS
     long long wg_waited = 0;
 #endif
-    if (folded && data_wave) {
+    if (!kAdd && folded && data_wave && two_pass) {
+        // pass 2: every run's finished row from where pass 1 parked it to its output row
+        const __amdgpu_buffer_rsrc_t ores = make_rsrc(out_ptr, (uint32_t)(out_cap * (long long)rb));
+        const int js = s0 + lane;
+        const bool mbit = lane < n && slotbit(js);
+        const unsigned long long memw = __ballot(mbit);
+        int dv = 0;
+        if (lane < n && !mbit) {
+            int i;
+            if constexpr (kHint) i = pos_hint(js);
+            else i = a.order[js];
+            dv = i - members_before_pos(i);
+        }
+        int cur = -1;
+#pragma unroll
+        for (int r = 0; r < RL + RV; ++r) {
+            if (r < n) {
+                if (!((memw >> r) & 1ull)) cur = __builtin_amdgcn_readlane(dv, r);
+                if (r + 1 < n && !((memw >> (r + 1)) & 1ull) && cur >= 0)
+                    buf_store16s<2>(ores, vcol, (uint32_t)cur * rb, r < RL ? *lrow(r) : v[r - RL]);
+            }
+        }
+        if (tail_lane >= 0) buf_store16s<2>(ores, vcol, (uint32_t)__builtin_amdgcn_readlane(dv, tail_lane) * rb, tail_x);
+        // non-visual rows (kept as they are): row q of the order's tail goes to workgroup q mod G
+        const int n_tail = L - nv;
+        for (int qq = bid; qq < n_tail; qq += G) {
+            int i;
+            if constexpr (kHint) i = qq < pre ? qq : qq + nv;
+            else i = a.order[nv + qq];
+            uint4 x = buf_load16s<2>(hres, vcol, (uint32_t)i * rb);
+            if constexpr (kAdd) x = add16<DT>(x, buf_load16s<2>(make_rsrc(a.addend, (uint32_t)L * rb), vcol, (uint32_t)i * rb));
+            buf_store16s<2>(ores, vcol, (uint32_t)(i - members_before_pos(i)) * rb, x);
+        }
+    } else if (folded && data_wave) {
         const __amdgpu_buffer_rsrc_t ores = make_rsrc(out_ptr, (uint32_t)(out_cap * (long long)rb));
         // member bits of my slots and of the 64 behind them; output row of every anchor (by lane)
         const int js = s0 + lane;
